@@ -1,0 +1,179 @@
+"""Pin the oracle against everything the reference's own artifacts can pin.
+
+The reference has no tests; these known-answer checks come from its results.csv files, its demo NIfTI
+volumes and its README/demo tables.  What they cannot reach (the ultralytics model arithmetic) is
+"parity unpinned" and says so in oracle/__init__.py and DESIGN.md.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prepost as P
+from oracle import yolo11seg as Y
+
+
+# ----------------------------------------------------------------------------- KAT #1: LR schedule, 25 runs
+def test_lr_schedule_matches_all_25_results_csv(golden_dir):
+    runs = json.loads((golden_dir / "lr_kat.json").read_text())
+    assert len(runs) == 25
+    worst = 0.0
+    for r in runs:
+        assert r["epochs"] == 50
+        assert r["lr_pg0"] == r["lr_pg1"] == r["lr_pg2"]  # bias warm-up forced to 0 ⇒ all groups equal
+        nb = r["nb_from_jpg"]
+        # independent recovery of nb from the epoch-1 LR: lr = lr0*lf(0)*(nb-1)/max(round(3nb),100)
+        cands = [n for n in range(20, 400) if abs(P.lr_schedule(0, n) - r["lr_pg0"][0]) <= 3.5e-6 * r["lr_pg0"][0]]
+        assert nb in cands
+        for e, lr in enumerate(r["lr_pg0"]):
+            want = P.lr_schedule(e, nb)
+            worst = max(worst, abs(want - lr) / lr)
+    assert worst <= 3.5e-6, worst
+
+
+def test_iters_per_epoch_table(golden_dir):
+    runs = {r["run"]: r["nb_from_jpg"] for r in json.loads((golden_dir / "lr_kat.json").read_text())}
+    base = "trains/Base/FLAIR_P50c_5folds_50epochs"
+    assert [runs[f"{base}/axial/fold{k}"] for k in range(1, 6)] == [112, 119, 116, 115, 113]
+    assert [runs[f"{base}/coronal/fold{k}"] for k in range(1, 6)] == [163, 174, 170, 165, 162]
+    assert [runs[f"{base}/sagital/fold{k}"] for k in range(1, 6)] == [117, 124, 121, 118, 118]
+
+
+# ----------------------------------------------------------------------------- KAT #3: fold assignment
+def test_fold_assignment():
+    sizes = [sum(P.calcular_fold(f"P{i}") == k for i in range(1, 54)) for k in range(1, 6)]
+    assert sizes == [11, 11, 11, 10, 10]
+    assert P.calcular_fold("P18") == 2 and P.calcular_fold("P39") == 4  # demo/README_demo.md:74-75
+
+
+# ----------------------------------------------------------------------------- KAT #4: demo volumes
+def test_demo_volume_facts(demo_volumes):
+    m39, m18 = demo_volumes["P39_mask"], demo_volumes["P18_mask"]
+    assert m39.shape == m18.shape == (182, 218, 182)
+    assert int(m39.sum()) == 72872 and int(m18.sum()) == 770
+    for m, want in ((m39, [101, 147, 113]), (m18, [28, 21, 23])):
+        got = [sum(bool(np.any(P.take_slice(m, pl, i) > 0)) for i in range(m.shape[P.PLANE_AXIS[pl]]))
+               for pl in ("axial", "coronal", "sagital")]
+        assert got == want
+    assert demo_volumes["P39_flair_max"] == 1513 and demo_volumes["P18_flair_max"] == 290
+
+
+# ----------------------------------------------------------------------------- KAT #2: geometry round trip
+@pytest.mark.parametrize("plano", ["axial", "coronal", "sagital"])
+def test_extract_then_normalise_is_identity_on_volume_coordinates(demo_volumes, plano):
+    """extraer_dataset writes corte.T with origin='lower'; generar_predicciones applies cv2.flip(pred.T, 1).
+    A perfect per-slice prediction must therefore land back on the GT voxels (validar_corte shape table)."""
+    gt = demo_volumes["P39_mask"]
+    slices = {}
+    for i in range(0, gt.shape[P.PLANE_AXIS[plano]], 7):
+        corte = P.take_slice(gt, plano, i)
+        png = corte.T[::-1]  # what lands on disk: [W-as-rows flipped, H]
+        pred = (png > 0).astype(np.uint8)  # a perfect model output in image coordinates
+        slices[i] = P.normalizar_prediccion(pred)
+        P.validar_corte(i, (slices[i] > 0).astype(np.float32), gt.shape, plano)
+    vol = P.reconstruir_volumen(slices, gt.shape, plano)
+    for i in slices:
+        assert np.array_equal(P.take_slice(vol, plano, i), P.take_slice(gt, plano, i).astype(np.float32))
+
+
+def test_validar_corte_rejects_wrong_shape_and_index():
+    with pytest.raises(ValueError):
+        P.validar_corte(182, np.zeros((182, 218)), (182, 218, 182), "axial")
+    with pytest.raises(ValueError):
+        P.validar_corte(0, np.zeros((218, 182)), (182, 218, 182), "axial")
+    P.validar_corte(0, np.zeros((218, 182)), (182, 218, 182), "sagital")
+
+
+def test_consensus_and_dice_with_gt_as_prediction(demo_volumes):
+    gt = demo_volumes["P39_mask"].astype(np.float64)
+    assert P.DSC(gt, gt) == 1.0
+    cons = P.combinar_volumenes(gt, gt, np.zeros_like(gt), umbral=2)
+    assert cons.dtype == np.uint8 and np.array_equal(cons, gt.astype(np.uint8))
+    assert int(P.combinar_volumenes(gt, gt, np.zeros_like(gt), umbral=3).sum()) == 0
+    shifted = np.roll(gt, 1, axis=0)
+    d = P.dsc_unrounded(gt, shifted)
+    assert 0.3 < d < 1.0 and P.DSC(gt, shifted) == round(d, 3)
+    assert P.DSC(np.zeros_like(gt), np.zeros_like(gt)) == 0.0  # 0/(0+1e-8)
+
+
+# ----------------------------------------------------------------------------- model: the only pins there are
+@pytest.mark.parametrize("scale,nc,want", [("n", 80, 2876848), ("n", 1, 2842803), ("s", 80, 10113248), ("s", 1, 10082675)])
+def test_param_counts(scale, nc, want):
+    assert Y.count_params(Y.build(scale, nc)) == want
+
+
+def test_output_shapes_and_fused_equals_unfused():
+    m = Y.randomize_bn_stats(Y.build("n", 1)).eval()
+    x = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        y0, p0 = m(x)
+        y1, p1 = Y.fuse_conv_bn(m)(x)
+    assert y0.shape == (1, 37, 8 * 12 + 4 * 6 + 2 * 3) and p0.shape == (1, 32, 16, 24)
+    assert torch.allclose(y0, y1, rtol=1e-4, atol=1e-4) and torch.allclose(p0, p1, rtol=1e-4, atol=1e-4)
+
+
+def test_checkpoint_key_names_follow_ultralytics_convention():
+    keys = set(Y.build("n", 1).state_dict())
+    for k in ("model.0.conv.weight", "model.2.m.0.cv1.bn.running_var", "model.6.m.0.m.1.cv2.conv.weight",
+              "model.10.m.0.attn.qkv.conv.weight", "model.10.m.0.attn.pe.conv.weight", "model.10.m.0.ffn.1.bn.bias",
+              "model.23.cv2.0.2.bias", "model.23.cv3.1.0.0.conv.weight", "model.23.cv3.2.2.weight",
+              "model.23.cv4.0.2.weight", "model.23.proto.upsample.bias", "model.23.proto.cv3.conv.weight",
+              "model.23.dfl.conv.weight"):
+        assert k in keys, k
+
+
+# ----------------------------------------------------------------------------- pre/post restatements
+@pytest.mark.parametrize("hw,lb", [((218, 182), (640, 544)), ((182, 182), (640, 640)), ((182, 218), (544, 640)),
+                                    ((640, 640), (640, 640))])
+def test_letterbox_shapes(hw, lb):
+    img = np.zeros(hw + (3,), np.uint8)
+    assert P.letterbox(img).shape[:2] == lb  # 640×544 / 640×640 / 544×640
+
+
+def test_letterbox_pad_value_and_content():
+    img = np.full((218, 182, 3), 7, np.uint8)
+    out = P.letterbox(img)
+    assert (out[:, :5] == 114).all() and (out[:, -5:] == 114).all() and (out[:, 5:-5] == 7).all()
+
+
+def test_linear_resize_constant_and_ramp():
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :], (10, 1))
+    up = P.cv_resize_linear_u8(ramp, (200, 20))
+    assert up.shape == (20, 200) and up[0, 0] == 0 and up[0, -1] == 198
+    assert (np.diff(up[0].astype(int)) >= 0).all()
+    assert np.array_equal(P.cv_resize_linear_u8(ramp, (100, 10)), ramp)
+
+
+def test_nearest_resize_index_rule():
+    src = np.arange(640 * 544, dtype=np.int64).reshape(640, 544)
+    out = P.cv_resize_nearest(src, (182, 218))
+    sy, sx = P.nearest_index_table(218, 640), P.nearest_index_table(182, 544)
+    assert out.shape == (218, 182) and np.array_equal(out, src[sy][:, sx])
+    assert sx[0] == 0 and sx[-1] == int(np.floor(181 * 544 / 182)) and sx.max() <= 543
+
+
+def test_nms_greedy_semantics():
+    boxes = torch.tensor([[0, 0, 10, 10], [0, 0, 10, 10.5], [20, 20, 30, 30], [0, 0, 10, 30]], dtype=torch.float32)
+    scores = torch.tensor([0.9, 0.8, 0.8, 0.95])
+    keep = P.nms_greedy(boxes, scores, 0.7).tolist()
+    assert keep == [3, 0, 2]  # box1 (IoU .952 with box0) suppressed; tie 1-vs-2 resolved by index (stable sort)
+    assert P.nms_greedy(boxes[:0], scores[:0], 0.7).numel() == 0
+    # IoU exactly at threshold is kept ("> thr" suppresses)
+    b = torch.tensor([[0, 0, 10, 10], [0, 0, 10, 7]], dtype=torch.float32)
+    assert P.nms_greedy(b, torch.tensor([0.9, 0.8]), 0.7).tolist() == [0, 1]
+
+
+def test_gray_colormap_lut_matches_matplotlib():
+    cm = pytest.importorskip("matplotlib.cm")
+    lut = cm.gray(np.arange(256), bytes=True)[:, 0]
+    assert np.array_equal(lut, P.GRAY_LUT)
+    x = np.linspace(0, 1, 5001)
+    assert np.array_equal(cm.gray(x, bytes=True)[:, 0], P.GRAY_LUT[np.clip((x * 256).astype(int), 0, 255)])
+
+
+def test_slice_to_png_array_shape_and_range(demo_volumes):
+    fl = demo_volumes["P39_flair"]
+    img = P.slice_to_png_array(P.take_slice(fl, "axial", 90))
+    assert img.shape == (218, 182, 3) and img.dtype == np.uint8 and img.max() == 255 and img.min() == 0
+    assert (img[..., 0] == img[..., 1]).all()
