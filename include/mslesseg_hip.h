@@ -1,0 +1,149 @@
+/*
+ * mslesseg_hip.h — C ABI of libmslesseg_hip.so: hand-written HIP kernels (gfx950 / CDNA4) for the
+ * YOLO11-seg predict + train hot path that the reference reaches through `ultralytics.YOLO`.
+ *
+ * What this replaces in the reference (there is NO native/FFI interface in the reference; its boundary to
+ * the arithmetic is five Python call sites into ultralytics — SURVEY.md §8b):
+ *   B1  YOLO(model_path)                      yolo_mslesseg/utils/utils.py:232-237
+ *   B2  model.train(data=..., epochs=..., …)  yolo_mslesseg/scripts/train.py:358-366
+ *   B3  model(img_array, verbose=False)[0]    yolo_mslesseg/scripts/generar_predicciones.py:114
+ *   B4  .masks.data.cpu().numpy()             yolo_mslesseg/scripts/generar_predicciones.py:118-120
+ *   and the per-slice post-processing + volume steps that consume B4:
+ *       combinar_predicciones / normalizar_prediccion   generar_predicciones.py:123-140
+ *       reconstruir_volumen                             scripts/reconstruir_volumen.py:199-213
+ *       combinar_volumenes                              scripts/generar_consenso.py:106-109
+ *       DSC                                             utils/utils.py:455-460
+ * The Python host (yolo-mslesseg_amd/mslesseg_amd, exposed as a drop-in `ultralytics` module) is the only
+ * caller; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocations); no torch types here.
+ *   - All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); nothing synchronises,
+ *     allocates or frees, so a whole program can be captured into a hipGraph (msl_graph_*).
+ *   - Return 0 on success, a negative MSL_E* code otherwise; msl_last_error() gives the text.  Nothing throws.
+ *   - Thread-compatible, not thread-safe.
+ *   - Activations are NHWC ("pixel-major"): element (n,y,x,c) of a tensor view lives at
+ *       base + ((n*H + y)*W + x)*cs + co + c        (cs = channel stride of the underlying buffer,
+ *                                                    co = channel offset of this view inside it)
+ *     so a Concat is just several producers writing different `co` of one buffer.
+ *   - dtype: MSL_BF16 (bf16 storage, fp32 accumulate on v_mfma_f32_16x16x32_bf16) or
+ *            MSL_F32  (fp32 storage, exact fp32 on v_mfma_f32_16x16x4_f32 — the parity mode).
+ */
+#ifndef MSLESSEG_HIP_H
+#define MSLESSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSL_ABI_VERSION 1
+
+enum { MSL_BF16 = 0, MSL_F32 = 1 };
+
+enum {
+  MSL_OK = 0,
+  MSL_EINVAL = -22,   /* bad descriptor (shape / alignment / unsupported combination) */
+  MSL_ELAUNCH = -5,   /* hipLaunch / runtime error */
+  MSL_ENOSYS = -38    /* unknown op kind */
+};
+
+/* Op kinds.  Slot meaning of msl_op.{p,i,f} per kind is documented beside each enumerator. */
+enum {
+  /* Implicit-GEMM convolution on MFMA: y = act(conv(x, w) + bias) [+ res].
+   * p: 0 x, 1 w packed [Cout_pad][Kpad] (K = (ky,kx,ci), zero padded; dtype = op dtype), 2 bias f32[Cout_pad],
+   *    3 res (or NULL; same dtype as x), 4 y
+   * i: 0 N,1 H,2 W,3 Cin,4 Ho,5 Wo,6 Cout,7 k,8 stride,9 pad,10 x_cs,11 x_co,12 y_cs,13 y_co,14 res_cs,15 res_co,
+   *    16 K(=k*k*Cin),17 Kpad,18 act(0 none,1 SiLU),19 out_f32(0/1),20 store_mode(0 plain, 1 pixel-shuffle 2x2:
+   *    GEMM channel q*C+c with q=dy*2+dx goes to pixel (2y+dy,2x+dx) channel c, C=Cout/4 — ConvTranspose2d k2 s2),
+   *    21 Cout_pad (multiple of 16) */
+  MSL_OP_CONV = 1,
+  /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
+   * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y
+   * i: 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout(16|32),12 y_cs,13 y_co,18 act */
+  MSL_OP_STEM = 2,
+  /* Depthwise 3x3 stride-1 pad-1: y = act(dw(x) + bias) [+ res].
+   * p: 0 x, 1 w f32 [9][C], 2 bias f32[C], 3 res|NULL, 4 y
+   * i: 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 y_cs,13 y_co,14 res_cs,15 res_co,18 act,
+   *    22 gsz,23 gstride,24 goff : input channel of output channel c is (c/gsz)*gstride + goff + c%gsz
+   *    (gsz=0 ⇒ identity) — lets Attention.pe read the v part of the qkv buffer in place. */
+  MSL_OP_DWCONV = 3,
+  /* SPPF pooling: from the C-channel view at co, write the 5x5, 9x9, 13x13 stride-1 max pools
+   * (= three chained 5x5 pools with -inf padding) at co+C, co+2C, co+3C of the same buffer.
+   * p: 0 buf ; i: 0 N,1 H,2 W,3 C,10 cs,11 co */
+  MSL_OP_SPPF_POOL = 4,
+  /* Nearest 2x upsample of a view into another view.  p: 0 x, 4 y ; i: 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 y_cs,13 y_co */
+  MSL_OP_UPSAMPLE2X = 5,
+  /* PSA attention core: qkv view laid out per head as [q(kd) | k(kd) | v(hd)]; out[n,i,h*hd+d] =
+   * sum_j softmax_j(scale * q_i.k_j) v_j[d].   p: 0 qkv, 4 y ; i: 0 N,1 H,2 W,3 heads,4 kd,5 hd,10 x_cs,11 x_co,
+   * 12 y_cs,13 y_co ; f: 0 scale */
+  MSL_OP_ATTENTION = 6,
+  /* Head decode: DFL softmax-expectation, dist2bbox*stride, sigmoid class score, gather mask coefficients.
+   * p: 0 box f32 [N,HW,64], 1 cls f32 [N,HW,nc], 2 coef f32 [N,HW,nm], 4 pred f32 [N,A,MSL_PRED_STRIDE]
+   * i: 0 N,1 H,2 W,3 nc,4 nm,5 anchor_offset,6 A ; f: 0 stride */
+  MSL_OP_HEAD_DECODE = 7,
+  /* Per-image NMS (conf filter → stable sort desc → greedy IoU>thr suppress → first max_det).
+   * p: 0 pred f32 [N,A,MSL_PRED_STRIDE], 1 keep_idx i32 [N,max_det], 2 keep_cnt i32 [N], 3 det f32 [N,max_det,MSL_PRED_STRIDE]
+   *      (xyxy, conf, cls, coeffs of the kept rows, in keep order)
+   * i: 0 N,6 A,7 max_det ; f: 0 conf_thres, 1 iou_thres */
+  MSL_OP_NMS = 8,
+  /* Low-resolution instance logits: lowres[n,d,y,x] = crop_d(y,x) * sum_c det[n,d].coef[c]*proto[n,y,x,c]
+   * p: 0 proto (op dtype) [N,mh,mw,nm] view, 1 det, 2 keep_cnt, 4 lowres f32 [N,max_det,mh,mw]
+   * i: 0 N,1 mh,2 mw,4 nm,7 max_det,10 x_cs,11 x_co, 8 Hlb, 9 Wlb */
+  MSL_OP_MASK_LOWRES = 9,
+  /* Boundary masks (B4): bilinear (align_corners=False) upsample of lowres to (Hlb,Wlb), > 0 → 1.0f/0.0f
+   * p: 0 lowres, 2 keep_cnt, 4 masks f32 [N,max_det,Hlb,Wlb] ; i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb */
+  MSL_OP_MASK_UPSAMPLE = 10,
+  /* Fused reference post-processing (combinar_predicciones + normalizar_prediccion): OR over instances of the
+   * upsampled mask sampled at OpenCV-INTER_NEAREST positions of the original (H0,W0) grid, transposed and
+   * flipped, times 255.   p: 0 lowres, 2 keep_cnt, 3 ytab i32[H0], 5 xtab i32[W0], 4 out u8 [N,W0,H0]
+   * i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb,10 H0,11 W0 */
+  MSL_OP_MASK_MERGE = 11,
+  /* LetterBox: fixed-point INTER_LINEAR resize (OpenCV 8-bit scheme) + constant border + BGR→RGB.
+   * p: 0 src u8 [N,H0,W0,Cs], 1 xtab i32 [Wn,4]=(sx0,sx1,a0,a1), 2 ytab i32 [Hn,4]=(sy0,sy1,b0,b1), 4 dst u8 [N,Hlb,Wlb,3]
+   * i: 0 N,1 H0,2 W0,3 Cs(1|3),4 Hn,5 Wn,6 top,7 left,8 Hlb,9 Wlb,10 pad_value,11 resize(0 ⇒ copy) */
+  MSL_OP_LETTERBOX = 12,
+  /* Volume steps.  INSERT: vol f32 [X,Y,Z] (C order) gets slice `idx` of plane axis from u8 [a,b] image (>0 → 1).
+   * p: 0 img u8 [S,a,b], 1 idx i32[S], 4 vol ; i: 0 S,1 X,2 Y,3 Z,4 axis(2 axial,1 coronal,0 sagittal) */
+  MSL_OP_VOL_INSERT = 13,
+  /* CONSENSUS: out u8 = (a+b+c >= thr).  p: 0 a f32,1 b f32,2 c f32,4 out u8 ; i: 0 n_lo,1 n_hi (n = n_hi<<31|n_lo),2 thr */
+  MSL_OP_VOL_CONSENSUS = 14,
+  /* DICE partial sums: acc u64[3] += (sum gt*pred, sum gt, sum pred) over n voxels (binary volumes).
+   * p: 0 gt u8, 1 pred u8, 4 acc u64[3] ; i: 0 n_lo,1 n_hi */
+  MSL_OP_VOL_DICE = 15
+};
+
+#define MSL_PRED_STRIDE 40 /* floats per anchor row: x,y,w,h | conf | cls | 32 coeffs | 2 pad */
+
+typedef struct msl_op {
+  int32_t kind;
+  int32_t dtype;   /* MSL_BF16 | MSL_F32: storage type of activation tensors touched by this op */
+  void* p[6];
+  int32_t i[26];
+  float f[4];
+} msl_op;
+
+int msl_abi_version(void);
+const char* msl_last_error(void);
+
+/* Validate and enqueue one op on `stream`. */
+int msl_launch(const msl_op* op, void* stream);
+/* Enqueue ops[0..n) in order on `stream` (one host call per forward pass). */
+int msl_run_program(const msl_op* ops, int32_t n, void* stream);
+
+/* hipGraph capture of a program: launch-bound inner loops (batch-1 predict, ~110 small kernels) replay as one graph. */
+int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out);
+int msl_graph_launch(void* graph_exec, void* stream);
+int msl_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on the caller's stream (bench.py measures kernels on the stream they run on). */
+int msl_event_create(void** ev_out);
+int msl_event_record(void* ev, void* stream);
+int msl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+int msl_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

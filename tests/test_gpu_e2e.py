@@ -1,0 +1,307 @@
+"""End-to-end parity of the HIP predict path against the CPU oracle (-m gpu), through the C-ABI.
+
+The oracle's model arithmetic is a restatement of ultralytics 8.3.70 — "parity unpinned" against the reference
+itself; what is asserted here is GPU-path == oracle on identical weights and slices:
+  * fp32 engine: head tensor / protos within 2e-3 abs-rel, kept anchor indices identical, final masks identical
+    up to a handful of threshold pixels, reconstructed-volume Dice within 1e-4 (north_star tolerance);
+  * NMS / mask assembly / merge on a FIXED pre-NMS tensor: bit-exact indices and bytes;
+  * bf16 engine: head tensor within bf16 tolerance of the oracle, Dice reported and bounded.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mslesseg_amd import engine as E  # noqa: E402
+from mslesseg_amd import geometry, graph, hiplib  # noqa: E402
+from mslesseg_amd.hiplib import MSL_BF16, MSL_F32, PRED_STRIDE  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def synth_state(golden_dir):
+    st = torch.load(golden_dir / "synth_n_nc1.pt", map_location="cpu", weights_only=True)
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
+
+
+@pytest.fixture(scope="module")
+def oracle_model(synth_state):
+    from oracle import synth
+
+    torch.set_num_threads(8)
+    return synth.model_from_state(synth_state)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(golden_dir / "e2e_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def eng_f32(synth_state):
+    return E.InferEngine(synth_state, "n", 1, MSL_F32, DEV)
+
+
+@pytest.fixture(scope="module")
+def eng_bf16(synth_state):
+    return E.InferEngine(synth_state, "n", 1, MSL_BF16, DEV)
+
+
+def _img(golden, k):
+    g = golden[f"img{k}"]
+    return np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))
+
+
+def _oracle_forward(oracle_model, img):
+    from oracle import prepost as P
+
+    x = P.preprocess(img)
+    with torch.no_grad():
+        y, proto = oracle_model(x)
+    return x, y, proto
+
+
+def _pred_from_head(y):
+    """oracle [N, 37, A] → engine row layout [N, A, PRED_STRIDE]."""
+    N, _, A = y.shape
+    p = torch.zeros(N, A, PRED_STRIDE)
+    p[..., :5] = y[:, :5].transpose(1, 2)
+    p[..., 6:38] = y[:, 5:].transpose(1, 2)
+    return p
+
+
+# --------------------------------------------------------------------------------------------- network forward
+@pytest.mark.parametrize("k", [0, 2, 3])  # 640x544, 640x640, 544x640 letterboxes
+def test_forward_fp32_matches_oracle(eng_f32, oracle_model, golden, k):
+    img = _img(golden, k)
+    x, y, proto = _oracle_forward(oracle_model, img)
+    plan = eng_f32.predict_batch(torch.from_numpy(img[None]))
+    torch.cuda.synchronize()
+    assert np.array_equal(plan.input.t.view(1, plan.Hlb, plan.Wlb, 3).cpu().numpy()[0].transpose(2, 0, 1),
+                          np.rint(x[0].numpy() * 255).astype(np.uint8))  # letterbox bit-exact
+    got = plan.head_tensor().cpu()
+    assert got.shape == y.shape
+    err = (got - y).abs() / (1.0 + y.abs())
+    assert float(err.max()) < 2e-3, f"head max rel-abs err {float(err.max()):.2e}"
+    gp = plan.proto.torch().float().cpu().permute(0, 3, 1, 2)
+    perr = (gp - proto).abs() / (1.0 + proto.abs())
+    assert float(perr.max()) < 2e-3, f"proto err {float(perr.max()):.2e}"
+
+
+def test_forward_intermediate_layers_fp32(eng_f32, oracle_model, golden):
+    """Layer-by-layer taps localise a wrong kernel: backbone stages, SPPF, C2PSA, neck outputs."""
+    from oracle import prepost as P
+
+    img = _img(golden, 0)
+    x = P.preprocess(img)
+    m = oracle_model.model
+    with torch.no_grad():
+        o0 = m[0](x)
+        o1 = m[1](o0)
+        o2 = m[2](o1)
+        o3 = m[3](o2)
+        o4 = m[4](o3)
+        o6 = m[6](m[5](o4))
+        o8 = m[8](m[7](o6))
+        o9 = m[9](o8)
+        o10 = m[10](o9)
+    plan = eng_f32.predict_batch(torch.from_numpy(img[None]))
+    torch.cuda.synchronize()
+    taps = plan.builder.taps
+    for name, ref in (("model.0", o0), ("model.1", o1), ("model.2.cv2", o2), ("model.3", o3), ("model.4.cv2", o4), ("model.6.cv2", o6),
+                      ("model.8.cv2", o8), ("model.9.cv2", o9), ("model.10.cv2", o10)):
+        got = taps[name].torch().float().cpu().permute(0, 3, 1, 2)
+        err = float(((got - ref).abs() / (1.0 + ref.abs())).max())
+        assert err < 1e-3, f"{name}: err {err:.2e}"
+
+
+def test_forward_bf16_close_to_oracle(eng_bf16, oracle_model, golden):
+    img = _img(golden, 0)
+    _, y, proto = _oracle_forward(oracle_model, img)
+    plan = eng_bf16.predict_batch(torch.from_numpy(img[None]))
+    torch.cuda.synchronize()
+    got = plan.head_tensor().cpu()
+    # boxes (pixels, up to 640) and scores: bf16 activations through ~60 layers
+    rel = float(((got[:, :4] - y[:, :4]).abs() / (8.0 + y[:, :4].abs())).max())
+    sc = float((got[:, 4] - y[:, 4]).abs().max())
+    assert rel < 0.08 and sc < 0.08, (rel, sc)
+    gp = plan.proto.torch().float().cpu().permute(0, 3, 1, 2)
+    assert float((gp - proto).abs().mean() / proto.abs().mean()) < 0.03
+
+
+def test_batch_equals_single(eng_f32, golden):
+    """Whole-volume batching must not change any slice's result (slices 0 and 1 share a shape)."""
+    a, b = _img(golden, 0), _img(golden, 1)
+    p2 = eng_f32.predict_batch(torch.from_numpy(np.stack([a, b])))
+    torch.cuda.synchronize()
+    h2 = p2.head_tensor().cpu().clone()
+    k2 = p2.keep_idx.cpu().clone()
+    c2 = p2.keep_cnt.cpu().clone()
+    for j, im in enumerate((a, b)):
+        p1 = eng_f32.predict_batch(torch.from_numpy(im[None]))
+        torch.cuda.synchronize()
+        assert torch.equal(p1.head_tensor().cpu()[0], h2[j])
+        assert int(p1.keep_cnt.cpu()[0]) == int(c2[j])
+        n = int(c2[j])
+        assert torch.equal(p1.keep_idx.cpu()[0, :n], k2[j, :n])
+
+
+# --------------------------------------------------------------------------------------------- NMS, bit-exact
+def _run_nms(pred, conf=0.25, iou=0.7, max_det=300):
+    N, A, _ = pred.shape
+    pd = pred.contiguous().to(DEV)
+    ki = torch.full((N, max_det), -1, dtype=torch.int32, device=DEV)
+    kc = torch.zeros(N, dtype=torch.int32, device=DEV)
+    det = torch.zeros(N, max_det, PRED_STRIDE, device=DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_NMS, MSL_F32, p=(pd.data_ptr(), ki.data_ptr(), kc.data_ptr(), det.data_ptr()),
+                                 i={0: N, 6: A, 7: max_det}, f=(conf, iou)), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return ki.cpu(), kc.cpu(), det.cpu()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 4])
+def test_nms_bit_exact_on_oracle_head_tensor(oracle_model, golden, k):
+    from oracle import prepost as P
+
+    _, y, _ = _oracle_forward(oracle_model, _img(golden, k))
+    rows, idx = P.non_max_suppression(y, nc=1)
+    assert np.array_equal(idx[0].numpy().astype(np.int32), golden[f"keep{k}"])  # oracle has not drifted
+    ki, kc, det = _run_nms(_pred_from_head(y))
+    n = int(kc[0])
+    assert n == len(idx[0]) and torch.equal(ki[0, :n].long(), idx[0])
+    want = rows[0]
+    assert torch.equal(det[0, :n, :5], want[:, :5]) and torch.equal(det[0, :n, 6:38], want[:, 6:])
+
+
+def test_nms_edge_cases():
+    from oracle import prepost as P
+
+    g = torch.Generator().manual_seed(0)
+    A = 8400
+    # (a) every anchor passes and boxes overlap heavily; (b) exact score ties; (c) nothing passes; (d) exactly one
+    y = torch.zeros(4, 37, A)
+    y[0, :2] = torch.rand(2, A, generator=g) * 600 + 20
+    y[0, 2:4] = torch.rand(2, A, generator=g) * 80 + 20
+    y[0, 4] = torch.rand(A, generator=g) * 0.7 + 0.3
+    y[1, :2] = torch.rand(2, A, generator=g) * 600 + 20
+    y[1, 2:4] = torch.rand(2, A, generator=g) * 200 + 10
+    y[1, 4] = (torch.randint(0, 8, (A,), generator=g).float() + 2) / 10  # 8 distinct scores → many ties
+    y[2, :4] = 50.0
+    y[2, 4] = 0.25  # not > 0.25
+    y[3, :4] = torch.tensor([100.0, 100.0, 40.0, 40.0])[:, None]
+    y[3, 4, 4242] = 0.9
+    y[:, 5:] = torch.rand(4, 32, A, generator=g)
+    rows, idx = P.non_max_suppression(y, nc=1)
+    ki, kc, det = _run_nms(_pred_from_head(y))
+    for n in range(4):
+        c = int(kc[n])
+        assert c == len(idx[n]), (n, c, len(idx[n]))
+        assert torch.equal(ki[n, :c].long(), idx[n]), n
+    assert int(kc[0]) == 300 and int(kc[2]) == 0 and int(kc[3]) == 1
+
+
+# --------------------------------------------------------------------------------------------- masks + merge
+@pytest.mark.parametrize("k", [0, 2, 3])
+def test_masks_and_merge_bit_exact_on_oracle_inputs(oracle_model, golden, k):
+    """Feed the ORACLE's kept rows and protos to the device mask ops: output bytes must equal the oracle's."""
+    from oracle import prepost as P
+
+    img = _img(golden, k)
+    x, y, proto = _oracle_forward(oracle_model, img)
+    rows, _ = P.non_max_suppression(y, nc=1)
+    Hlb, Wlb = x.shape[2:]
+    want_masks = P.postprocess_one(rows[0], proto[0], (Hlb, Wlb))
+    n = len(rows[0])
+    mh, mw = proto.shape[2:]
+    det = torch.zeros(1, 300, PRED_STRIDE)
+    det[0, :n, :6] = rows[0][:, :6]
+    det[0, :n, 6:38] = rows[0][:, 6:]
+    det_d, cnt_d = det.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)
+    proto_d = proto.permute(0, 2, 3, 1).contiguous().to(DEV)
+    low = torch.zeros(1, 300, mh, mw, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_LOWRES, MSL_F32, p=(proto_d.data_ptr(), det_d.data_ptr(), cnt_d.data_ptr(), 0, low.data_ptr()),
+                                 i={0: 1, 1: mh, 2: mw, 4: 32, 7: 300, 8: Hlb, 9: Wlb, 10: 32, 11: 0}), s)
+    off = torch.zeros(1, dtype=torch.int32, device=DEV)
+    full = torch.zeros(n, Hlb, Wlb, device=DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_UPSAMPLE, MSL_F32, p=(low.data_ptr(), 0, cnt_d.data_ptr(), off.data_ptr(), full.data_ptr()),
+                                 i={0: 1, 1: mh, 2: mw, 7: 300, 8: Hlb, 9: Wlb}), s)
+    H0, W0 = img.shape[:2]
+    yt = torch.from_numpy(geometry.nearest_table(H0, Hlb)).to(DEV)
+    xt = torch.from_numpy(geometry.nearest_table(W0, Wlb)).to(DEV)
+    out = torch.zeros(1, W0, H0, dtype=torch.uint8, device=DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_MERGE, MSL_F32, p=(low.data_ptr(), 0, cnt_d.data_ptr(), yt.data_ptr(), out.data_ptr(), xt.data_ptr()),
+                                 i={0: 1, 1: mh, 2: mw, 7: 300, 8: Hlb, 9: Wlb, 10: H0, 11: W0}), s)
+    torch.cuda.synchronize()
+    # the oracle drops all-empty instance masks; compare on the union and per kept instance
+    full_c = full.cpu()
+    keep = full_c.sum((-2, -1)) > 0
+    mism = int((full_c[keep] != want_masks).sum())
+    assert mism <= 1e-6 * want_masks.numel(), f"{mism} mask pixels differ"  # sign ties of ~0 logits only
+    want = P.normalizar_prediccion(P.combinar_predicciones(want_masks.numpy(), (H0, W0)))
+    got = out.cpu().numpy()[0]
+    assert got.shape == want.shape and int((got != want).sum()) <= 2
+
+
+# --------------------------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 4])
+def test_predict_slices_fp32_equals_golden(eng_f32, golden, k):
+    img = _img(golden, k)
+    out = eng_f32.predict_slices(torch.from_numpy(img[None])).cpu().numpy()[0]
+    shape = tuple(golden[f"out{k}_shape"])
+    want = np.unpackbits(golden[f"out{k}_bits"])[: shape[0] * shape[1]].reshape(shape).astype(np.uint8) * 255
+    assert out.shape == want.shape and set(np.unique(out)) <= {0, 255}
+    plan = eng_f32.plan(1, *[(640, 544), (640, 544), (640, 640), (544, 640), (640, 544)][k])
+    n = int(plan.keep_cnt.cpu()[0])
+    assert n == len(golden[f"keep{k}"]) and np.array_equal(plan.keep_idx.cpu().numpy()[0, :n], golden[f"keep{k}"])
+    diff = int((out != want).sum())
+    assert diff <= max(3, int(2e-4 * out.size)), f"{diff} of {out.size} output pixels differ from the oracle"
+
+
+def test_boundary_yolo_call_surface(golden_dir, golden, oracle_model, tmp_path):
+    """B1/B3/B4 through the drop-in `ultralytics` module, then the reference's own NumPy steps."""
+    from oracle import prepost as P
+    from ultralytics import YOLO
+
+    from mslesseg_amd import params
+
+    ck = tmp_path / "weights" / "best.pt"
+    st = torch.load(golden_dir / "synth_n_nc1.pt", map_location="cpu", weights_only=True)
+    params.save_checkpoint(ck, st, "n", 1, {0: "lesion"})
+    assert ck.exists() and ck.stat().st_size > 0  # existe_modelo_entrenado [REF utils.py:240-251]
+    model = YOLO(ck, precision="fp32")
+    img = _img(golden, 1)
+    pred = model(img, verbose=False)[0]
+    assert pred.masks is not None
+    arr = pred.masks.data.cpu().numpy()
+    assert arr.dtype == np.float32 and arr.shape[1:] == (640, 544) and set(np.unique(arr)) <= {0.0, 1.0}
+    got = P.normalizar_prediccion(P.combinar_predicciones(arr, img.shape[:2]))
+    shape = tuple(golden["out1_shape"])
+    want = np.unpackbits(golden["out1_bits"])[: shape[0] * shape[1]].reshape(shape).astype(np.uint8) * 255
+    assert int((got != want).sum()) <= max(3, int(2e-4 * want.size))
+    blank = np.zeros((182, 182, 3), np.uint8)
+    r = model(blank, verbose=False)[0]
+    assert r.masks is None or r.masks.data.shape[1:] == (640, 640)
+    with pytest.raises(FileNotFoundError):
+        YOLO(tmp_path / "nope.pt")
+
+
+def test_volume_dice_fp32_vs_oracle_and_bf16_report(eng_f32, eng_bf16, oracle_model, demo_volumes):
+    """Whole-volume batched inference (every 6th axial slice of P39) → reconstruct → Dice vs GT; GPU fp32 must
+    match the oracle's Dice within 1e-4 (un-rounded).  The bf16 engine's Dice is bounded more loosely."""
+    from oracle import prepost as P
+
+    fl, gt = demo_volumes["P39_flair"], demo_volumes["P39_mask"]
+    idx = list(range(30, 150, 6))
+    imgs = np.stack([P.slice_to_png_array(P.take_slice(fl, "axial", i)) for i in idx])
+    want = {i: P.generar_prediccion_2D(oracle_model, imgs[j]) for j, i in enumerate(idx)}
+    vol_o = P.reconstruir_volumen(want, gt.shape, "axial")
+    d_o = P.dsc_unrounded(gt, vol_o)
+    for eng, tol in ((eng_f32, 1e-4), (eng_bf16, 2e-2)):
+        out = eng.predict_slices(torch.from_numpy(imgs)).cpu().numpy()
+        vol = P.reconstruir_volumen({i: out[j] for j, i in enumerate(idx)}, gt.shape, "axial")
+        d = P.dsc_unrounded(gt, vol)
+        print(f"dtype={eng.dtype} dice={d:.6f} oracle={d_o:.6f} voxels differing={int((vol != vol_o).sum())}")
+        assert abs(d - d_o) <= tol, (eng.dtype, d, d_o)

@@ -1,0 +1,275 @@
+"""Per-kernel parity: every HIP op against a plain PyTorch fp32 CPU reference of the same op (-m gpu).
+
+Tolerances: MSL_F32 runs on the exact-fp32 MFMA (fma chains; only the summation order differs from the CPU):
+rtol 1e-4.  MSL_BF16 rounds inputs/weights/outputs to bf16 (8 significand bits) with fp32 accumulation: the
+reference is computed in fp32 from the same bf16-rounded inputs and compared at rtol 1e-2 (+ atol 1e-2·max|ref|).
+Integer/byte kernels (letterbox, NMS indices, merge, volume ops) are compared bit-exactly.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mslesseg_amd import engine as E  # noqa: E402
+from mslesseg_amd import geometry, hiplib  # noqa: E402
+from mslesseg_amd.hiplib import MSL_BF16, MSL_F32  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _tdt(dtype):
+    return torch.float32 if dtype == MSL_F32 else torch.bfloat16
+
+
+def _rand_act(shape, dtype, gen, scale=1.0):
+    x = (torch.rand(shape, generator=gen) * 2 - 1) * scale
+    return x.to(_tdt(dtype))  # rounded to storage type
+
+
+def _close(out, ref, dtype, what=""):
+    out, ref = out.float().cpu(), ref.float()
+    if dtype == MSL_F32:
+        rtol, atol = 1e-4, 1e-5 * max(1.0, float(ref.abs().max()))
+    else:
+        rtol, atol = 1e-2, 1e-2 * max(1e-3, float(ref.abs().max()))
+    bad = (out - ref).abs() > atol + rtol * ref.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max abs err {float((out - ref).abs().max()):.3e}, max ref {float(ref.abs().max()):.3e}"
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, s, x_cs, x_co, y_cs, y_co, act, res, out_f32
+    (2, 16, 24, 16, 32, 3, 2, 16, 0, 32, 0, 1, 0, 0),
+    (1, 20, 17, 64, 64, 3, 1, 64, 0, 64, 0, 1, 1, 0),
+    (2, 12, 12, 8, 16, 3, 1, 48, 16, 48, 32, 1, 1, 0),     # narrow Cin: several taps per K-step; concat slices
+    (1, 10, 14, 48, 64, 1, 1, 48, 0, 64, 0, 1, 0, 0),      # K tail masking (48 not a multiple of the K-step)
+    (1, 9, 11, 96, 128, 1, 1, 96, 0, 128, 0, 0, 0, 0),
+    (2, 8, 8, 128, 256, 3, 2, 384, 256, 256, 0, 1, 0, 0),  # 16 channel tiles → 4 y-blocks of COT=4
+    (1, 8, 8, 64, 1, 1, 1, 64, 0, 1, 0, 0, 0, 1),          # cls head: Cout=1, fp32 out, scalar stores
+    (1, 8, 8, 32, 32, 1, 1, 32, 0, 32, 0, 0, 0, 1),        # mask-coefficient head: fp32 out
+    (3, 7, 5, 16, 8, 3, 1, 16, 0, 8, 0, 1, 0, 0),          # Cout=8 (half a channel tile), ragged pixel count
+    (1, 40, 40, 32, 64, 3, 1, 32, 0, 64, 0, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(case, dtype):
+    N, H, W, Cin, Cout, k, s, x_cs, x_co, y_cs, y_co, act, res, out_f32 = case
+    g = torch.Generator().manual_seed(hash(case) % (2**31))
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    xbuf = _rand_act((N, H, W, x_cs), dtype, g)
+    w = (torch.rand((Cout, Cin, k, k), generator=g) * 2 - 1) / (Cin * k * k) ** 0.5
+    w = w.to(_tdt(dtype)).float()
+    b = torch.rand(Cout, generator=g) - 0.5
+    rbuf = _rand_act((N, Ho, Wo, y_cs), dtype, g)
+    ybuf = torch.full((N, Ho, Wo, y_cs), 7.0, dtype=torch.float32 if out_f32 else _tdt(dtype))
+    ref = F.conv2d(xbuf[..., x_co : x_co + Cin].float().permute(0, 3, 1, 2), w, b, stride=s, padding=pad)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if res:
+        ref = ref + rbuf[..., y_co : y_co + Cout].float()
+    wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), b, dtype, DEV)
+    xd, rd, yd = xbuf.to(DEV), rbuf.to(DEV), ybuf.to(DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), rd.data_ptr() if res else 0, yd.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: k, 8: s, 9: pad, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co,
+                           14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"]})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    out = yd.cpu()
+    _close(out[..., y_co : y_co + Cout], ref, dtype, f"conv {case}")
+    untouched = torch.ones(y_cs, dtype=torch.bool)
+    untouched[y_co : y_co + Cout] = False
+    assert (out[..., untouched].float() == 7.0).all(), "conv wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+def test_conv_transpose_2x2_pixel_shuffle(dtype):
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = 2, 6, 9, 64, 64
+    x = _rand_act((N, H, W, Cin), dtype, g)
+    w = ((torch.rand((Cin, Cout, 2, 2), generator=g) * 2 - 1) / Cin**0.5).to(_tdt(dtype)).float()
+    b = torch.rand(Cout, generator=g) - 0.5
+    ref = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w, b, stride=2).permute(0, 2, 3, 1)
+    wt, bt, m = E.pack_gemm(w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin), b.repeat(4), dtype, DEV)
+    xd = x.to(DEV)
+    yd = torch.zeros((N, 2 * H, 2 * W, Cout), dtype=_tdt(dtype), device=DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: 4 * Cout, 7: 1, 8: 1, 9: 0, 10: Cin, 11: 0, 12: Cout, 13: 0,
+                           16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 1, 21: m["Cout_pad"]})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(yd, ref, dtype, "convT")
+
+
+def test_conv_rejects_bad_descriptor():
+    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(1, 1, 1, 0, 1), i={0: 1, 1: 8, 2: 8, 3: 12, 4: 8, 5: 8, 6: 16, 7: 3, 8: 1, 9: 1,
+                                                                         10: 12, 12: 16, 16: 108, 17: 128, 21: 16})
+    with pytest.raises(hiplib.MslError):
+        hiplib.launch(op, _stream())  # Cin=12 is not a multiple of 8
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("cout", [16, 32])
+def test_stem(dtype, cout):
+    g = torch.Generator().manual_seed(7)
+    N, H, W = 2, 64, 96
+    img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+    w = (torch.rand((cout, 3, 3, 3), generator=g) * 2 - 1) / 27**0.5
+    b = torch.rand(cout, generator=g) - 0.5
+    ref = F.silu(F.conv2d(img.float().permute(0, 3, 1, 2) / 255, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
+    wd = w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV)
+    bd, xd = b.to(DEV), img.to(DEV)
+    yd = torch.zeros((N, H // 2, W // 2, cout), dtype=_tdt(dtype), device=DEV)
+    op = hiplib.make_op(hiplib.OP_STEM, dtype, p=(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 0, yd.data_ptr()),
+                        i={0: N, 1: H, 2: W, 4: H // 2, 5: W // 2, 6: cout, 12: cout, 13: 0, 18: 1})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(yd, ref, dtype, "stem")
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+def test_dwconv_plain_and_grouped_residual(dtype):
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C = 2, 10, 13, 64
+    x = _rand_act((N, H, W, C), dtype, g)
+    w = (torch.rand((C, 1, 3, 3), generator=g) * 2 - 1) / 3
+    b = torch.rand(C, generator=g) - 0.5
+    ref = F.silu(F.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=1, groups=C)).permute(0, 2, 3, 1)
+    wd, bd, xd = w.view(C, 9).t().contiguous().to(DEV), b.to(DEV), x.to(DEV)
+    yd = torch.zeros((N, H, W, C), dtype=_tdt(dtype), device=DEV)
+    op = hiplib.make_op(hiplib.OP_DWCONV, dtype, p=(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 0, yd.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: C, 10: C, 11: 0, 12: C, 13: 0, 18: 1})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(yd, ref, dtype, "dwconv")
+    # Attention.pe: 2 heads, qkv rows [q32|k32|v64] per head; in place on the attention output
+    heads, C2 = 2, 128
+    qkv = _rand_act((N, H, W, 256), dtype, g)
+    att = _rand_act((N, H, W, C2), dtype, g)
+    w2 = (torch.rand((C2, 1, 3, 3), generator=g) * 2 - 1) / 3
+    b2 = torch.rand(C2, generator=g) - 0.5
+    v = torch.cat([qkv[..., h * 128 + 64 : h * 128 + 128] for h in range(heads)], -1).float()
+    ref2 = F.conv2d(v.permute(0, 3, 1, 2), w2, b2, padding=1, groups=C2).permute(0, 2, 3, 1) + att.float()
+    qd, ad = qkv.to(DEV), att.to(DEV)
+    w2d, b2d = w2.view(C2, 9).t().contiguous().to(DEV), b2.to(DEV)
+    op = hiplib.make_op(hiplib.OP_DWCONV, dtype, p=(qd.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), ad.data_ptr(), ad.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: C2, 10: 256, 11: 0, 12: C2, 13: 0, 14: C2, 15: 0, 18: 0, 22: 64, 23: 128, 24: 64})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(ad, ref2, dtype, "dwconv pe")
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+def test_sppf_pool_equals_three_chained_maxpools(dtype):
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 2, 20, 17, 32
+    buf = _rand_act((N, H, W, 4 * C), dtype, g)
+    y0 = buf[..., :C].float().permute(0, 3, 1, 2)
+    y1 = F.max_pool2d(y0, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    ref = torch.cat([y0, y1, y2, y3], 1).permute(0, 2, 3, 1)
+    bd = buf.to(DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_SPPF_POOL, dtype, p=(bd.data_ptr(),), i={0: N, 1: H, 2: W, 3: C, 10: 4 * C, 11: 0}), _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bd.float().cpu(), ref)  # max is exact in any dtype
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+def test_upsample2x_into_concat_slice(dtype):
+    g = torch.Generator().manual_seed(13)
+    N, H, W, C = 2, 5, 7, 64
+    x = _rand_act((N, H, W, C), dtype, g)
+    yd = torch.zeros((N, 2 * H, 2 * W, 96), dtype=_tdt(dtype), device=DEV)
+    xd = x.to(DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_UPSAMPLE2X, dtype, p=(xd.data_ptr(), 0, 0, 0, yd.data_ptr()),
+                                 i={0: N, 1: H, 2: W, 3: C, 10: C, 11: 0, 12: 96, 13: 32}), _stream())
+    torch.cuda.synchronize()
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    out = yd.float().cpu()
+    assert torch.equal(out[..., 32:], ref) and (out[..., :32] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("hw", [(20, 20), (20, 17), (5, 3)])
+def test_attention(dtype, hw):
+    g = torch.Generator().manual_seed(17)
+    N, (H, W), heads, kd, hd = 2, hw, 2, 32, 64
+    qkv = _rand_act((N, H, W, heads * 128), dtype, g, scale=1.5)
+    q4 = qkv.float().view(N, H * W, heads, 128).permute(0, 2, 3, 1)  # [N,heads,128,HW]
+    q, k, v = q4.split([kd, kd, hd], 2)
+    attn = ((q.transpose(-2, -1) @ k) * kd**-0.5).softmax(-1)
+    ref = (v @ attn.transpose(-2, -1)).permute(0, 3, 1, 2).reshape(N, H, W, heads * hd)
+    qd = qkv.to(DEV)
+    yd = torch.zeros((N, H, W, heads * hd), dtype=_tdt(dtype), device=DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_ATTENTION, dtype, p=(qd.data_ptr(), 0, 0, 0, yd.data_ptr()),
+                                 i={0: N, 1: H, 2: W, 3: heads, 4: kd, 5: hd, 10: heads * 128, 11: 0, 12: heads * hd, 13: 0}, f=(kd**-0.5,)), _stream())
+    torch.cuda.synchronize()
+    _close(yd, ref, dtype, "attention")
+
+
+@pytest.mark.parametrize("hw,c", [((218, 182), 3), ((182, 182), 3), ((182, 218), 1), ((640, 640), 3), ((37, 91), 3)])
+def test_letterbox_bit_exact(hw, c):
+    from oracle import prepost as P
+
+    rng = np.random.default_rng(3)
+    N, (H0, W0) = 3, hw
+    imgs = rng.integers(0, 256, size=(N, H0, W0, c), dtype=np.uint8)
+    lb = geometry.letterbox_for(H0, W0)
+    src = torch.from_numpy(imgs).to(DEV)
+    dst = torch.zeros((N, lb.hlb, lb.wlb, 3), dtype=torch.uint8, device=DEV)
+    xt = torch.from_numpy(geometry.linear_table(lb.wn, W0, True)).to(DEV)
+    yt = torch.from_numpy(geometry.linear_table(lb.hn, H0, False)).to(DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_LETTERBOX, MSL_BF16, p=(src.data_ptr(), xt.data_ptr(), yt.data_ptr(), 0, dst.data_ptr()),
+                                 i={0: N, 1: H0, 2: W0, 3: c, 4: lb.hn, 5: lb.wn, 6: lb.top, 7: lb.left, 8: lb.hlb, 9: lb.wlb, 10: 114,
+                                    11: 1 if lb.resize else 0}), _stream())
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy()
+    for n in range(N):
+        bgr = imgs[n] if c == 3 else np.repeat(imgs[n], 3, axis=2)
+        want = P.letterbox(bgr)[..., ::-1]  # oracle letterboxes BGR; the device image is RGB
+        assert np.array_equal(out[n], want)
+
+
+def test_volume_ops_bit_exact(demo_volumes):
+    from oracle import prepost as P
+
+    gt = demo_volumes["P39_mask"]
+    X, Y, Z = gt.shape
+    vols = {}
+    for plano, axis in (("axial", 2), ("coronal", 1), ("sagital", 0)):
+        idx = list(range(0, gt.shape[axis], 3))
+        imgs = np.stack([P.take_slice(gt, plano, i) * 255 for i in idx]).astype(np.uint8)
+        ref = P.reconstruir_volumen({i: im for i, im in zip(idx, imgs)}, gt.shape, plano)
+        vd = torch.zeros((X, Y, Z), dtype=torch.float32, device=DEV)
+        im_d, ix_d = torch.from_numpy(imgs).to(DEV), torch.tensor(idx, dtype=torch.int32, device=DEV)
+        hiplib.launch(hiplib.make_op(hiplib.OP_VOL_INSERT, MSL_F32, p=(im_d.data_ptr(), ix_d.data_ptr(), 0, 0, vd.data_ptr()),
+                                     i={0: len(idx), 1: X, 2: Y, 3: Z, 4: axis}), _stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(vd.cpu().numpy(), ref), plano
+        vols[plano] = vd
+    n = X * Y * Z
+    for thr in (2, 3):
+        out = torch.zeros(n, dtype=torch.uint8, device=DEV)
+        hiplib.launch(hiplib.make_op(hiplib.OP_VOL_CONSENSUS, MSL_F32,
+                                     p=(vols["axial"].data_ptr(), vols["coronal"].data_ptr(), vols["sagital"].data_ptr(), 0, out.data_ptr()),
+                                     i={0: n & 0x7FFFFFFF, 1: n >> 31, 2: thr}), _stream())
+        torch.cuda.synchronize()
+        want = P.combinar_volumenes(*(vols[p].cpu().numpy() for p in ("axial", "coronal", "sagital")), umbral=thr)
+        assert np.array_equal(out.cpu().numpy().reshape(X, Y, Z), want)
+        acc = torch.zeros(3, dtype=torch.int64, device=DEV)
+        gd = torch.from_numpy(gt.reshape(-1)).to(DEV)
+        hiplib.launch(hiplib.make_op(hiplib.OP_VOL_DICE, MSL_F32, p=(gd.data_ptr(), out.data_ptr(), 0, 0, acc.data_ptr()),
+                                     i={0: n & 0x7FFFFFFF, 1: n >> 31}), _stream())
+        torch.cuda.synchronize()
+        inter, sg, sp = (int(v) for v in acc.cpu())
+        assert (inter, sg, sp) == (int((gt * want).sum()), int(gt.sum()), int(want.sum()))
+        assert abs(2.0 * inter / (sg + sp + 1e-8) - P.dsc_unrounded(gt, want)) < 1e-12

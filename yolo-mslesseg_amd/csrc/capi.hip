@@ -1,0 +1,122 @@
+// extern "C" surface of libmslesseg_hip.so (include/mslesseg_hip.h): validation + dispatch only.
+#include <stdarg.h>
+#include <string.h>
+
+#include "msl_common.h"
+
+static thread_local char g_err[512] = "";
+
+void msl_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int dispatch(const msl_op& op, hipStream_t s) {
+  switch (op.kind) {
+    case MSL_OP_CONV: return msl_launch_conv(op, s);
+    case MSL_OP_STEM: return msl_launch_stem(op, s);
+    case MSL_OP_DWCONV: return msl_launch_dwconv(op, s);
+    case MSL_OP_SPPF_POOL: return msl_launch_sppf_pool(op, s);
+    case MSL_OP_UPSAMPLE2X: return msl_launch_upsample2x(op, s);
+    case MSL_OP_ATTENTION: return msl_launch_attention(op, s);
+    case MSL_OP_HEAD_DECODE: return msl_launch_head_decode(op, s);
+    case MSL_OP_NMS: return msl_launch_nms(op, s);
+    case MSL_OP_MASK_LOWRES: return msl_launch_mask_lowres(op, s);
+    case MSL_OP_MASK_UPSAMPLE: return msl_launch_mask_upsample(op, s);
+    case MSL_OP_MASK_MERGE: return msl_launch_mask_merge(op, s);
+    case MSL_OP_LETTERBOX: return msl_launch_letterbox(op, s);
+    case MSL_OP_VOL_INSERT: return msl_launch_vol_insert(op, s);
+    case MSL_OP_VOL_CONSENSUS: return msl_launch_vol_consensus(op, s);
+    case MSL_OP_VOL_DICE: return msl_launch_vol_dice(op, s);
+    default:
+      msl_set_error("unknown op kind %d", op.kind);
+      return MSL_ENOSYS;
+  }
+}
+
+extern "C" {
+
+int msl_abi_version(void) { return MSL_ABI_VERSION; }
+const char* msl_last_error(void) { return g_err; }
+
+int msl_launch(const msl_op* op, void* stream) {
+  if (!op) { msl_set_error("msl_launch: null op"); return MSL_EINVAL; }
+  return dispatch(*op, (hipStream_t)stream);
+}
+
+int msl_run_program(const msl_op* ops, int32_t n, void* stream) {
+  if (!ops || n < 0) { msl_set_error("msl_run_program: bad arguments"); return MSL_EINVAL; }
+  for (int32_t i = 0; i < n; ++i) {
+    int rc = dispatch(ops[i], (hipStream_t)stream);
+    if (rc != MSL_OK) {
+      char tmp[400];
+      strncpy(tmp, g_err, sizeof(tmp) - 1);
+      tmp[sizeof(tmp) - 1] = 0;
+      msl_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
+      return rc;
+    }
+  }
+  return MSL_OK;
+}
+
+int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out) {
+  if (!ops || n <= 0 || !graph_exec_out) { msl_set_error("msl_graph_create: bad arguments"); return MSL_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { msl_set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  int rc = msl_run_program(ops, n, stream);
+  e = hipStreamEndCapture(s, &graph);
+  if (rc != MSL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) { msl_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { msl_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  *graph_exec_out = (void*)exec;
+  return MSL_OK;
+}
+
+int msl_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) { msl_set_error("msl_graph_launch: null graph"); return MSL_EINVAL; }
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) { msl_set_error("hipGraphLaunch: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  return MSL_OK;
+}
+
+int msl_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return MSL_OK;
+}
+
+int msl_event_create(void** ev_out) {
+  if (!ev_out) { msl_set_error("msl_event_create: null out"); return MSL_EINVAL; }
+  hipEvent_t ev;
+  hipError_t e = hipEventCreate(&ev);
+  if (e != hipSuccess) { msl_set_error("hipEventCreate: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  *ev_out = (void*)ev;
+  return MSL_OK;
+}
+
+int msl_event_record(void* ev, void* stream) {
+  hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+  if (e != hipSuccess) { msl_set_error("hipEventRecord: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  return MSL_OK;
+}
+
+int msl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+  if (!ms_out) { msl_set_error("msl_event_elapsed_ms: null out"); return MSL_EINVAL; }
+  hipError_t e = hipEventSynchronize((hipEvent_t)ev_stop);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms_out, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+  if (e != hipSuccess) { msl_set_error("hipEventElapsedTime: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  return MSL_OK;
+}
+
+int msl_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+  return MSL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// HBM-bound byte/element kernels around the conv GEMMs: stem conv from uint8, depthwise 3x3, SPPF pooling,
+// nearest upsample, LetterBox.  All are coalesced NHWC streams with 8/16-byte accesses per lane; none is
+// reshaped into a GEMM (their arithmetic intensity is far below the MFMA ridge).
+#include "msl_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Stem: y = SiLU(conv3x3/s2(rgb_u8/255) + b).  One thread = one output pixel x COUT channels.
+// Replaces ultralytics preprocess (`im.float()/255`) + model.0 Conv  [UPSTREAM engine/predictor.py, nn/modules/conv.py].
+// ---------------------------------------------------------------------------------------------------------
+template <bool F32, int COUT>
+__global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, void* __restrict__ y, int N, int H,
+                                                   int W, int Ho, int Wo, int y_cs, int y_co, int act) {
+  __shared__ float sw[27 * COUT + COUT];
+  for (int i = threadIdx.x; i < 27 * COUT + COUT; i += 256) sw[i] = i < 27 * COUT ? w[i] : bias[i - 27 * COUT];
+  __syncthreads();
+  long p = (long)blockIdx.x * 256 + threadIdx.x;
+  long M = (long)N * Ho * Wo;
+  if (p >= M) return;
+  int n = (int)(p / ((long)Ho * Wo));
+  int r = (int)(p - (long)n * Ho * Wo);
+  int oy = r / Wo, ox = r - oy * Wo;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = sw[27 * COUT + c];
+  const uint8_t* img = x + (long)n * H * W * 3;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = oy * 2 - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = ox * 2 - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const uint8_t* px = img + ((long)iy * W + ix) * 3;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        float v = (float)px[ci] / 255.0f;  // exact IEEE division, as torch `im / 255`
+        const float* wr = sw + ((ky * 3 + kx) * 3 + ci) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+      }
+    }
+  }
+  long oi = p * y_cs + y_co;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) {
+    float v[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
+    }
+    st4<F32>(y, oi + c, v);
+  }
+}
+
+int msl_launch_stem(const msl_op& op, hipStream_t s) {
+  const uint8_t* x = (const uint8_t*)op.p[0];
+  const float* w = (const float*)op.p[1];
+  const float* b = (const float*)op.p[2];
+  void* y = op.p[4];
+  int N = op.i[0], H = op.i[1], W = op.i[2], Ho = op.i[4], Wo = op.i[5], Cout = op.i[6], y_cs = op.i[12], y_co = op.i[13], act = op.i[18];
+  MSL_REQUIRE(x && w && b && y, "stem: null pointer");
+  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "stem: bad dims");
+  MSL_REQUIRE(Cout == 16 || Cout == 32, "stem: Cout=%d unsupported (16|32)", Cout);
+  MSL_REQUIRE(y_cs % 4 == 0 && y_co % 4 == 0 && y_co + Cout <= y_cs, "stem: bad output view");
+  long M = (long)N * Ho * Wo;
+  unsigned grid = (unsigned)((M + 255) / 256);
+  const bool f32 = op.dtype == MSL_F32;
+#define STEM(F, C) hipLaunchKernelGGL((stem_kernel<F, C>), dim3(grid), dim3(256), 0, s, x, w, b, y, N, H, W, Ho, Wo, y_cs, y_co, act)
+  if (f32) { if (Cout == 16) STEM(true, 16); else STEM(true, 32); }
+  else     { if (Cout == 16) STEM(false, 16); else STEM(false, 32); }
+#undef STEM
+  MSL_CHECK_LAUNCH("stem");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Depthwise 3x3, stride 1, pad 1.  One thread = one pixel x 4 channels.
+// [UPSTREAM DWConv in Segment.cv3; Attention.pe]
+// ---------------------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const void* __restrict__ res,
+                                                     void* __restrict__ y, int N, int H, int W, int C, int x_cs, int x_co,
+                                                     int y_cs, int y_co, int res_cs, int res_co, int act, int gsz,
+                                                     int gstride, int goff) {
+  const int C4 = C >> 2;
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  long total = (long)N * H * W * C4;
+  if (t >= total) return;
+  int c = (int)(t % C4) * 4;
+  long p = t / C4;
+  int ix = (int)(p % W);
+  long q = p / W;
+  int iy = (int)(q % H);
+  int n = (int)(q / H);
+  int cin = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
+  float4 b4 = *(const float4*)(bias + c);
+  float acc[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int yy = iy - 1 + ky;
+    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int xx = ix - 1 + kx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      float v[4];
+      ld4<F32>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin, v);
+      float4 w4 = *(const float4*)(w + (ky * 3 + kx) * C + c);
+      acc[0] = fmaf(v[0], w4.x, acc[0]); acc[1] = fmaf(v[1], w4.y, acc[1]);
+      acc[2] = fmaf(v[2], w4.z, acc[2]); acc[3] = fmaf(v[3], w4.w, acc[3]);
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = silu_f(acc[r]);
+  }
+  if (res) {
+    float rv[4];
+    ld4<F32>(res, p * res_cs + res_co + c, rv);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += rv[r];
+  }
+  st4<F32>(y, p * y_cs + y_co + c, acc);
+}
+
+int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13];
+  int res_cs = op.i[14], res_co = op.i[15], act = op.i[18], gsz = op.i[22], gstride = op.i[23], goff = op.i[24];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4], "dwconv: null pointer");
+  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv: bad dims");
+  MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && y_co + C <= y_cs, "dwconv: bad views");
+  if (gsz) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && x_co + (C / gsz - 1) * gstride + goff + gsz <= x_cs, "dwconv: bad group map");
+  else MSL_REQUIRE(x_co + C <= x_cs, "dwconv: input view exceeds stride");
+  if (op.p[3]) MSL_REQUIRE(res_cs % 4 == 0 && res_co % 4 == 0 && res_co + C <= res_cs, "dwconv: bad residual view");
+  long total = (long)N * H * W * (C / 4);
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (op.dtype == MSL_F32)
+    hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff);
+  MSL_CHECK_LAUNCH("dwconv");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SPPF pooling: three chained 5x5/s1/p2 max pools == 5x5, 9x9, 13x13 windows clipped to the image.
+// [UPSTREAM SPPF.forward]
+// ---------------------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(void* __restrict__ buf, int N, int H, int W, int C, int cs, int co) {
+  const int C4 = C >> 2;
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  long total = (long)N * H * W * C4;
+  if (t >= total) return;
+  int c = (int)(t % C4) * 4;
+  long p = t / C4;
+  int ix = (int)(p % W);
+  long q = p / W;
+  int iy = (int)(q % H);
+  int n = (int)(q / H);
+  const float NEG = -__builtin_inff();
+  float m1[4] = {NEG, NEG, NEG, NEG}, m2[4] = {NEG, NEG, NEG, NEG}, m3[4] = {NEG, NEG, NEG, NEG};
+  for (int dy = -6; dy <= 6; ++dy) {
+    int yy = iy + dy;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int dx = -6; dx <= 6; ++dx) {
+      int xx = ix + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      float v[4];
+      ld4<F32>(buf, (((long)n * H + yy) * W + xx) * cs + co + c, v);
+      int ad = max(abs(dy), abs(dx));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        m3[r] = fmaxf(m3[r], v[r]);
+        if (ad <= 4) m2[r] = fmaxf(m2[r], v[r]);
+        if (ad <= 2) m1[r] = fmaxf(m1[r], v[r]);
+      }
+    }
+  }
+  long o = p * cs + co + c;
+  st4<F32>(buf, o + C, m1);
+  st4<F32>(buf, o + 2 * C, m2);
+  st4<F32>(buf, o + 3 * C, m3);
+}
+
+int msl_launch_sppf_pool(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], cs = op.i[10], co = op.i[11];
+  MSL_REQUIRE(op.p[0], "sppf: null pointer");
+  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && co + 4 * C <= cs, "sppf: bad dims/view");
+  long total = (long)N * H * W * (C / 4);
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_kernel<true>, dim3(grid), dim3(256), 0, s, op.p[0], N, H, W, C, cs, co);
+  else hipLaunchKernelGGL(sppf_pool_kernel<false>, dim3(grid), dim3(256), 0, s, op.p[0], N, H, W, C, cs, co);
+  MSL_CHECK_LAUNCH("sppf_pool");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Nearest 2x upsample into a (concat) view.  One thread = 16 bytes of one OUTPUT pixel.  [UPSTREAM nn.Upsample]
+// ---------------------------------------------------------------------------------------------------------
+template <int ES>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict__ x, char* __restrict__ y, int N, int H, int W,
+                                                         int C, int x_cs, int x_co, int y_cs, int y_co) {
+  constexpr int V = 16 / ES;
+  const int CV = C / V;
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  long total = (long)N * (2 * H) * (2 * W) * CV;
+  if (t >= total) return;
+  int c = (int)(t % CV) * V;
+  long p = t / CV;
+  int ox = (int)(p % (2 * W));
+  long q = p / (2 * W);
+  int oy = (int)(q % (2 * H));
+  int n = (int)(q / (2 * H));
+  uint4 v = *(const uint4*)(x + ((((long)n * H + (oy >> 1)) * W + (ox >> 1)) * x_cs + x_co + c) * ES);
+  *(uint4*)(y + (p * y_cs + y_co + c) * ES) = v;
+}
+
+int msl_launch_upsample2x(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13];
+  const bool f32 = op.dtype == MSL_F32;
+  const int V = f32 ? 4 : 8;
+  MSL_REQUIRE(op.p[0] && op.p[4], "upsample: null pointer");
+  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % V == 0 && x_cs % V == 0 && x_co % V == 0 && y_cs % V == 0 && y_co % V == 0 &&
+                  x_co + C <= x_cs && y_co + C <= y_cs, "upsample: bad dims/view");
+  long total = (long)N * 4 * H * W * (C / V);
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (f32) hipLaunchKernelGGL(upsample2x_kernel<4>, dim3(grid), dim3(256), 0, s, (const char*)op.p[0], (char*)op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co);
+  else hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid), dim3(256), 0, s, (const char*)op.p[0], (char*)op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co);
+  MSL_CHECK_LAUNCH("upsample2x");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LetterBox on device: OpenCV's 8-bit INTER_LINEAR fixed-point scheme (11-bit weights; vertical pass
+// (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2), constant border, BGR→RGB.  Integer arithmetic: bit-exact.
+// [UPSTREAM ultralytics LetterBox + cv2.resize/copyMakeBorder, called from model(img) — REF generar_predicciones.py:114]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, const int4* __restrict__ xtab,
+                                                        const int4* __restrict__ ytab, uint8_t* __restrict__ dst, int N, int H0,
+                                                        int W0, int Cs, int Hn, int Wn, int top, int left, int Hlb, int Wlb,
+                                                        int padv, int resize) {
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  long total = (long)N * Hlb * Wlb;
+  if (t >= total) return;
+  int x = (int)(t % Wlb);
+  long q = t / Wlb;
+  int y = (int)(q % Hlb);
+  int n = (int)(q / Hlb);
+  int rx = x - left, ry = y - top;
+  uint8_t o[3] = {(uint8_t)padv, (uint8_t)padv, (uint8_t)padv};
+  if ((unsigned)rx < (unsigned)Wn && (unsigned)ry < (unsigned)Hn) {
+    const uint8_t* img = src + (long)n * H0 * W0 * Cs;
+    if (!resize) {
+      const uint8_t* px = img + ((long)ry * W0 + rx) * Cs;
+      for (int c = 0; c < 3; ++c) o[c] = Cs == 3 ? px[2 - c] : px[0];
+    } else {
+      int4 xt = xtab[rx], yt = ytab[ry];
+      const uint8_t* r0 = img + (long)yt.x * W0 * Cs;
+      const uint8_t* r1 = img + (long)yt.y * W0 * Cs;
+      for (int c = 0; c < (Cs == 3 ? 3 : 1); ++c) {
+        int S0 = (int)r0[xt.x * Cs + c] * xt.z + (int)r0[xt.y * Cs + c] * xt.w;
+        int S1 = (int)r1[xt.x * Cs + c] * xt.z + (int)r1[xt.y * Cs + c] * xt.w;
+        int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        if (Cs == 3) o[2 - c] = (uint8_t)v; else o[0] = o[1] = o[2] = (uint8_t)v;
+      }
+    }
+  }
+  uint8_t* d = dst + t * 3;
+  d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+}
+
+int msl_launch_letterbox(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], H0 = op.i[1], W0 = op.i[2], Cs = op.i[3], Hn = op.i[4], Wn = op.i[5], top = op.i[6], left = op.i[7];
+  int Hlb = op.i[8], Wlb = op.i[9], padv = op.i[10], resize = op.i[11];
+  MSL_REQUIRE(op.p[0] && op.p[4] && (!resize || (op.p[1] && op.p[2])), "letterbox: null pointer");
+  MSL_REQUIRE(N > 0 && H0 > 0 && W0 > 0 && (Cs == 1 || Cs == 3), "letterbox: bad source dims");
+  MSL_REQUIRE(Hn > 0 && Wn > 0 && top >= 0 && left >= 0 && top + Hn <= Hlb && left + Wn <= Wlb, "letterbox: bad geometry");
+  MSL_REQUIRE(resize || (Hn == H0 && Wn == W0), "letterbox: copy mode needs equal sizes");
+  long total = (long)N * Hlb * Wlb;
+  unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(letterbox_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t*)op.p[0], (const int4*)op.p[1], (const int4*)op.p[2],
+                     (uint8_t*)op.p[4], N, H0, W0, Cs, Hn, Wn, top, left, Hlb, Wlb, padv, resize);
+  MSL_CHECK_LAUNCH("letterbox");
+  return MSL_OK;
+}

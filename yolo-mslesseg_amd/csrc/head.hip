@@ -1,0 +1,301 @@
+// Detection/segmentation head after the conv GEMMs: DFL decode, NMS, mask assembly and the reference's own
+// merge / orient step.  Compiled with -ffp-contract=off: the IoU and box arithmetic must be the same
+// individually-rounded fp32 operations as the CPU path (torchvision nms / ultralytics ops) for the kept
+// indices to be bit-identical on the same pre-NMS tensor.
+#include "msl_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Decode one pyramid level into pred rows [x,y,w,h,conf,cls,coef*nm].  One thread = one anchor.
+// [UPSTREAM Detect._inference: DFL (softmax over 16 bins, expectation), dist2bbox(xywh) * stride, cls.sigmoid()]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_decode_kernel(const float* __restrict__ box, const float* __restrict__ cls,
+                                                          const float* __restrict__ coef, float* __restrict__ pred, int N,
+                                                          int H, int W, int nc, int nm, int aoff, int A, float stride) {
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (t >= (long)N * HW) return;
+  int n = (int)(t / HW), a = (int)(t - (long)n * HW);
+  int ay = a / W, ax = a - ay * W;
+  const float* b = box + t * 64;
+  float d[4];
+#pragma unroll
+  for (int side = 0; side < 4; ++side) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      float4 q = *(const float4*)(b + side * 16 + k);
+      v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+    }
+    float mx = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+    float sum = 0.f, e[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { e[k] = expf(v[k] - mx); sum += e[k]; }
+    float ex = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ex += (float)k * (e[k] / sum);  // conv with weights arange(16) over softmax
+    d[side] = ex;
+  }
+  const float cx = (float)ax + 0.5f, cy = (float)ay + 0.5f;
+  const float x1 = cx - d[0], y1 = cy - d[1], x2 = cx + d[2], y2 = cy + d[3];
+  float* o = pred + ((long)n * A + aoff + a) * MSL_PRED_STRIDE;
+  o[0] = ((x1 + x2) / 2.f) * stride;
+  o[1] = ((y1 + y2) / 2.f) * stride;
+  o[2] = (x2 - x1) * stride;
+  o[3] = (y2 - y1) * stride;
+  float best = -1.f;
+  int bj = 0;
+  for (int j = 0; j < nc; ++j) {
+    float sc = 1.0f / (1.0f + expf(-cls[t * nc + j]));
+    if (sc > best) { best = sc; bj = j; }
+  }
+  o[4] = best;
+  o[5] = (float)bj;
+  for (int j = 0; j < nm; ++j) o[6 + j] = coef[t * nm + j];
+  for (int j = 6 + nm; j < MSL_PRED_STRIDE; ++j) o[j] = 0.f;
+}
+
+int msl_launch_head_decode(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], H = op.i[1], W = op.i[2], nc = op.i[3], nm = op.i[4], aoff = op.i[5], A = op.i[6];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4], "head_decode: null pointer");
+  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && nc > 0 && nm >= 0 && 6 + nm <= MSL_PRED_STRIDE && aoff >= 0 && aoff + H * W <= A, "head_decode: bad dims");
+  long total = (long)N * H * W;
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)op.p[0], (const float*)op.p[1],
+                     (const float*)op.p[2], (float*)op.p[4], N, H, W, nc, nm, aoff, A, op.f[0]);
+  MSL_CHECK_LAUNCH("head_decode");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NMS: one 1024-thread workgroup per image.
+//   1. candidates = anchors with conf > conf_thres                      [UPSTREAM ops.non_max_suppression]
+//   2. bitonic sort in LDS on key = (conf bits << 32 | ~anchor): score descending, ties by lower anchor index —
+//      the order of torchvision's stable descending sort                 [UPSTREAM torchvision ops.nms CPU kernel]
+//   3. greedy: the next unsuppressed candidate is kept; all threads test the rest against it (IoU > thr suppresses);
+//      stops after max_det keeps (== nms(...)[:max_det]).
+// ---------------------------------------------------------------------------------------------------------
+#define NMS_CAP 16384
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ pred, int* __restrict__ keep_idx, int* __restrict__ keep_cnt,
+                                                   float* __restrict__ det, int A, int max_det, float conf_thres, float iou_thres) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;            // NMS_CAP * 8
+  unsigned char* supp = smem + (size_t)NMS_CAP * 8;                // NMS_CAP
+  __shared__ int s_count;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* P = pred + (long)n * A * MSL_PRED_STRIDE;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  for (int a = tid; a < A; a += 1024) {
+    float c = P[(long)a * MSL_PRED_STRIDE + 4];
+    if (c > conf_thres) {
+      int slot = atomicAdd(&s_count, 1);
+      keys[slot] = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)a);
+    }
+  }
+  __syncthreads();
+  const int count = s_count;
+  int S = 1;
+  while (S < count) S <<= 1;
+  for (int i = count + tid; i < S; i += 1024) keys[i] = 0ull;
+  for (int i = tid; i < S; i += 1024) supp[i] = 0;
+  __syncthreads();
+  // bitonic sort, descending
+  for (int k = 2; k <= S; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < S; i += 1024) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a0 = keys[i], a1 = keys[ixj];
+          bool desc = (i & k) == 0;
+          if (desc ? (a0 < a1) : (a0 > a1)) { keys[i] = a1; keys[ixj] = a0; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // greedy suppression
+  int kept = 0;
+  for (int i = 0; i < count && kept < max_det; ++i) {
+    if (supp[i]) continue;  // uniform: every thread reads the same byte, written before the last barrier
+    const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+    const float* bi = P + (long)ai * MSL_PRED_STRIDE;
+    if (tid == 0) keep_idx[(long)n * max_det + kept] = ai;
+    if (tid < MSL_PRED_STRIDE) {
+      float v = bi[tid];
+      if (tid < 4) {  // xywh2xyxy
+        float c0 = bi[tid & 1], hw = bi[2 + (tid & 1)] / 2.f;
+        v = tid < 2 ? c0 - hw : c0 + hw;
+      }
+      det[((long)n * max_det + kept) * MSL_PRED_STRIDE + tid] = v;
+    }
+    ++kept;
+    const float iw2 = bi[2] / 2.f, ih2 = bi[3] / 2.f;
+    const float ix1 = bi[0] - iw2, iy1 = bi[1] - ih2, ix2 = bi[0] + iw2, iy2 = bi[1] + ih2;
+    const float iarea = (ix2 - ix1) * (iy2 - iy1);
+    for (int j = i + 1 + tid; j < count; j += 1024) {
+      if (supp[j]) continue;
+      const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
+      const float4 bj = *(const float4*)(P + (long)aj * MSL_PRED_STRIDE);
+      const float jw2 = bj.z / 2.f, jh2 = bj.w / 2.f;
+      const float jx1 = bj.x - jw2, jy1 = bj.y - jh2, jx2 = bj.x + jw2, jy2 = bj.y + jh2;
+      const float jarea = (jx2 - jx1) * (jy2 - jy1);
+      const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1), xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+      const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+      const float inter = w * h;
+      const float ovr = inter / (iarea + jarea - inter);
+      if (ovr > iou_thres) supp[j] = 1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) keep_cnt[n] = kept;
+}
+
+int msl_launch_nms(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], A = op.i[6], max_det = op.i[7];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3], "nms: null pointer");
+  MSL_REQUIRE(N > 0 && A > 0 && A <= NMS_CAP && max_det > 0, "nms: bad dims (A=%d, cap %d)", A, NMS_CAP);
+  static bool attr_set = false;
+  const size_t lds = (size_t)NMS_CAP * 9;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(1024), lds, s, (const float*)op.p[0], (int*)op.p[1], (int*)op.p[2], (float*)op.p[3], A, max_det,
+                     op.f[0], op.f[1]);
+  MSL_CHECK_LAUNCH("nms");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Low-resolution instance logits with crop.  One thread = one proto pixel, looping over the image's kept rows.
+// [UPSTREAM ops.process_mask: (masks_in @ protos) → crop_mask at proto scale]
+// ---------------------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void mask_lowres_kernel(const void* __restrict__ proto, const float* __restrict__ det,
+                                                          const int* __restrict__ keep_cnt, float* __restrict__ lowres, int mh,
+                                                          int mw, int nm, int max_det, int x_cs, int x_co, float wr, float hr) {
+  const int n = blockIdx.y;
+  const int cnt = keep_cnt[n];
+  if (cnt == 0) return;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= mh * mw) return;
+  const int py = pix / mw, px = pix - py * mw;
+  float pr[32];
+  const long pb = ((long)n * mh * mw + pix) * x_cs + x_co;
+#pragma unroll
+  for (int c = 0; c < 32; c += 4) {
+    float v[4];
+    ld4<F32>(proto, pb + c, v);
+    pr[c] = v[0]; pr[c + 1] = v[1]; pr[c + 2] = v[2]; pr[c + 3] = v[3];
+  }
+  const float fx = (float)px, fy = (float)py;
+  for (int d = 0; d < cnt; ++d) {
+    const float* row = det + ((long)n * max_det + d) * MSL_PRED_STRIDE;
+    const float bx1 = row[0] * wr, by1 = row[1] * hr, bx2 = row[2] * wr, by2 = row[3] * hr;
+    float v = 0.f;
+    if (fx >= bx1 && fx < bx2 && fy >= by1 && fy < by2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) acc = fmaf(row[6 + c], pr[c], acc);
+      v = acc;
+    }
+    lowres[(((long)n * max_det + d) * mh + py) * mw + px] = v;
+  }
+}
+
+int msl_launch_mask_lowres(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], mh = op.i[1], mw = op.i[2], nm = op.i[4], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9], x_cs = op.i[10], x_co = op.i[11];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4], "mask_lowres: null pointer");
+  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && nm == 32 && max_det > 0 && Hlb > 0 && Wlb > 0, "mask_lowres: bad dims (nm must be 32)");
+  MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && x_co + nm <= x_cs, "mask_lowres: bad proto view");
+  const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
+  dim3 grid((mh * mw + 255) / 256, N);
+  if (op.dtype == MSL_F32)
+    hipLaunchKernelGGL(mask_lowres_kernel<true>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const int*)op.p[2], (float*)op.p[4], mh, mw, nm, max_det, x_cs, x_co, wr, hr);
+  else
+    hipLaunchKernelGGL(mask_lowres_kernel<false>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const int*)op.p[2], (float*)op.p[4], mh, mw, nm, max_det, x_cs, x_co, wr, hr);
+  MSL_CHECK_LAUNCH("mask_lowres");
+  return MSL_OK;
+}
+
+// bilinear sample (align_corners=False) of one low-res map at destination pixel (oy, ox) of an (Hout, Wout) grid
+// [UPSTREAM F.interpolate(mode="bilinear"): src = scale*(dst+0.5)-0.5 clamped at 0; i1 = min(i0+1, in-1)]
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ m, int mh, int mw, float sy, float sx, int oy, int ox) {
+  float fy = sy * ((float)oy + 0.5f) - 0.5f;
+  float fx = sx * ((float)ox + 0.5f) - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  int y0 = min((int)fy, mh - 1), x0 = min((int)fx, mw - 1);
+  int y1 = min(y0 + 1, mh - 1), x1 = min(x0 + 1, mw - 1);
+  float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+  float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  float v00 = m[y0 * mw + x0], v01 = m[y0 * mw + x1], v10 = m[y1 * mw + x0], v11 = m[y1 * mw + x1];
+  return ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Boundary masks (B4): [total_kept, Hlb, Wlb] float {0,1}.  [UPSTREAM process_mask upsample + gt_(0.0)]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_upsample_kernel(const float* __restrict__ lowres, const int* __restrict__ keep_cnt,
+                                                            const int* __restrict__ offsets, float* __restrict__ masks, int mh, int mw,
+                                                            int max_det, int Hlb, int Wlb, float sy, float sx) {
+  const int n = blockIdx.y;
+  const int cnt = keep_cnt[n];
+  if (cnt == 0) return;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= Hlb * Wlb) return;
+  const int oy = pix / Wlb, ox = pix - oy * Wlb;
+  const long off = offsets[n];
+  for (int d = 0; d < cnt; ++d) {
+    const float* m = lowres + ((long)n * max_det + d) * mh * mw;
+    float v = bilinear_at(m, mh, mw, sy, sx, oy, ox);
+    masks[(off + d) * (long)Hlb * Wlb + pix] = v > 0.f ? 1.f : 0.f;
+  }
+}
+
+int msl_launch_mask_upsample(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], mh = op.i[1], mw = op.i[2], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9];
+  MSL_REQUIRE(op.p[0] && op.p[2] && op.p[3] && op.p[4], "mask_upsample: null pointer");
+  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && Hlb > 0 && Wlb > 0, "mask_upsample: bad dims");
+  const float sy = (float)mh / (float)Hlb, sx = (float)mw / (float)Wlb;
+  dim3 grid((Hlb * Wlb + 255) / 256, N);
+  hipLaunchKernelGGL(mask_upsample_kernel, grid, dim3(256), 0, s, (const float*)op.p[0], (const int*)op.p[2], (const int*)op.p[3], (float*)op.p[4],
+                     mh, mw, max_det, Hlb, Wlb, sy, sx);
+  MSL_CHECK_LAUNCH("mask_upsample");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused merge + orient: for each pixel (y0,x0) of the ORIGINAL slice grid, OR over instances of the upsampled
+// mask at the letterbox pixel OpenCV INTER_NEAREST would pick; written transposed + horizontally flipped, x255.
+// [REF generar_predicciones.py:123-140 combinar_predicciones + normalizar_prediccion]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict__ lowres, const int* __restrict__ keep_cnt,
+                                                         const int* __restrict__ ytab, const int* __restrict__ xtab, uint8_t* __restrict__ out,
+                                                         int mh, int mw, int max_det, int Hlb, int Wlb, int H0, int W0, float sy, float sx) {
+  const int n = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= H0 * W0) return;
+  const int y0 = pix / W0, x0 = pix - y0 * W0;
+  const int cnt = keep_cnt[n];
+  const int oy = ytab[y0], ox = xtab[x0];
+  bool on = false;
+  for (int d = 0; d < cnt && !on; ++d) {
+    const float* m = lowres + ((long)n * max_det + d) * mh * mw;
+    on = bilinear_at(m, mh, mw, sy, sx, oy, ox) > 0.f;
+  }
+  out[((long)n * W0 + x0) * H0 + (H0 - 1 - y0)] = on ? 255 : 0;
+}
+
+int msl_launch_mask_merge(const msl_op& op, hipStream_t s) {
+  int N = op.i[0], mh = op.i[1], mw = op.i[2], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9], H0 = op.i[10], W0 = op.i[11];
+  MSL_REQUIRE(op.p[0] && op.p[2] && op.p[3] && op.p[4] && op.p[5], "mask_merge: null pointer");
+  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && Hlb > 0 && Wlb > 0 && H0 > 0 && W0 > 0, "mask_merge: bad dims");
+  const float sy = (float)mh / (float)Hlb, sx = (float)mw / (float)Wlb;
+  dim3 grid((H0 * W0 + 255) / 256, N);
+  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), 0, s, (const float*)op.p[0], (const int*)op.p[2], (const int*)op.p[3], (const int*)op.p[5],
+                     (uint8_t*)op.p[4], mh, mw, max_det, Hlb, Wlb, H0, W0, sy, sx);
+  MSL_CHECK_LAUNCH("mask_merge");
+  return MSL_OK;
+}

@@ -1,0 +1,98 @@
+// Shared device/host helpers for libmslesseg_hip (gfx950 only — no other target is supported or guarded for).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mslesseg_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void msl_set_error(const char* fmt, ...);
+
+#define MSL_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      msl_set_error(__VA_ARGS__);       \
+      return MSL_EINVAL;                \
+    }                                   \
+  } while (0)
+
+#define MSL_CHECK_LAUNCH(what)                                               \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      msl_set_error("%s: %s", what, hipGetErrorString(e_));                  \
+      return MSL_ELAUNCH;                                                    \
+    }                                                                        \
+  } while (0)
+
+// ---- element access for the two storage types -----------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+template <bool F32>
+struct Elem;
+template <>
+struct Elem<true> {
+  typedef float T;
+  static constexpr int SIZE = 4;
+  static constexpr int VEC = 4;  // elements per 16 bytes
+  __device__ static __forceinline__ float ld(const void* p, long i) { return ((const float*)p)[i]; }
+  __device__ static __forceinline__ void st(void* p, long i, float v) { ((float*)p)[i] = v; }
+};
+template <>
+struct Elem<false> {
+  typedef unsigned short T;
+  static constexpr int SIZE = 2;
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const void* p, long i) { return bf16_bits_to_f32(((const unsigned short*)p)[i]); }
+  __device__ static __forceinline__ void st(void* p, long i, float v) { ((unsigned short*)p)[i] = (unsigned short)f32_to_bf16_bits(v); }
+};
+
+// load / store 4 consecutive elements (i multiple of 4) as floats
+template <bool F32>
+__device__ __forceinline__ void ld4(const void* p, long i, float (&v)[4]) {
+  if constexpr (F32) {
+    float4 t = *(const float4*)((const float*)p + i);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    uint2 t = *(const uint2*)((const unsigned short*)p + i);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void st4(void* p, long i, const float (&v)[4]) {
+  if constexpr (F32) {
+    *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 t;
+    t.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+    t.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+    *(uint2*)((unsigned short*)p + i) = t;
+  }
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// op launchers (one per translation unit)
+int msl_launch_conv(const msl_op& op, hipStream_t s);
+int msl_launch_stem(const msl_op& op, hipStream_t s);
+int msl_launch_dwconv(const msl_op& op, hipStream_t s);
+int msl_launch_sppf_pool(const msl_op& op, hipStream_t s);
+int msl_launch_upsample2x(const msl_op& op, hipStream_t s);
+int msl_launch_attention(const msl_op& op, hipStream_t s);
+int msl_launch_head_decode(const msl_op& op, hipStream_t s);
+int msl_launch_nms(const msl_op& op, hipStream_t s);
+int msl_launch_mask_lowres(const msl_op& op, hipStream_t s);
+int msl_launch_mask_upsample(const msl_op& op, hipStream_t s);
+int msl_launch_mask_merge(const msl_op& op, hipStream_t s);
+int msl_launch_letterbox(const msl_op& op, hipStream_t s);
+int msl_launch_vol_insert(const msl_op& op, hipStream_t s);
+int msl_launch_vol_consensus(const msl_op& op, hipStream_t s);
+int msl_launch_vol_dice(const msl_op& op, hipStream_t s);

@@ -1,0 +1,348 @@
+"""Inference engine: packs folded weights for the HIP kernels and turns graph.walk into a fixed op program
+(one host call per forward; optionally one hipGraph replay).
+
+Replaces the arithmetic under ``modelo(img_array, verbose=False)[0]`` [REF generar_predicciones.py:114]
+and the batch-1 loop around it [REF generar_predicciones.py:205-222] with whole-batch programs.
+PyTorch is used for device memory and streams only; every kernel is in libmslesseg_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import geometry, graph, hiplib, params
+from .hiplib import MSL_BF16, MSL_F32, PRED_STRIDE
+
+CONF_THRES = 0.25  # [UPSTREAM predictor default conf]
+IOU_THRES = 0.7  # [REF trains/Base/…/args.yaml:41]
+MAX_DET = 300  # [REF …/args.yaml:42]
+
+
+def _dt(dtype: int) -> torch.dtype:
+    return torch.float32 if dtype == MSL_F32 else torch.bfloat16
+
+
+class View:
+    """A channel slice of an NHWC activation buffer."""
+
+    __slots__ = ("t", "N", "H", "W", "C", "cs", "co", "f32")
+
+    def __init__(self, t, N, H, W, C, cs, co, f32=False):
+        self.t, self.N, self.H, self.W, self.C, self.cs, self.co, self.f32 = t, N, H, W, C, cs, co, f32
+
+    def torch(self) -> torch.Tensor:
+        """[N,H,W,C] strided torch view (for tests)."""
+        return self.t.view(self.N, self.H, self.W, self.cs)[..., self.co : self.co + self.C]
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,k,k] → GEMM rows [Cout, (ky,kx,ci)] matching the NHWC gather order of conv_igemm."""
+    cout, cin, k, _ = w.shape
+    return w.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+
+
+def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
+    """Zero-pad GEMM weights to [Cout_pad(16)][Kpad(K-step)] in the op dtype; bias stays fp32."""
+    kstep = 16 if dtype == MSL_F32 else 32
+    cout, K = wg.shape
+    cout_pad = (cout + 15) // 16 * 16
+    kpad = (K + kstep - 1) // kstep * kstep
+    wp = torch.zeros(cout_pad, kpad, dtype=torch.float32)
+    wp[:cout, :K] = wg
+    bp = torch.zeros(cout_pad, dtype=torch.float32)
+    bp[:cout] = b
+    return wp.to(_dt(dtype)).contiguous().to(device), bp.to(device), dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
+
+
+class PackedWeights:
+    """Folded Conv+BN weights laid out for the kernels, per dtype; shape independent."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], scale: str, nc: int, dtype: int, device):
+        self.scale, self.nc, self.dtype, self.device = scale, nc, dtype, device
+        self.specs = params.param_specs(scale, nc)
+        self.t: Dict[str, Tuple[torch.Tensor, torch.Tensor, dict]] = {}
+        kstep = 16 if dtype == MSL_F32 else 32
+        for name, s in self.specs.items():
+            w, b = params.folded(state, name, s)
+            if s["kind"] == "convT":  # [Cin,Cout,2,2] → GEMM rows (dy*2+dx)*Cout+co, K = Cin
+                cin, cout = s["cin"], s["cout"]
+                wg = w.permute(2, 3, 1, 0).reshape(4 * cout, cin)
+                bg = b.repeat(4)
+                self._pack_gemm(name, wg, bg, kstep)
+            elif s.get("stem"):
+                wg = w.permute(2, 3, 1, 0).reshape(27, s["cout"]).contiguous()  # (ky,kx,ci) major, ci in RGB order
+                self.t[name] = (wg.to(device), b.contiguous().to(device), {})
+            elif s["groups"] > 1:
+                wg = w.view(s["cout"], 9).t().contiguous()  # [9][C]
+                self.t[name] = (wg.to(device), b.contiguous().to(device), {})
+            else:
+                cout, cin, k = s["cout"], s["cin"], s["k"]
+                self._pack_gemm(name, pack_conv_weight(w), b, kstep)
+
+    def _pack_gemm(self, name, wg, b, kstep):
+        self.t[name] = pack_gemm(wg, b, self.dtype, self.device)
+
+
+class ProgramBuilder(graph.Visitor):
+    """graph.Visitor that allocates buffers and emits msl_op descriptors for a fixed (N, Hlb, Wlb)."""
+
+    def __init__(self, weights: PackedWeights, N: int, Hlb: int, Wlb: int):
+        self.w, self.N, self.Hlb, self.Wlb = weights, N, Hlb, Wlb
+        self.dtype, self.device = weights.dtype, weights.device
+        self.ops = []
+        self.names = []  # op index → layer name (profiling / tests)
+        self.taps: Dict[str, View] = {}  # layer name → output view (tests)
+        self.levels = {}
+        self.proto_view: Optional[View] = None
+        self.in_view: Optional[View] = None
+
+    # -- helpers
+    def _new(self, H, W, C, f32=False) -> View:
+        t = torch.empty(self.N * H * W * C, dtype=torch.float32 if f32 else _dt(self.dtype), device=self.device)
+        return View(t, self.N, H, W, C, C, 0, f32)
+
+    def _emit(self, name, op):
+        self.ops.append(op)
+        self.names.append(name)
+
+    # -- Visitor
+    def input(self):
+        t = torch.empty(self.N * self.Hlb * self.Wlb * 3, dtype=torch.uint8, device=self.device)
+        self.in_view = View(t, self.N, self.Hlb, self.Wlb, 3, 3, 0)
+        return self.in_view
+
+    def stem(self, name, x, cout):
+        Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        y = self._new(Ho, Wo, cout)
+        wt, bt, _ = self.w.t[name]
+        self._emit(name, hiplib.make_op(hiplib.OP_STEM, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.t.data_ptr()),
+                                        i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: y.cs, 13: y.co, 18: 1}))
+        self.taps[name] = y
+        return y
+
+    def conv(self, name, x, cout, k=1, s=1, act=True, bn=True, out=None, res=None, f32_out=False):
+        pad = k // 2
+        Ho, Wo = (x.H + 2 * pad - k) // s + 1, (x.W + 2 * pad - k) // s + 1
+        y = out if out is not None else self._new(Ho, Wo, cout, f32=f32_out)
+        assert (y.H, y.W, y.C) == (Ho, Wo, cout), (name, (y.H, y.W, y.C), (Ho, Wo, cout))
+        wt, bt, m = self.w.t[name]
+        i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
+             16: m["K"], 17: m["Kpad"], 18: 1 if act else 0, 19: 1 if f32_out else 0, 20: 0, 21: m["Cout_pad"]}
+        rp = 0
+        if res is not None:
+            assert (res.H, res.W, res.C) == (Ho, Wo, cout), name
+            i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
+        self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), rp, y.t.data_ptr()), i=i))
+        self.taps[name] = y
+        return y
+
+    def convT2x2(self, name, x, cout):
+        y = self._new(2 * x.H, 2 * x.W, cout)
+        wt, bt, m = self.w.t[name]
+        i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: x.H, 5: x.W, 6: 4 * cout, 7: 1, 8: 1, 9: 0, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
+             16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 1, 21: m["Cout_pad"]}
+        self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.t.data_ptr()), i=i))
+        self.taps[name] = y
+        return y
+
+    def dwconv(self, name, x, act=True, res=None, gmap=None, out=None):
+        C = x.C if gmap is None else x.C // gmap[1] * gmap[0]
+        y = out if out is not None else self._new(x.H, x.W, C)
+        wt, bt, _ = self.w.t[name]
+        i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co, 18: 1 if act else 0}
+        if gmap is not None:
+            i[22], i[23], i[24] = gmap
+        rp = 0
+        if res is not None:
+            i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
+        self._emit(name, hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), rp, y.t.data_ptr()), i=i))
+        self.taps[name] = y
+        return y
+
+    def cat_buffer(self, like, C, scale=1.0):
+        return self._new(like.H, like.W, C)
+
+    def view(self, buf, c0, c):
+        return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32)
+
+    def upsample2x(self, x, out):
+        assert (out.H, out.W, out.C) == (2 * x.H, 2 * x.W, x.C)
+        self._emit("upsample", hiplib.make_op(hiplib.OP_UPSAMPLE2X, self.dtype, p=(x.t.data_ptr(), 0, 0, 0, out.t.data_ptr()),
+                                              i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: x.cs, 11: x.co, 12: out.cs, 13: out.co}))
+        return out
+
+    def sppf_pool(self, buf, c):
+        self._emit("sppf_pool", hiplib.make_op(hiplib.OP_SPPF_POOL, self.dtype, p=(buf.t.data_ptr(),),
+                                               i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co}))
+
+    def attention(self, qkv, heads, kd, hd):
+        y = self._new(qkv.H, qkv.W, heads * hd)
+        self._emit("attention", hiplib.make_op(hiplib.OP_ATTENTION, self.dtype, p=(qkv.t.data_ptr(), 0, 0, 0, y.t.data_ptr()),
+                                               i={0: self.N, 1: qkv.H, 2: qkv.W, 3: heads, 4: kd, 5: hd, 10: qkv.cs, 11: qkv.co, 12: y.cs, 13: y.co},
+                                               f=(kd**-0.5,)))
+        return y
+
+    def head_level(self, i, box, cls, coef):
+        self.levels[i] = (box, cls, coef)
+
+    def proto(self, p):
+        self.proto_view = p
+
+
+class Plan:
+    """Buffers + programs for one (N, Hlb, Wlb): network forward, decode, NMS, low-res masks."""
+
+    def __init__(self, weights: PackedWeights, N: int, Hlb: int, Wlb: int, conf=CONF_THRES, iou=IOU_THRES, max_det=MAX_DET):
+        assert Hlb % 32 == 0 and Wlb % 32 == 0, "letterboxed size must be a multiple of the model stride"
+        self.N, self.Hlb, self.Wlb, self.max_det = N, Hlb, Wlb, max_det
+        self.dtype, self.device, self.nc = weights.dtype, weights.device, weights.nc
+        b = ProgramBuilder(weights, N, Hlb, Wlb)
+        graph.walk(b, weights.scale, weights.nc)
+        self.builder = b
+        self.input = b.in_view
+        self.proto = b.proto_view
+        self.n_net_ops = len(b.ops)
+        dev = self.device
+        self.A = sum(v[0].H * v[0].W for v in b.levels.values())
+        self.pred = torch.empty(N, self.A, PRED_STRIDE, dtype=torch.float32, device=dev)
+        self.keep_idx = torch.zeros(N, max_det, dtype=torch.int32, device=dev)
+        self.keep_cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.det = torch.zeros(N, max_det, PRED_STRIDE, dtype=torch.float32, device=dev)
+        mh, mw = self.proto.H, self.proto.W
+        self.lowres = torch.empty(N, max_det, mh, mw, dtype=torch.float32, device=dev)
+        aoff = 0
+        for li in sorted(b.levels):
+            box, cls, coef = b.levels[li]
+            b._emit(f"decode.{li}", hiplib.make_op(hiplib.OP_HEAD_DECODE, self.dtype,
+                                                   p=(box.t.data_ptr(), cls.t.data_ptr(), coef.t.data_ptr(), 0, self.pred.data_ptr()),
+                                                   i={0: N, 1: box.H, 2: box.W, 3: self.nc, 4: graph.NM, 5: aoff, 6: self.A},
+                                                   f=(float(graph.STRIDES[li]),)))
+            aoff += box.H * box.W
+        b._emit("nms", hiplib.make_op(hiplib.OP_NMS, self.dtype,
+                                      p=(self.pred.data_ptr(), self.keep_idx.data_ptr(), self.keep_cnt.data_ptr(), self.det.data_ptr()),
+                                      i={0: N, 6: self.A, 7: max_det}, f=(conf, iou)))
+        b._emit("mask_lowres", hiplib.make_op(hiplib.OP_MASK_LOWRES, self.dtype,
+                                              p=(self.proto.t.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), 0, self.lowres.data_ptr()),
+                                              i={0: N, 1: mh, 2: mw, 4: graph.NM, 7: max_det, 8: Hlb, 9: Wlb, 10: self.proto.cs, 11: self.proto.co}))
+        self.program = hiplib.Program(b.ops)
+        self.op_names = list(b.names)
+        self._merge = {}
+
+    def run(self, stream: Optional[int] = None, graph_replay: bool = False) -> None:
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        if graph_replay:
+            self.program.replay(s)
+        else:
+            self.program.run(s)
+
+    # ---- boundary B4: per-image masks at the letterboxed size
+    def masks(self):
+        """→ list over images of float32 [n_i, Hlb, Wlb] CUDA tensors in {0,1} (or None when nothing was kept)."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        cnt = self.keep_cnt.cpu()  # the one host sync of the boundary path
+        total = int(cnt.sum())
+        if total == 0:
+            return [None] * self.N
+        offsets = torch.zeros(self.N, dtype=torch.int32)
+        offsets[1:] = torch.cumsum(cnt, 0)[:-1]
+        off_dev = offsets.to(self.device)
+        out = torch.empty(total, self.Hlb, self.Wlb, dtype=torch.float32, device=self.device)
+        op = hiplib.make_op(hiplib.OP_MASK_UPSAMPLE, self.dtype,
+                            p=(self.lowres.data_ptr(), 0, self.keep_cnt.data_ptr(), off_dev.data_ptr(), out.data_ptr()),
+                            i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb})
+        hiplib.launch(op, s)
+        res = []
+        for n in range(self.N):
+            c, o = int(cnt[n]), int(offsets[n])
+            res.append(out[o : o + c] if c else None)
+        return res
+
+    # ---- fused reference post-processing: merged, re-oriented uint8 slices
+    def merged(self, H0: int, W0: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """→ uint8 [N, W0, H0] in {0,255}: combinar_predicciones + normalizar_prediccion on device."""
+        key = (H0, W0)
+        if key not in self._merge:
+            ytab = torch.from_numpy(geometry.nearest_table(H0, self.Hlb)).to(self.device)
+            xtab = torch.from_numpy(geometry.nearest_table(W0, self.Wlb)).to(self.device)
+            self._merge[key] = (ytab, xtab)
+        ytab, xtab = self._merge[key]
+        if out is None:
+            out = torch.empty(self.N, W0, H0, dtype=torch.uint8, device=self.device)
+        op = hiplib.make_op(hiplib.OP_MASK_MERGE, self.dtype,
+                            p=(self.lowres.data_ptr(), 0, self.keep_cnt.data_ptr(), ytab.data_ptr(), out.data_ptr(), xtab.data_ptr()),
+                            i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb, 10: H0, 11: W0})
+        hiplib.launch(op, torch.cuda.current_stream(self.device).cuda_stream)
+        return out
+
+    def head_tensor(self) -> torch.Tensor:
+        """[N, 4+nc+nm, A] in the upstream layout (tests; nc == 1)."""
+        p = self.pred
+        return torch.cat([p[..., :5], p[..., 6 : 6 + graph.NM]], -1).transpose(1, 2).contiguous()
+
+
+class LetterBoxProgram:
+    """Device LetterBox for a batch of equal-size uint8 slices [N,H0,W0,C] (C = 3 BGR or 1 grey)."""
+
+    def __init__(self, N, H0, W0, C, plan: Plan):
+        lb = geometry.letterbox_for(H0, W0)
+        assert (lb.hlb, lb.wlb) == (plan.Hlb, plan.Wlb)
+        self.lb, dev = lb, plan.device
+        self.src = torch.empty(N, H0, W0, C, dtype=torch.uint8, device=dev)
+        self.xtab = torch.from_numpy(geometry.linear_table(lb.wn, W0, True)).to(dev)
+        self.ytab = torch.from_numpy(geometry.linear_table(lb.hn, H0, False)).to(dev)
+        self.op = hiplib.make_op(hiplib.OP_LETTERBOX, plan.dtype,
+                                 p=(self.src.data_ptr(), self.xtab.data_ptr(), self.ytab.data_ptr(), 0, plan.input.t.data_ptr()),
+                                 i={0: N, 1: H0, 2: W0, 3: C, 4: lb.hn, 5: lb.wn, 6: lb.top, 7: lb.left, 8: lb.hlb, 9: lb.wlb,
+                                    10: geometry.PAD_VALUE, 11: 1 if lb.resize else 0})
+
+    def run(self, stream=None):
+        s = torch.cuda.current_stream(self.src.device).cuda_stream if stream is None else stream
+        hiplib.launch(self.op, s)
+
+
+class InferEngine:
+    """Weights + plan cache.  `dtype` MSL_BF16 (throughput) or MSL_F32 (exact-fp32 parity mode)."""
+
+    def __init__(self, state, scale: str, nc: int, dtype: int = MSL_BF16, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise hiplib.MslError("no GPU: the mslesseg_amd inference path runs only on the HIP kernels (no CPU fallback)")
+        hiplib.lib()
+        self.device = torch.device(device)
+        self.scale, self.nc, self.dtype = scale, nc, dtype
+        params.validate_state(state, scale, nc)
+        self.weights = PackedWeights(state, scale, nc, dtype, self.device)
+        self._plans: Dict[Tuple[int, int, int], Plan] = {}
+        self._lb: Dict[Tuple[int, int, int, int], LetterBoxProgram] = {}
+
+    def plan(self, N: int, Hlb: int, Wlb: int) -> Plan:
+        key = (N, Hlb, Wlb)
+        if key not in self._plans:
+            self._plans[key] = Plan(self.weights, N, Hlb, Wlb)
+        return self._plans[key]
+
+    def letterbox(self, N, H0, W0, C) -> Tuple[LetterBoxProgram, Plan]:
+        key = (N, H0, W0, C)
+        if key not in self._lb:
+            lb = geometry.letterbox_for(H0, W0)
+            plan = self.plan(N, lb.hlb, lb.wlb)
+            self._lb[key] = LetterBoxProgram(N, H0, W0, C, plan)
+        p = self._lb[key]
+        return p, self.plan(N, p.lb.hlb, p.lb.wlb)
+
+    def predict_batch(self, imgs: torch.Tensor, graph_replay: bool = False) -> Plan:
+        """imgs uint8 [N,H0,W0,C] (host or device) → runs letterbox + network + decode + NMS + low-res masks."""
+        N, H0, W0, C = imgs.shape
+        lbp, plan = self.letterbox(N, H0, W0, C)
+        lbp.src.copy_(imgs, non_blocking=True)
+        lbp.run()
+        plan.run(graph_replay=graph_replay)
+        return plan
+
+    def predict_slices(self, imgs: torch.Tensor, graph_replay: bool = False) -> torch.Tensor:
+        """Whole-batch replacement of generar_prediccion_2D [REF generar_predicciones.py:175-187] minus the PNG write:
+        uint8 [N,H0,W0,C] → uint8 [N,W0,H0] in {0,255} (device tensor; one D2H is left to the caller)."""
+        plan = self.predict_batch(imgs, graph_replay)
+        return plan.merged(imgs.shape[1], imgs.shape[2])

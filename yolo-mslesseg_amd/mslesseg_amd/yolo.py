@@ -1,0 +1,197 @@
+"""Drop-in for the five ultralytics call sites of the reference:
+
+  B1  YOLO(model_path)                                  [REF yolo_mslesseg/utils/utils.py:232-237]
+  B2  model.train(data=, epochs=, batch=-1, cache=True, project=, name=, verbose=False)
+                                                        [REF yolo_mslesseg/scripts/train.py:358-366]
+  B3  model(img_array, verbose=False)[0]                [REF yolo_mslesseg/scripts/generar_predicciones.py:114]
+  B4  .masks is None  |  .masks.data.cpu().numpy()      [REF generar_predicciones.py:118-120]
+
+plus the batched entry points the reference's per-slice loop is replaced with (predict_slices / predict_volume).
+Errors are plain Python exceptions (the reference wraps them in RuntimeError itself).  One model object per
+process, synchronous, not re-entrant — same as the reference's usage.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import re
+from pathlib import Path
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import geometry, params
+from .hiplib import MSL_BF16, MSL_F32
+
+LOGGER = logging.getLogger("ultralytics")
+_NAME_RE = re.compile(r"^yolo11([nsmlx])-seg(\.pt|\.yaml)?$")
+
+
+def _precision(p: Optional[str]) -> int:
+    p = (p or os.environ.get("MSLESSEG_PRECISION", "bf16")).lower()
+    if p in ("bf16", "bfloat16"):
+        return MSL_BF16
+    if p in ("fp32", "f32", "float32"):
+        return MSL_F32
+    raise ValueError(f"unknown precision {p!r} (bf16 | fp32)")
+
+
+class Masks:
+    """`.data`: float32 [n, Hlb, Wlb] in {0,1} at the LETTERBOXED size (the reference resizes from there itself)."""
+
+    def __init__(self, data: torch.Tensor, orig_shape):
+        self.data, self.orig_shape = data, orig_shape
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def cpu(self):
+        return Masks(self.data.cpu(), self.orig_shape)
+
+    def numpy(self):
+        return self.data.cpu().numpy()
+
+
+class Boxes:
+    """`.data`: [n, 6] = xyxy (letterboxed pixels mapped back to the original image), conf, cls."""
+
+    def __init__(self, data: torch.Tensor, orig_shape):
+        self.data, self.orig_shape = data, orig_shape
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    @property
+    def xyxy(self):
+        return self.data[:, :4]
+
+    @property
+    def conf(self):
+        return self.data[:, 4]
+
+    @property
+    def cls(self):
+        return self.data[:, 5]
+
+
+class Results:
+    def __init__(self, orig_img, names, boxes: Optional[Boxes], masks: Optional[Masks], path=None):
+        self.orig_img, self.orig_shape = orig_img, orig_img.shape[:2]
+        self.names, self.boxes, self.masks, self.path = names, boxes, masks, path
+
+    def __len__(self):
+        return 0 if self.boxes is None else len(self.boxes)
+
+
+def _scale_boxes(lb: geometry.LetterBox, xyxy: torch.Tensor) -> torch.Tensor:
+    """[UPSTREAM ops.scale_boxes]: undo the letterbox (gain = min ratio, pad with the ±0.1 rounding), clip."""
+    gain = min(lb.hlb / lb.h0, lb.wlb / lb.w0)
+    pad_x = round((lb.wlb - lb.w0 * gain) / 2 - 0.1)
+    pad_y = round((lb.hlb - lb.h0 * gain) / 2 - 0.1)
+    out = xyxy.clone()
+    out[:, [0, 2]] -= pad_x
+    out[:, [1, 3]] -= pad_y
+    out /= gain
+    out[:, [0, 2]] = out[:, [0, 2]].clamp(0, lb.w0)
+    out[:, [1, 3]] = out[:, [1, 3]].clamp(0, lb.h0)
+    return out
+
+
+class YOLO:
+    def __init__(self, model: Union[str, Path] = "yolo11n-seg.pt", task=None, verbose: bool = False, precision: Optional[str] = None,
+                 device: str = "cuda:0"):
+        self.ckpt_path = Path(model)
+        self.task = task or "segment"
+        self.device = device
+        self.dtype = _precision(precision)
+        self.names = {0: "lesion"}
+        self._engine = None
+        self.trainer = None
+        if self.ckpt_path.is_file():
+            ck = params.load_checkpoint(self.ckpt_path)
+            self.scale, self.nc, self.state = ck["scale"], int(ck["nc"]), ck["state"]
+            self.names = {int(k): v for k, v in ck.get("names", {}).items()} or {i: str(i) for i in range(self.nc)}
+            self.pretrained = True
+        else:
+            m = _NAME_RE.match(self.ckpt_path.name)
+            if not m:
+                raise FileNotFoundError(f"{model}: no such checkpoint")
+            # The reference passes the bare name "yolo11n-seg.pt" and lets ultralytics download COCO weights
+            # [REF ConfigTrain.py:139].  There is no network here and none is ever attempted: the model starts from
+            # a seeded random initialisation instead.
+            self.scale, self.nc, self.state = m.group(1), 80, None
+            self.pretrained = False
+            LOGGER.warning(f"{model} not found: starting from random initialisation (no download is attempted)")
+
+    # ------------------------------------------------------------------ inference
+    def _get_engine(self):
+        if self._engine is None:
+            from .engine import InferEngine
+
+            if self.state is None:
+                self.state = params.init_state(self.scale, self.nc, seed=0)
+            self._engine = InferEngine({k: (v.float() if v.is_floating_point() else v) for k, v in self.state.items()},
+                                       self.scale, self.nc, self.dtype, self.device)
+        return self._engine
+
+    @staticmethod
+    def _load_image(src) -> np.ndarray:
+        if isinstance(src, (str, Path)):
+            from PIL import Image
+
+            rgb = np.asarray(Image.open(src).convert("RGB"))
+            return np.ascontiguousarray(rgb[..., ::-1])  # cv2.imread order (BGR)
+        arr = np.asarray(src)
+        if arr.ndim == 2:
+            arr = np.repeat(arr[..., None], 3, axis=2)
+        if arr.ndim != 3 or arr.shape[2] != 3 or arr.dtype != np.uint8:
+            raise TypeError(f"expected uint8 HxWx3 BGR array, got {arr.dtype} {arr.shape}")
+        return np.ascontiguousarray(arr)
+
+    def predict(self, source, verbose: bool = False, **kwargs) -> List[Results]:
+        srcs = list(source) if isinstance(source, (list, tuple)) else [source]
+        imgs = [self._load_image(s) for s in srcs]
+        eng = self._get_engine()
+        results: List[Optional[Results]] = [None] * len(imgs)
+        by_shape = {}
+        for i, im in enumerate(imgs):
+            by_shape.setdefault(im.shape, []).append(i)
+        for shape, idxs in by_shape.items():
+            batch = torch.from_numpy(np.stack([imgs[i] for i in idxs]))
+            plan = eng.predict_batch(batch)
+            masks = plan.masks()  # syncs on keep_cnt
+            cnt = plan.keep_cnt.cpu()
+            det = plan.det.cpu()
+            lb = geometry.letterbox_for(shape[0], shape[1])
+            for j, i in enumerate(idxs):
+                n = int(cnt[j])
+                if n == 0:
+                    results[i] = Results(imgs[i], self.names, None, None)
+                    continue
+                rows = det[j, :n]
+                boxes = torch.cat([_scale_boxes(lb, rows[:, :4]), rows[:, 4:6]], 1)
+                results[i] = Results(imgs[i], self.names, Boxes(boxes, shape[:2]), Masks(masks[j], shape[:2]),
+                                     path=srcs[i] if isinstance(srcs[i], (str, Path)) else None)
+        return results  # type: ignore[return-value]
+
+    __call__ = predict
+
+    def predict_slices(self, imgs: Union[np.ndarray, torch.Tensor]) -> np.ndarray:
+        """uint8 [N,H,W,3|1] slices of one shape → uint8 [N,W,H] in {0,255}: exactly what the reference writes to
+        pred_masks/*.png per slice [REF generar_predicciones.py:175-187], for the whole batch in one pass."""
+        t = torch.from_numpy(np.ascontiguousarray(imgs)) if isinstance(imgs, np.ndarray) else imgs
+        return self._get_engine().predict_slices(t).cpu().numpy()
+
+    # ------------------------------------------------------------------ training (B2)
+    def train(self, data=None, epochs: int = 100, batch: int = -1, cache: bool = True, project=None, name: str = "train",
+              verbose: bool = False, **kwargs):
+        from .train import Trainer  # noqa: PLC0415  (imports the training kernels lazily)
+
+        self.trainer = Trainer(self, data=data, epochs=epochs, batch=batch, cache=cache, project=project, name=name, verbose=verbose, **kwargs)
+        return self.trainer.fit()
+
+    def save(self, path) -> None:
+        if self.state is None:
+            self.state = params.init_state(self.scale, self.nc, seed=0)
+        params.save_checkpoint(path, self.state, self.scale, self.nc, self.names)
