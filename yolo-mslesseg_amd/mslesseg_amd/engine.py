@@ -277,6 +277,53 @@ class Plan:
         hiplib.launch(op, torch.cuda.current_stream(self.device).cuda_stream)
         return out
 
+    # ---- measurement
+    def time_ops(self, reps: int = 5):
+        """Per-op device time with HIP events recorded on the launch stream: → [(name, kind, mean ms)]."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        n = self.program.n
+        evs = [[hiplib.Event() for _ in range(n + 1)] for _ in range(reps)]
+        for r in range(reps):
+            evs[r][0].record(s)
+            for i in range(n):
+                hiplib.launch(self.program.arr[i], s)
+                evs[r][i + 1].record(s)
+        torch.cuda.synchronize(self.device)
+        out = []
+        for i in range(n):
+            ms = sum(evs[r][i].elapsed_ms(evs[r][i + 1]) for r in range(reps)) / reps
+            out.append((self.op_names[i], int(self.program.arr[i].kind), ms))
+        return out
+
+    def op_cost(self, i: int):
+        """Algorithmic (flops, bytes) of op i: 2*MAC for conv/attention GEMM work; bytes = input view + output view
+        + weights, each touched once."""
+        op = self.program.arr[i]
+        es = 4 if self.dtype == MSL_F32 else 2
+        I = op.i
+        if op.kind == hiplib.OP_CONV:
+            N, H, W, Cin, Ho, Wo, Cout, K = I[0], I[1], I[2], I[3], I[4], I[5], I[6], I[16]
+            flops = 2.0 * N * Ho * Wo * Cout * K
+            out_es = 4 if I[19] else es
+            npix_out = N * Ho * Wo * (4 if I[20] == 1 else 1)
+            cout_store = Cout // 4 if I[20] == 1 else Cout
+            byts = N * H * W * Cin * es + npix_out * cout_store * out_es + Cout * K * es + (N * Ho * Wo * Cout * es if op.p[3] else 0)
+            return flops, float(byts)
+        if op.kind == hiplib.OP_STEM:
+            N, H, W, Ho, Wo, Cout = I[0], I[1], I[2], I[4], I[5], I[6]
+            return 2.0 * N * Ho * Wo * Cout * 27, float(N * H * W * 3 + N * Ho * Wo * Cout * es)
+        if op.kind == hiplib.OP_DWCONV:
+            N, H, W, C = I[0], I[1], I[2], I[3]
+            return 2.0 * N * H * W * C * 9, float(N * H * W * C * es * (3 if op.p[3] else 2))
+        if op.kind == hiplib.OP_ATTENTION:
+            N, HW, heads, kd, hd = I[0], I[1] * I[2], I[3], I[4], I[5]
+            return 2.0 * N * heads * HW * HW * (kd + hd), float(N * HW * heads * (2 * kd + 2 * hd) * es)
+        if op.kind == hiplib.OP_SPPF_POOL:
+            return 0.0, float(I[0] * I[1] * I[2] * I[3] * es * 4)
+        if op.kind == hiplib.OP_UPSAMPLE2X:
+            return 0.0, float(I[0] * I[1] * I[2] * I[3] * es * 5)
+        return 0.0, 0.0
+
     def head_tensor(self) -> torch.Tensor:
         """[N, 4+nc+nm, A] in the upstream layout (tests; nc == 1)."""
         p = self.pred
