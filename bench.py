@@ -141,7 +141,7 @@ def main():
         total_ms = sum(t[2] for t in table)
         conv_ms = sum(t[2] for t in table if t[1] == hiplib.OP_CONV)
         conv_flops = sum(c[0] for t, c in zip(table, costs) if t[1] == hiplib.OP_CONV)
-        dom = max(range(len(table)), key=lambda i: table[i][2])
+        dom = max((i for i in range(len(table)) if table[i][1] == hiplib.OP_CONV), key=lambda i: table[i][2])  # dominant MFMA kernel launch
         d_name, d_kind, d_ms = table[dom]
         d_flops, d_bytes = costs[dom]
         peak = PEAK_MFMA_BF16_TFLOPS if dtype == MSL_BF16 else PEAK_MFMA_F32_TFLOPS
@@ -163,6 +163,15 @@ def main():
                          "ms": round(conv_ms, 3), "share_of_step": round(conv_ms / total_ms, 3)},
             "whole_net_frac_of_mfma_roof": round(value / world * FWD_GFLOP_PER_SLICE_640 * (S * S / 640.0 / 640.0) / 1e3 / peak, 4),
         }
+        # letterbox + merge are launched outside the op program: time them the same way
+        ev = [hiplib.Event() for _ in range(3)]
+        lbp, _ = eng.letterbox(B, S, S, 3)
+        st_ = torch.cuda.current_stream(dev).cuda_stream
+        ev[0].record(st_); lbp.run(); ev[1].record(st_); lb_plan.merged(S, S, out=out); ev[2].record(st_)
+        torch.cuda.synchronize(dev)
+        extra = {"letterbox_ms": round(ev[0].elapsed_ms(ev[1]), 4), "mask_merge_ms": round(ev[1].elapsed_ms(ev[2]), 4),
+                 "program_ms": round(total_ms, 3)}
+        roofline["step_breakdown"] = extra
         if args.op_table:
             with open(args.op_table, "w") as f:
                 f.write(f"# per-op HIP-event times, batch {B}, {S}x{S}, {args.dtype}; total {total_ms:.3f} ms\n")

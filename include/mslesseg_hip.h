@@ -88,16 +88,18 @@ enum {
    *      (xyxy, conf, cls, coeffs of the kept rows, in keep order)
    * i: 0 N,6 A,7 max_det ; f: 0 conf_thres, 1 iou_thres */
   MSL_OP_NMS = 8,
-  /* Low-resolution instance logits: lowres[n,d,y,x] = crop_d(y,x) * sum_c det[n,d].coef[c]*proto[n,y,x,c]
+  /* Low-resolution instance logits: lowres[n,d,y,x] = sum_c det[n,d].coef[c]*proto[n,y,x,c], written ONLY inside the
+   * instance's crop box (outside it the value is 0 by definition; MASK_UPSAMPLE / MASK_MERGE apply the same box test per tap)
    * p: 0 proto (op dtype) [N,mh,mw,nm] view, 1 det, 2 keep_cnt, 4 lowres f32 [N,max_det,mh,mw]
    * i: 0 N,1 mh,2 mw,4 nm,7 max_det,10 x_cs,11 x_co, 8 Hlb, 9 Wlb */
   MSL_OP_MASK_LOWRES = 9,
   /* Boundary masks (B4): bilinear (align_corners=False) upsample of lowres to (Hlb,Wlb), > 0 → 1.0f/0.0f
-   * p: 0 lowres, 2 keep_cnt, 4 masks f32 [N,max_det,Hlb,Wlb] ; i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb */
+   * p: 0 lowres, 1 det, 2 keep_cnt, 3 offsets i32[N] (exclusive prefix sum of keep_cnt), 4 masks f32 [sum(keep_cnt),Hlb,Wlb]
+   * i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb */
   MSL_OP_MASK_UPSAMPLE = 10,
   /* Fused reference post-processing (combinar_predicciones + normalizar_prediccion): OR over instances of the
    * upsampled mask sampled at OpenCV-INTER_NEAREST positions of the original (H0,W0) grid, transposed and
-   * flipped, times 255.   p: 0 lowres, 2 keep_cnt, 3 ytab i32[H0], 5 xtab i32[W0], 4 out u8 [N,W0,H0]
+   * flipped, times 255.   p: 0 lowres, 1 det, 2 keep_cnt, 3 ytab i32[H0], 5 xtab i32[W0], 4 out u8 [N,W0,H0]
    * i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb,10 H0,11 W0 */
   MSL_OP_MASK_MERGE = 11,
   /* LetterBox: fixed-point INTER_LINEAR resize (OpenCV 8-bit scheme) + constant border + BGR→RGB.

@@ -193,14 +193,12 @@ __global__ __launch_bounds__(256) void mask_lowres_kernel(const void* __restrict
   for (int d = 0; d < cnt; ++d) {
     const float* row = det + ((long)n * max_det + d) * MSL_PRED_STRIDE;
     const float bx1 = row[0] * wr, by1 = row[1] * hr, bx2 = row[2] * wr, by2 = row[3] * hr;
-    float v = 0.f;
-    if (fx >= bx1 && fx < bx2 && fy >= by1 && fy < by2) {
-      float acc = 0.f;
+    if (fx >= bx1 && fx < bx2 && fy >= by1 && fy < by2) {  // outside the crop the value is 0 by definition: never stored,
+      float acc = 0.f;                                       // never read (readers apply the same box test per tap)
 #pragma unroll
       for (int c = 0; c < 32; ++c) acc = fmaf(row[6 + c], pr[c], acc);
-      v = acc;
+      lowres[(((long)n * max_det + d) * mh + py) * mw + px] = acc;
     }
-    lowres[(((long)n * max_det + d) * mh + py) * mw + px] = v;
   }
 }
 
@@ -219,49 +217,81 @@ int msl_launch_mask_lowres(const msl_op& op, hipStream_t s) {
   return MSL_OK;
 }
 
-// bilinear sample (align_corners=False) of one low-res map at destination pixel (oy, ox) of an (Hout, Wout) grid
+// Bilinear taps (align_corners=False) of destination pixel (oy, ox) of an (Hout, Wout) grid in a (mh, mw) map.
 // [UPSTREAM F.interpolate(mode="bilinear"): src = scale*(dst+0.5)-0.5 clamped at 0; i1 = min(i0+1, in-1)]
-__device__ __forceinline__ float bilinear_at(const float* __restrict__ m, int mh, int mw, float sy, float sx, int oy, int ox) {
+struct Taps {
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+};
+__device__ __forceinline__ Taps make_taps(int mh, int mw, float sy, float sx, int oy, int ox) {
+  Taps t;
   float fy = sy * ((float)oy + 0.5f) - 0.5f;
   float fx = sx * ((float)ox + 0.5f) - 0.5f;
   fy = fy < 0.f ? 0.f : fy;
   fx = fx < 0.f ? 0.f : fx;
-  int y0 = min((int)fy, mh - 1), x0 = min((int)fx, mw - 1);
-  int y1 = min(y0 + 1, mh - 1), x1 = min(x0 + 1, mw - 1);
-  float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
-  float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-  float v00 = m[y0 * mw + x0], v01 = m[y0 * mw + x1], v10 = m[y1 * mw + x0], v11 = m[y1 * mw + x1];
-  return ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  t.y0 = min((int)fy, mh - 1);
+  t.x0 = min((int)fx, mw - 1);
+  t.y1 = min(t.y0 + 1, mh - 1);
+  t.x1 = min(t.x0 + 1, mw - 1);
+  t.ly1 = fminf(fmaxf(fy - (float)t.y0, 0.f), 1.f);
+  t.lx1 = fminf(fmaxf(fx - (float)t.x0, 0.f), 1.f);
+  t.ly0 = 1.f - t.ly1;
+  t.lx0 = 1.f - t.lx1;
+  return t;
+}
+// One instance's upsampled logit at those taps; `b` = crop box at proto scale (x1,y1,x2,y2).  Taps outside the crop
+// are 0 (crop_mask), and the low-res map is only defined inside it.
+__device__ __forceinline__ float sample_cropped(const float* __restrict__ m, int mw, const Taps& t, float4 b) {
+  const bool iy0 = (float)t.y0 >= b.y && (float)t.y0 < b.w, iy1 = (float)t.y1 >= b.y && (float)t.y1 < b.w;
+  const bool ix0 = (float)t.x0 >= b.x && (float)t.x0 < b.z, ix1 = (float)t.x1 >= b.x && (float)t.x1 < b.z;
+  if (!((iy0 || iy1) && (ix0 || ix1))) return 0.f;
+  const float v00 = (iy0 && ix0) ? m[t.y0 * mw + t.x0] : 0.f, v01 = (iy0 && ix1) ? m[t.y0 * mw + t.x1] : 0.f;
+  const float v10 = (iy1 && ix0) ? m[t.y1 * mw + t.x0] : 0.f, v11 = (iy1 && ix1) ? m[t.y1 * mw + t.x1] : 0.f;
+  return t.ly0 * (t.lx0 * v00 + t.lx1 * v01) + t.ly1 * (t.lx0 * v10 + t.lx1 * v11);
+}
+// stage the image's crop boxes (proto scale) in LDS
+__device__ __forceinline__ void stage_boxes(float4* sbox, const float* __restrict__ det, int n, int cnt, int max_det, float wr, float hr) {
+  for (int d = threadIdx.x; d < cnt; d += blockDim.x) {
+    const float* row = det + ((long)n * max_det + d) * MSL_PRED_STRIDE;
+    sbox[d] = make_float4(row[0] * wr, row[1] * hr, row[2] * wr, row[3] * hr);
+  }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Boundary masks (B4): [total_kept, Hlb, Wlb] float {0,1}.  [UPSTREAM process_mask upsample + gt_(0.0)]
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mask_upsample_kernel(const float* __restrict__ lowres, const int* __restrict__ keep_cnt,
-                                                            const int* __restrict__ offsets, float* __restrict__ masks, int mh, int mw,
-                                                            int max_det, int Hlb, int Wlb, float sy, float sx) {
+__global__ __launch_bounds__(256) void mask_upsample_kernel(const float* __restrict__ lowres, const float* __restrict__ det,
+                                                            const int* __restrict__ keep_cnt, const int* __restrict__ offsets,
+                                                            float* __restrict__ masks, int mh, int mw, int max_det, int Hlb, int Wlb,
+                                                            float sy, float sx, float wr, float hr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* sbox = (float4*)smem;
   const int n = blockIdx.y;
   const int cnt = keep_cnt[n];
   if (cnt == 0) return;
+  stage_boxes(sbox, det, n, cnt, max_det, wr, hr);
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= Hlb * Wlb) return;
   const int oy = pix / Wlb, ox = pix - oy * Wlb;
+  const Taps t = make_taps(mh, mw, sy, sx, oy, ox);
   const long off = offsets[n];
   for (int d = 0; d < cnt; ++d) {
     const float* m = lowres + ((long)n * max_det + d) * mh * mw;
-    float v = bilinear_at(m, mh, mw, sy, sx, oy, ox);
+    float v = sample_cropped(m, mw, t, sbox[d]);
     masks[(off + d) * (long)Hlb * Wlb + pix] = v > 0.f ? 1.f : 0.f;
   }
 }
 
 int msl_launch_mask_upsample(const msl_op& op, hipStream_t s) {
   int N = op.i[0], mh = op.i[1], mw = op.i[2], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9];
-  MSL_REQUIRE(op.p[0] && op.p[2] && op.p[3] && op.p[4], "mask_upsample: null pointer");
-  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && Hlb > 0 && Wlb > 0, "mask_upsample: bad dims");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4], "mask_upsample: null pointer");
+  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && max_det <= 2048 && Hlb > 0 && Wlb > 0, "mask_upsample: bad dims");
   const float sy = (float)mh / (float)Hlb, sx = (float)mw / (float)Wlb;
+  const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
   dim3 grid((Hlb * Wlb + 255) / 256, N);
-  hipLaunchKernelGGL(mask_upsample_kernel, grid, dim3(256), 0, s, (const float*)op.p[0], (const int*)op.p[2], (const int*)op.p[3], (float*)op.p[4],
-                     mh, mw, max_det, Hlb, Wlb, sy, sx);
+  hipLaunchKernelGGL(mask_upsample_kernel, grid, dim3(256), (size_t)max_det * 16, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2],
+                     (const int*)op.p[3], (float*)op.p[4], mh, mw, max_det, Hlb, Wlb, sy, sx, wr, hr);
   MSL_CHECK_LAUNCH("mask_upsample");
   return MSL_OK;
 }
@@ -271,31 +301,36 @@ int msl_launch_mask_upsample(const msl_op& op, hipStream_t s) {
 // mask at the letterbox pixel OpenCV INTER_NEAREST would pick; written transposed + horizontally flipped, x255.
 // [REF generar_predicciones.py:123-140 combinar_predicciones + normalizar_prediccion]
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict__ lowres, const int* __restrict__ keep_cnt,
-                                                         const int* __restrict__ ytab, const int* __restrict__ xtab, uint8_t* __restrict__ out,
-                                                         int mh, int mw, int max_det, int Hlb, int Wlb, int H0, int W0, float sy, float sx) {
+__global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict__ lowres, const float* __restrict__ det,
+                                                         const int* __restrict__ keep_cnt, const int* __restrict__ ytab,
+                                                         const int* __restrict__ xtab, uint8_t* __restrict__ out, int mh, int mw, int max_det,
+                                                         int Hlb, int Wlb, int H0, int W0, float sy, float sx, float wr, float hr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* sbox = (float4*)smem;
   const int n = blockIdx.y;
+  const int cnt = keep_cnt[n];
+  stage_boxes(sbox, det, n, cnt, max_det, wr, hr);
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= H0 * W0) return;
   const int y0 = pix / W0, x0 = pix - y0 * W0;
-  const int cnt = keep_cnt[n];
-  const int oy = ytab[y0], ox = xtab[x0];
+  const Taps t = make_taps(mh, mw, sy, sx, ytab[y0], xtab[x0]);
   bool on = false;
   for (int d = 0; d < cnt && !on; ++d) {
     const float* m = lowres + ((long)n * max_det + d) * mh * mw;
-    on = bilinear_at(m, mh, mw, sy, sx, oy, ox) > 0.f;
+    on = sample_cropped(m, mw, t, sbox[d]) > 0.f;
   }
   out[((long)n * W0 + x0) * H0 + (H0 - 1 - y0)] = on ? 255 : 0;
 }
 
 int msl_launch_mask_merge(const msl_op& op, hipStream_t s) {
   int N = op.i[0], mh = op.i[1], mw = op.i[2], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9], H0 = op.i[10], W0 = op.i[11];
-  MSL_REQUIRE(op.p[0] && op.p[2] && op.p[3] && op.p[4] && op.p[5], "mask_merge: null pointer");
-  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && Hlb > 0 && Wlb > 0 && H0 > 0 && W0 > 0, "mask_merge: bad dims");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5], "mask_merge: null pointer");
+  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && max_det <= 2048 && Hlb > 0 && Wlb > 0 && H0 > 0 && W0 > 0, "mask_merge: bad dims");
   const float sy = (float)mh / (float)Hlb, sx = (float)mw / (float)Wlb;
+  const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
   dim3 grid((H0 * W0 + 255) / 256, N);
-  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), 0, s, (const float*)op.p[0], (const int*)op.p[2], (const int*)op.p[3], (const int*)op.p[5],
-                     (uint8_t*)op.p[4], mh, mw, max_det, Hlb, Wlb, H0, W0, sy, sx);
+  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), (size_t)max_det * 16, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2],
+                     (const int*)op.p[3], (const int*)op.p[5], (uint8_t*)op.p[4], mh, mw, max_det, Hlb, Wlb, H0, W0, sy, sx, wr, hr);
   MSL_CHECK_LAUNCH("mask_merge");
   return MSL_OK;
 }

@@ -251,7 +251,7 @@ class Plan:
         off_dev = offsets.to(self.device)
         out = torch.empty(total, self.Hlb, self.Wlb, dtype=torch.float32, device=self.device)
         op = hiplib.make_op(hiplib.OP_MASK_UPSAMPLE, self.dtype,
-                            p=(self.lowres.data_ptr(), 0, self.keep_cnt.data_ptr(), off_dev.data_ptr(), out.data_ptr()),
+                            p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), off_dev.data_ptr(), out.data_ptr()),
                             i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb})
         hiplib.launch(op, s)
         res = []
@@ -272,7 +272,7 @@ class Plan:
         if out is None:
             out = torch.empty(self.N, W0, H0, dtype=torch.uint8, device=self.device)
         op = hiplib.make_op(hiplib.OP_MASK_MERGE, self.dtype,
-                            p=(self.lowres.data_ptr(), 0, self.keep_cnt.data_ptr(), ytab.data_ptr(), out.data_ptr(), xtab.data_ptr()),
+                            p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), ytab.data_ptr(), out.data_ptr(), xtab.data_ptr()),
                             i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb, 10: H0, 11: W0})
         hiplib.launch(op, torch.cuda.current_stream(self.device).cuda_stream)
         return out
