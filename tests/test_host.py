@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_op_struct_layout_matches_header(built_lib):
-    # int32 kind, dtype; 6 pointers; 26 int32; 4 floats  → 8 + 48 + 104 + 16
-    assert ctypes.sizeof(hiplib.MslOp) == 176
+    # int32 kind, dtype; 8 pointers; 26 int32; 4 floats  → 8 + 64 + 104 + 16
+    assert ctypes.sizeof(hiplib.MslOp) == 192
     header = (ROOT / "include" / "mslesseg_hip.h").read_text()
     kinds = dict(re.findall(r"^\s*(MSL_OP_\w+)\s*=\s*(\d+)", header, flags=re.M))
     for name, val in kinds.items():

@@ -26,7 +26,7 @@ class MslOp(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
         ("dtype", C.c_int32),
-        ("p", C.c_void_p * 6),
+        ("p", C.c_void_p * 8),
         ("i", C.c_int32 * 26),
         ("f", C.c_float * 4),
     ]
