@@ -316,27 +316,46 @@ __global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict
                                                          const int* __restrict__ ytab, const int* __restrict__ xtab, uint8_t* __restrict__ out,
                                                          int mh, int mw, int max_det, int Hlb, int Wlb, int H0, int W0, float sy, float sx,
                                                          float wr, float hr) {
+  // One workgroup = a 32x32 tile of the ORIGINAL grid.  Pixels are evaluated x-fastest (neighbouring lanes sample
+  // neighbouring proto pixels) and written y-fastest through an LDS transpose, because the output is the transposed,
+  // flipped image [W0][H0]: byte stores straight from the x-fastest mapping would each touch a different cache line.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* sbox = (float4*)smem;
-  const int n = blockIdx.y;
+  unsigned char* tile = smem + (size_t)max_det * 16;  // [32][33]
+  const int n = blockIdx.z;
   const int cnt = keep_cnt[n];
   stage_boxes(sbox, det, n, cnt, max_det, wr, hr);
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= H0 * W0) return;
-  const int y0 = pix / W0, x0 = pix - y0 * W0;
-  const Taps t = make_taps(mh, mw, sy, sx, ytab[y0], xtab[x0]);
-  // A positive bilinear value needs a positive in-box logit at one of the 4 taps (weights are >= 0): only instances inside
-  // [min first, max last] of the taps' recorded ranges can switch this pixel on.
+  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const unsigned* rg = range + (long)n * mh * mw;
-  const unsigned r00 = rg[t.y0 * mw + t.x0], r01 = rg[t.y0 * mw + t.x1], r10 = rg[t.y1 * mw + t.x0], r11 = rg[t.y1 * mw + t.x1];
-  const int dfirst = (int)min(min(r00 & 0xFFFFu, r01 & 0xFFFFu), min(r10 & 0xFFFFu, r11 & 0xFFFFu));
-  const int dlast = min((int)max(max(r00 >> 16, r01 >> 16), max(r10 >> 16, r11 >> 16)), cnt - 1);
-  bool on = false;
-  for (int d = dfirst; d <= dlast && !on; ++d) {
-    const float* m = lowres + ((long)n * max_det + d) * mh * mw;
-    on = sample_cropped(m, mw, t, sbox[d]) > 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int yl = ty + 8 * r;
+    const int y0 = Y0 + yl, x0 = X0 + tx;
+    bool on = false;
+    if (y0 < H0 && x0 < W0 && cnt > 0) {
+      const Taps t = make_taps(mh, mw, sy, sx, ytab[y0], xtab[x0]);
+      // A positive bilinear value needs a positive in-box logit at one of the 4 taps (weights are >= 0): only instances
+      // inside [min first, max last] of the taps' recorded ranges can switch this pixel on.
+      const unsigned r00 = rg[t.y0 * mw + t.x0], r01 = rg[t.y0 * mw + t.x1], r10 = rg[t.y1 * mw + t.x0], r11 = rg[t.y1 * mw + t.x1];
+      const int dfirst = (int)min(min(r00 & 0xFFFFu, r01 & 0xFFFFu), min(r10 & 0xFFFFu, r11 & 0xFFFFu));
+      const int dlast = min((int)max(max(r00 >> 16, r01 >> 16), max(r10 >> 16, r11 >> 16)), cnt - 1);
+      for (int d = dfirst; d <= dlast && !on; ++d) {
+        const float* m = lowres + ((long)n * max_det + d) * mh * mw;
+        on = sample_cropped(m, mw, t, sbox[d]) > 0.f;
+      }
+    }
+    tile[yl * 33 + tx] = on ? 255 : 0;
   }
-  out[((long)n * W0 + x0) * H0 + (H0 - 1 - y0)] = on ? 255 : 0;
+  __syncthreads();
+  // out[n][x0][H0-1-y0]: 32 consecutive lanes write 32 consecutive bytes (one x0, descending y0)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = r * 256 + threadIdx.x;
+    const int xl = idx >> 5, yl = 31 - (idx & 31);
+    const int y0 = Y0 + yl, x0 = X0 + xl;
+    if (y0 < H0 && x0 < W0) out[((long)n * W0 + x0) * H0 + (H0 - 1 - y0)] = tile[yl * 33 + xl];
+  }
 }
 
 int msl_launch_mask_merge(const msl_op& op, hipStream_t s) {
@@ -346,8 +365,8 @@ int msl_launch_mask_merge(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && max_det <= 2048 && Hlb > 0 && Wlb > 0 && H0 > 0 && W0 > 0, "mask_merge: bad dims");
   const float sy = (float)mh / (float)Hlb, sx = (float)mw / (float)Wlb;
   const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
-  dim3 grid((H0 * W0 + 255) / 256, N);
-  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), (size_t)max_det * 16, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2], range,
+  dim3 grid((W0 + 31) / 32, (H0 + 31) / 32, N);
+  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), (size_t)max_det * 16 + 32 * 33, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2], range,
                      (const int*)op.p[3], (const int*)op.p[5], (uint8_t*)op.p[4], mh, mw, max_det, Hlb, Wlb, H0, W0, sy, sx, wr, hr);
   MSL_CHECK_LAUNCH("mask_merge");
   return MSL_OK;
