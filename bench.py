@@ -171,6 +171,8 @@ def main():
         torch.cuda.synchronize(dev)
         extra = {"letterbox_ms": round(ev[0].elapsed_ms(ev[1]), 4), "mask_merge_ms": round(ev[1].elapsed_ms(ev[2]), 4),
                  "program_ms": round(total_ms, 3)}
+        extra["mean_kept_instances_per_slice"] = round(float(lb_plan.keep_cnt.float().mean().item()), 1)
+        extra["mask_on_fraction"] = round(float((out > 0).float().mean().item()), 3)
         roofline["step_breakdown"] = extra
         if args.op_table:
             with open(args.op_table, "w") as f:

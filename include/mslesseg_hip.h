@@ -92,7 +92,8 @@ enum {
    * instance's crop box (outside it the value is 0 by definition; MASK_UPSAMPLE / MASK_MERGE apply the same box test per tap)
    * p: 0 proto (op dtype) [N,mh,mw,nm] view, 1 det, 2 keep_cnt, 4 lowres f32 [N,max_det,mh,mw],
    *    5 range u32 [N,mh,mw] = first | last<<16 : instance-index range with a positive in-box logit at that proto pixel
-   *      (first = 0xFFFF when none) — lets MASK_MERGE skip every instance that cannot switch a pixel on
+   *      (first = 0xFFFF when none), 6 posbits u32 [N,mh,mw,ceil(max_det/32)]: bit d set iff instance d has a positive in-box
+   *      logit there (words beyond keep_cnt are not written) — lets MASK_MERGE skip every instance that cannot switch a pixel on
    * i: 0 N,1 mh,2 mw,4 nm,7 max_det,10 x_cs,11 x_co, 8 Hlb, 9 Wlb */
   MSL_OP_MASK_LOWRES = 9,
   /* Boundary masks (B4): bilinear (align_corners=False) upsample of lowres to (Hlb,Wlb), > 0 → 1.0f/0.0f
@@ -101,7 +102,7 @@ enum {
   MSL_OP_MASK_UPSAMPLE = 10,
   /* Fused reference post-processing (combinar_predicciones + normalizar_prediccion): OR over instances of the
    * upsampled mask sampled at OpenCV-INTER_NEAREST positions of the original (H0,W0) grid, transposed and
-   * flipped, times 255.   p: 0 lowres, 1 det, 2 keep_cnt, 3 ytab i32[H0], 5 xtab i32[W0], 6 range (from MASK_LOWRES), 4 out u8 [N,W0,H0]
+   * flipped, times 255.   p: 0 lowres, 1 det, 2 keep_cnt, 3 ytab i32[H0], 5 xtab i32[W0], 6 range, 7 posbits (both from MASK_LOWRES), 4 out u8 [N,W0,H0]
    * i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb,10 H0,11 W0 */
   MSL_OP_MASK_MERGE = 11,
   /* LetterBox: fixed-point INTER_LINEAR resize (OpenCV 8-bit scheme) + constant border + BGR→RGB.

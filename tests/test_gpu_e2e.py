@@ -234,8 +234,9 @@ def test_masks_and_merge_bit_exact_on_oracle_inputs(oracle_model, golden, k):
     proto_d = proto.permute(0, 2, 3, 1).contiguous().to(DEV)
     low = torch.full((1, 300, mh, mw), float('nan'), device=DEV)  # only in-box entries may ever be read
     rng_d = torch.zeros(1, mh, mw, dtype=torch.int32, device=DEV)
+    pbits_d = torch.full((1, mh, mw, 10), -1, dtype=torch.int32, device=DEV)
     s = torch.cuda.current_stream().cuda_stream
-    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_LOWRES, MSL_F32, p=(proto_d.data_ptr(), det_d.data_ptr(), cnt_d.data_ptr(), 0, low.data_ptr(), rng_d.data_ptr()),
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_LOWRES, MSL_F32, p=(proto_d.data_ptr(), det_d.data_ptr(), cnt_d.data_ptr(), 0, low.data_ptr(), rng_d.data_ptr(), pbits_d.data_ptr()),
                                  i={0: 1, 1: mh, 2: mw, 4: 32, 7: 300, 8: Hlb, 9: Wlb, 10: 32, 11: 0}), s)
     off = torch.zeros(1, dtype=torch.int32, device=DEV)
     full = torch.zeros(n, Hlb, Wlb, device=DEV)
@@ -245,7 +246,7 @@ def test_masks_and_merge_bit_exact_on_oracle_inputs(oracle_model, golden, k):
     yt = torch.from_numpy(geometry.nearest_table(H0, Hlb)).to(DEV)
     xt = torch.from_numpy(geometry.nearest_table(W0, Wlb)).to(DEV)
     out = torch.zeros(1, W0, H0, dtype=torch.uint8, device=DEV)
-    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_MERGE, MSL_F32, p=(low.data_ptr(), det_d.data_ptr(), cnt_d.data_ptr(), yt.data_ptr(), out.data_ptr(), xt.data_ptr(), rng_d.data_ptr()),
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_MERGE, MSL_F32, p=(low.data_ptr(), det_d.data_ptr(), cnt_d.data_ptr(), yt.data_ptr(), out.data_ptr(), xt.data_ptr(), rng_d.data_ptr(), pbits_d.data_ptr()),
                                  i={0: 1, 1: mh, 2: mw, 7: 300, 8: Hlb, 9: Wlb, 10: H0, 11: W0}), s)
     torch.cuda.synchronize()
     # the oracle drops all-empty instance masks; compare on the union and per kept instance

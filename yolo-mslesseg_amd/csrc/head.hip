@@ -174,12 +174,14 @@ int msl_launch_nms(const msl_op& op, hipStream_t s) {
 template <bool F32>
 __global__ __launch_bounds__(256) void mask_lowres_kernel(const void* __restrict__ proto, const float* __restrict__ det,
                                                           const int* __restrict__ keep_cnt, float* __restrict__ lowres,
-                                                          unsigned* __restrict__ range, int mh, int mw, int nm, int max_det, int x_cs,
-                                                          int x_co, float wr, float hr) {
+                                                          unsigned* __restrict__ range, unsigned* __restrict__ posbits, int mh, int mw, int nm,
+                                                          int max_det, int x_cs, int x_co, float wr, float hr) {
   const int n = blockIdx.y;
   const int cnt = keep_cnt[n];
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= mh * mw) return;
+  const int W = (max_det + 31) >> 5;
+  unsigned* pb_out = posbits + ((long)n * mh * mw + pix) * W;
   if (cnt == 0) {
     range[(long)n * mh * mw + pix] = 0x0000FFFFu;
     return;
@@ -195,34 +197,40 @@ __global__ __launch_bounds__(256) void mask_lowres_kernel(const void* __restrict
   }
   const float fx = (float)px, fy = (float)py;
   unsigned first = 0xFFFFu, last = 0u;  // instance index range with a POSITIVE in-box logit at this proto pixel
-  for (int d = 0; d < cnt; ++d) {
-    const float* row = det + ((long)n * max_det + d) * MSL_PRED_STRIDE;
-    const float bx1 = row[0] * wr, by1 = row[1] * hr, bx2 = row[2] * wr, by2 = row[3] * hr;
-    if (fx >= bx1 && fx < bx2 && fy >= by1 && fy < by2) {  // outside the crop the value is 0 by definition: never stored,
-      float acc = 0.f;                                       // never read (readers apply the same box test per tap)
+  for (int w0 = 0; w0 < cnt; w0 += 32) {
+    unsigned word = 0u;  // bit b: instance w0+b has a positive in-box logit here
+    const int dend = min(w0 + 32, cnt);
+    for (int d = w0; d < dend; ++d) {
+      const float* row = det + ((long)n * max_det + d) * MSL_PRED_STRIDE;
+      const float bx1 = row[0] * wr, by1 = row[1] * hr, bx2 = row[2] * wr, by2 = row[3] * hr;
+      if (fx >= bx1 && fx < bx2 && fy >= by1 && fy < by2) {  // outside the crop the value is 0 by definition: never stored,
+        float acc = 0.f;                                       // never read (readers apply the same box test per tap)
 #pragma unroll
-      for (int c = 0; c < 32; ++c) acc = fmaf(row[6 + c], pr[c], acc);
-      lowres[(((long)n * max_det + d) * mh + py) * mw + px] = acc;
-      if (acc > 0.f) {
-        if (first == 0xFFFFu) first = (unsigned)d;
-        last = (unsigned)d;
+        for (int c = 0; c < 32; ++c) acc = fmaf(row[6 + c], pr[c], acc);
+        lowres[(((long)n * max_det + d) * mh + py) * mw + px] = acc;
+        if (acc > 0.f) {
+          if (first == 0xFFFFu) first = (unsigned)d;
+          last = (unsigned)d;
+          word |= 1u << (d - w0);
+        }
       }
     }
+    pb_out[w0 >> 5] = word;
   }
   range[(long)n * mh * mw + pix] = first | (last << 16);
 }
 
 int msl_launch_mask_lowres(const msl_op& op, hipStream_t s) {
   int N = op.i[0], mh = op.i[1], mw = op.i[2], nm = op.i[4], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9], x_cs = op.i[10], x_co = op.i[11];
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4] && op.p[5], "mask_lowres: null pointer");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4] && op.p[5] && op.p[6], "mask_lowres: null pointer");
   MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && nm == 32 && max_det > 0 && max_det < 0xFFFF && Hlb > 0 && Wlb > 0, "mask_lowres: bad dims (nm must be 32)");
   MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && x_co + nm <= x_cs, "mask_lowres: bad proto view");
   const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
   dim3 grid((mh * mw + 255) / 256, N);
   if (op.dtype == MSL_F32)
-    hipLaunchKernelGGL(mask_lowres_kernel<true>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const int*)op.p[2], (float*)op.p[4], (unsigned*)op.p[5], mh, mw, nm, max_det, x_cs, x_co, wr, hr);
+    hipLaunchKernelGGL(mask_lowres_kernel<true>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const int*)op.p[2], (float*)op.p[4], (unsigned*)op.p[5], (unsigned*)op.p[6], mh, mw, nm, max_det, x_cs, x_co, wr, hr);
   else
-    hipLaunchKernelGGL(mask_lowres_kernel<false>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const int*)op.p[2], (float*)op.p[4], (unsigned*)op.p[5], mh, mw, nm, max_det, x_cs, x_co, wr, hr);
+    hipLaunchKernelGGL(mask_lowres_kernel<false>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const int*)op.p[2], (float*)op.p[4], (unsigned*)op.p[5], (unsigned*)op.p[6], mh, mw, nm, max_det, x_cs, x_co, wr, hr);
   MSL_CHECK_LAUNCH("mask_lowres");
   return MSL_OK;
 }
@@ -313,7 +321,8 @@ int msl_launch_mask_upsample(const msl_op& op, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict__ lowres, const float* __restrict__ det,
                                                          const int* __restrict__ keep_cnt, const unsigned* __restrict__ range,
-                                                         const int* __restrict__ ytab, const int* __restrict__ xtab, uint8_t* __restrict__ out,
+                                                         const unsigned* __restrict__ posbits, const int* __restrict__ ytab,
+                                                         const int* __restrict__ xtab, uint8_t* __restrict__ out,
                                                          int mh, int mw, int max_det, int Hlb, int Wlb, int H0, int W0, float sy, float sx,
                                                          float wr, float hr) {
   // One workgroup = a 32x32 tile of the ORIGINAL grid.  Pixels are evaluated x-fastest (neighbouring lanes sample
@@ -328,6 +337,8 @@ __global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict
   const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const unsigned* rg = range + (long)n * mh * mw;
+  const int W = (max_det + 31) >> 5;
+  const unsigned* pbits = posbits + (long)n * mh * mw * W;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int yl = ty + 8 * r;
@@ -335,14 +346,20 @@ __global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict
     bool on = false;
     if (y0 < H0 && x0 < W0 && cnt > 0) {
       const Taps t = make_taps(mh, mw, sy, sx, ytab[y0], xtab[x0]);
-      // A positive bilinear value needs a positive in-box logit at one of the 4 taps (weights are >= 0): only instances
-      // inside [min first, max last] of the taps' recorded ranges can switch this pixel on.
-      const unsigned r00 = rg[t.y0 * mw + t.x0], r01 = rg[t.y0 * mw + t.x1], r10 = rg[t.y1 * mw + t.x0], r11 = rg[t.y1 * mw + t.x1];
+      // A positive bilinear value needs a positive in-box logit at one of the 4 taps (the weights are >= 0), so only the
+      // instances set in the OR of the taps' positive-instance bitmasks can switch this pixel on; [first,last] bounds the words.
+      const int i00 = t.y0 * mw + t.x0, i01 = t.y0 * mw + t.x1, i10 = t.y1 * mw + t.x0, i11 = t.y1 * mw + t.x1;
+      const unsigned r00 = rg[i00], r01 = rg[i01], r10 = rg[i10], r11 = rg[i11];
       const int dfirst = (int)min(min(r00 & 0xFFFFu, r01 & 0xFFFFu), min(r10 & 0xFFFFu, r11 & 0xFFFFu));
       const int dlast = min((int)max(max(r00 >> 16, r01 >> 16), max(r10 >> 16, r11 >> 16)), cnt - 1);
-      for (int d = dfirst; d <= dlast && !on; ++d) {
-        const float* m = lowres + ((long)n * max_det + d) * mh * mw;
-        on = sample_cropped(m, mw, t, sbox[d]) > 0.f;
+      for (int w = dfirst >> 5; w <= (dlast >> 5) && !on; ++w) {
+        unsigned cand = pbits[(long)i00 * W + w] | pbits[(long)i01 * W + w] | pbits[(long)i10 * W + w] | pbits[(long)i11 * W + w];
+        while (cand && !on) {
+          const int d = (w << 5) + __builtin_ctz(cand);
+          cand &= cand - 1;
+          const float* m = lowres + ((long)n * max_det + d) * mh * mw;
+          on = sample_cropped(m, mw, t, sbox[d]) > 0.f;
+        }
       }
     }
     tile[yl * 33 + tx] = on ? 255 : 0;
@@ -360,13 +377,14 @@ __global__ __launch_bounds__(256) void mask_merge_kernel(const float* __restrict
 
 int msl_launch_mask_merge(const msl_op& op, hipStream_t s) {
   int N = op.i[0], mh = op.i[1], mw = op.i[2], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9], H0 = op.i[10], W0 = op.i[11];
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6], "mask_merge: null pointer");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && op.p[7], "mask_merge: null pointer");
   const unsigned* range = (const unsigned*)op.p[6];
+  const unsigned* posbits = (const unsigned*)op.p[7];
   MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && max_det > 0 && max_det <= 2048 && Hlb > 0 && Wlb > 0 && H0 > 0 && W0 > 0, "mask_merge: bad dims");
   const float sy = (float)mh / (float)Hlb, sx = (float)mw / (float)Wlb;
   const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
   dim3 grid((W0 + 31) / 32, (H0 + 31) / 32, N);
-  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), (size_t)max_det * 16 + 32 * 33, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2], range,
+  hipLaunchKernelGGL(mask_merge_kernel, grid, dim3(256), (size_t)max_det * 16 + 32 * 33, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2], range, posbits,
                      (const int*)op.p[3], (const int*)op.p[5], (uint8_t*)op.p[4], mh, mw, max_det, Hlb, Wlb, H0, W0, sy, sx, wr, hr);
   MSL_CHECK_LAUNCH("mask_merge");
   return MSL_OK;

@@ -214,6 +214,7 @@ class Plan:
         mh, mw = self.proto.H, self.proto.W
         self.lowres = torch.empty(N, max_det, mh, mw, dtype=torch.float32, device=dev)
         self.range = torch.empty(N, mh, mw, dtype=torch.int32, device=dev)  # first|last<<16 positive-instance range per proto pixel
+        self.posbits = torch.empty(N, mh, mw, (max_det + 31) // 32, dtype=torch.int32, device=dev)  # positive-instance bitmask per proto pixel
         aoff = 0
         for li in sorted(b.levels):
             box, cls, coef = b.levels[li]
@@ -226,7 +227,7 @@ class Plan:
                                       p=(self.pred.data_ptr(), self.keep_idx.data_ptr(), self.keep_cnt.data_ptr(), self.det.data_ptr()),
                                       i={0: N, 6: self.A, 7: max_det}, f=(conf, iou)))
         b._emit("mask_lowres", hiplib.make_op(hiplib.OP_MASK_LOWRES, self.dtype,
-                                              p=(self.proto.t.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), 0, self.lowres.data_ptr(), self.range.data_ptr()),
+                                              p=(self.proto.t.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), 0, self.lowres.data_ptr(), self.range.data_ptr(), self.posbits.data_ptr()),
                                               i={0: N, 1: mh, 2: mw, 4: graph.NM, 7: max_det, 8: Hlb, 9: Wlb, 10: self.proto.cs, 11: self.proto.co}))
         self.program = hiplib.Program(b.ops)
         self.op_names = list(b.names)
@@ -273,7 +274,7 @@ class Plan:
         if out is None:
             out = torch.empty(self.N, W0, H0, dtype=torch.uint8, device=self.device)
         op = hiplib.make_op(hiplib.OP_MASK_MERGE, self.dtype,
-                            p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), ytab.data_ptr(), out.data_ptr(), xtab.data_ptr(), self.range.data_ptr()),
+                            p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), ytab.data_ptr(), out.data_ptr(), xtab.data_ptr(), self.range.data_ptr(), self.posbits.data_ptr()),
                             i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb, 10: H0, 11: W0})
         hiplib.launch(op, torch.cuda.current_stream(self.device).cuda_stream)
         return out
