@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-table", default="", help="write the per-op timing table to this file")
+    ap.add_argument("--target-kept", type=float, default=12.0,
+                    help="shift the class bias so NMS keeps about this many instances per synthetic slice (0: leave the "
+                         "calibrated-random weights as they are, which saturates max_det=300 on noise slices)")
     args = ap.parse_args()
 
     from mslesseg_amd import engine as E
@@ -102,10 +105,28 @@ def main():
 
     dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
     state = load_weights()
-    eng = E.InferEngine(state, "n", 1, dtype, str(dev))
     B, S = args.batch, args.size
     host = synthetic_slices(B, S, S, seed=rank)  # each rank its own shard of slices
     imgs = torch.from_numpy(host).to(dev)  # inputs resident in HBM before the timed region
+    bias_shift = 0.0
+    if args.target_kept > 0:
+        # Real MS slices carry a handful of lesions; the calibrated-random weights keep 300 boxes on every noise slice.
+        # Bisect a class-bias shift (weights only — conf/iou/max_det stay the reference's) on a 16-slice probe batch.
+        lo, hi = -12.0, 0.0
+        for _ in range(10):
+            mid = 0.5 * (lo + hi)
+            st = dict(state)
+            for i in range(3):
+                st[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + mid
+            probe = E.InferEngine(st, "n", 1, dtype, str(dev))
+            kept = float(probe.predict_batch(imgs[:16]).keep_cnt.float().mean().item())
+            del probe
+            lo, hi = (mid, hi) if kept < args.target_kept else (lo, mid)
+        bias_shift = 0.5 * (lo + hi)
+        for i in range(3):
+            state[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + bias_shift
+        torch.cuda.empty_cache()
+    eng = E.InferEngine(state, "n", 1, dtype, str(dev))
     out = None
 
     def step():
@@ -188,7 +209,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"predict (infer leg of the metric): YOLO11n-seg nc=1, {S}x{S}x3 uint8 slices, LetterBox+net+NMS+masks+merge, "
-                                   f"batch {B}/GPU; calibrated random weights (no trained weights exist offline); training leg not built yet",
+                                   f"batch {B}/GPU; calibrated random weights (no trained weights exist offline), class bias shifted {bias_shift:+.2f} "
+                                   f"for ~{args.target_kept:g} kept instances/slice; training leg not built yet",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"slice-sharded x{world}, no collective"},
             "roofline": roofline,
             "cpu_baseline": cpu,
