@@ -57,7 +57,11 @@ enum {
    * i: 0 N,1 H,2 W,3 Cin,4 Ho,5 Wo,6 Cout,7 k,8 stride,9 pad,10 x_cs,11 x_co,12 y_cs,13 y_co,14 res_cs,15 res_co,
    *    16 K(=k*k*Cin),17 Kpad,18 act(0 none,1 SiLU),19 out_f32(0/1),20 store_mode(0 plain, 1 pixel-shuffle 2x2:
    *    GEMM channel q*C+c with q=dy*2+dx goes to pixel (2y+dy,2x+dx) channel c, C=Cout/4 — ConvTranspose2d k2 s2),
-   *    21 Cout_pad (multiple of 16) */
+   *    21 Cout_pad (multiple of 16),
+   *    25 weight layout: 0 = GEMM rows above (generic kernel); 1 = LDS image for the tiled 3x3 kernel (k=3, pad=1, stride 1|2,
+   *       Cin % chunk == 0 with chunk = 32 bf16 / 16 fp32, Cout % 16 == 0):
+   *       w[cout_blk][chunk][tap=ky*3+kx][g 0..3][COB][16 bytes], element e of (.., g, col, .) = W[cout_blk*COB+col][chunk*CH*4+g*CH+e][ky][kx],
+   *       CH = 8 bf16 / 4 fp32, COB = 16*COT, and 24 = COT (4 if Cout%64==0, else 2 if Cout%32==0, else 1) */
   MSL_OP_CONV = 1,
   /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
    * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y

@@ -90,6 +90,52 @@ def test_conv_igemm(case, dtype):
     assert (out[..., untouched].float() == 7.0).all(), "conv wrote outside its channel slice"
 
 
+LDS3_CASES = [
+    # N, H, W, Cin, Cout, s, x_cs, x_co, y_cs, y_co, act, res, out_f32
+    (2, 16, 40, 64, 64, 1, 64, 0, 64, 0, 1, 1, 0),       # ragged: 40 cols = 1.25 tiles, 16 rows = 2 tiles
+    (1, 9, 33, 32, 32, 1, 96, 32, 48, 16, 1, 0, 0),      # COT=2, concat slices, partial tiles both ways
+    (1, 20, 20, 128, 64, 1, 128, 0, 64, 0, 1, 0, 0),     # 4 channel chunks (bf16) / 8 (fp32)
+    (2, 13, 70, 32, 16, 1, 32, 0, 16, 0, 0, 0, 1),       # COT=1, fp32 output, no activation
+    (1, 8, 8, 64, 128, 1, 64, 0, 128, 0, 1, 0, 0),       # 2 cout blocks of 64
+    (2, 16, 40, 64, 64, 2, 64, 0, 64, 0, 1, 0, 0),       # stride 2, even size
+    (1, 21, 35, 32, 32, 2, 32, 0, 32, 0, 1, 0, 0),       # stride 2, odd size
+    (1, 80, 80, 64, 64, 2, 64, 0, 192, 0, 1, 0, 0),      # model.17-like: into a concat slice
+    (1, 160, 160, 64, 64, 1, 64, 0, 64, 0, 1, 0, 0),     # proto.cv2 shape at batch 1
+]
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("case", LDS3_CASES)
+def test_conv3x3_lds(case, dtype):
+    N, H, W, Cin, Cout, s, x_cs, x_co, y_cs, y_co, act, res, out_f32 = case
+    g = torch.Generator().manual_seed(hash(case) % (2**31))
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    xbuf = _rand_act((N, H, W, x_cs), dtype, g)
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cin * 9) ** 0.5).to(_tdt(dtype)).float()
+    b = torch.rand(Cout, generator=g) - 0.5
+    rbuf = _rand_act((N, Ho, Wo, y_cs), dtype, g)
+    ybuf = torch.full((N, Ho, Wo, y_cs), 7.0, dtype=torch.float32 if out_f32 else _tdt(dtype))
+    ref = F.conv2d(xbuf[..., x_co : x_co + Cin].float().permute(0, 3, 1, 2), w, b, stride=s, padding=1)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if res:
+        ref = ref + rbuf[..., y_co : y_co + Cout].float()
+    assert E.lds3x3_eligible(Cin, Cout, 3, dtype)
+    wt, bt, m = E.pack_conv3x3_lds(w, b, dtype, DEV)
+    xd, rd, yd = xbuf.to(DEV), rbuf.to(DEV), ybuf.to(DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), rd.data_ptr() if res else 0, yd.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co,
+                           14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"], 24: m["cot"], 25: 1})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    out = yd.cpu()
+    _close(out[..., y_co : y_co + Cout], ref, dtype, f"conv3x3_lds {case}")
+    untouched = torch.ones(y_cs, dtype=torch.bool)
+    untouched[y_co : y_co + Cout] = False
+    assert (out[..., untouched].float() == 7.0).all(), "conv3x3_lds wrote outside its channel slice"
+
+
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 def test_conv_transpose_2x2_pixel_shuffle(dtype):
     g = torch.Generator().manual_seed(5)

@@ -1,0 +1,220 @@
+// LDS-tiled 3x3 convolution (stride 1 or 2) on the CDNA4 matrix cores — the fast path for the layers that carry
+// ~3/4 of the network's FLOPs (dense 3x3: 73 % of MACs).
+//
+// Why: the generic conv_igemm kernel fetches both MFMA fragments from L1/L2 on every K-step (fragment-shaped 16-byte
+// loads) and is bound by the texture-address path at ~11 % of the MFMA peak.  Here a workgroup owns a (4·RW rows x 32
+// cols) output tile of one image and, per chunk of 4x16 bytes of input channels (32 bf16 / 16 fp32):
+//   * stages the input HALO tile once through LDS-DMA (global_load_lds, 16 B/lane, per-lane source = row gather with a
+//     zero page for padding) — each input element is then reused by the 9 taps and by all channel tiles from LDS;
+//   * stages that chunk's weight slab (9 taps x COB output channels) with contiguous LDS-DMA copies of a host-packed
+//     LDS image;
+//   * runs 9 taps x (PT pixel tiles x COT channel tiles) MFMAs per wave from ds_read_b128 fragment reads.
+// LDS image: [k-group g (4)][slot][16 B] planes, every plane a multiple of 256 B.  The 16 lanes of each ds_read_b128
+// lane group then read 16 consecutive 16-byte slots of one plane (B: 16 consecutive pixels of a row; A: 16 consecutive
+// output channels) or two such half-runs in different planes that land on disjoint bank quarters: conflict-free for any
+// tile alignment.  Stride 2 splits the halo columns by parity so that 16 consecutive OUTPUT pixels are again contiguous.
+//
+// GEMM orientation, fragment k-permutation (fp32) and epilogue are those of conv_igemm.hip.
+#include "msl_common.h"
+
+__device__ __attribute__((aligned(16))) unsigned msl_zero_page[4];  // source of padding for LDS-DMA gathers
+
+struct Conv3Args {
+  const char* x;
+  const char* w;  // LDS-image weights: [cout_blk][chunk][tap 9][g 4][COB][16 B]
+  const float* bias;
+  const char* res;
+  char* y;
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int x_cs, x_co, y_cs, y_co, res_cs, res_co;
+  int act, out_f32, tiles_x, tiles_y;
+};
+
+template <int S, int RW>
+struct Tile3 {
+  static constexpr int TW = 32, TH = 4 * RW;
+  static constexpr int ROWP = 34;                                  // slots per halo row (s1) / per parity row (s2)
+  static constexpr int ROWS = S == 1 ? TH + 2 : 2 * TH + 1;        // halo rows
+  static constexpr int SLOTS = S == 1 ? ROWS * ROWP : ROWS * 2 * ROWP;
+  static constexpr int PS = (SLOTS + 63) / 64 * 64;                // slots per plane (multiple of 64: whole LDS-DMA pieces)
+};
+
+template <bool F32, int S, int RW, int COT>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
+  using T = Tile3<S, RW>;
+  constexpr int ES = F32 ? 4 : 2;
+  constexpr int CHUNK = 64 / ES;          // channels per chunk (4 groups x 16 B)
+  constexpr int COB = COT * 16;
+  constexpr int PT = 2 * RW;              // pixel tiles per wave: RW rows x 2 column halves
+  constexpr int IN_BYTES = 4 * T::PS * 16;
+  constexpr int W_BYTES = 9 * 4 * COB * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;
+  unsigned char* s_w = smem + IN_BYTES;
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lp = lane & 15, g = lane >> 4;
+  int bid = blockIdx.x;
+  const int txi = bid % a.tiles_x; bid /= a.tiles_x;
+  const int tyi = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+  const int oy0 = tyi * T::TH, ox0 = txi * T::TW;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;  // halo origin (pad 1)
+  const int cob = blockIdx.y;
+
+  f32x4 acc[COT][PT];
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const char* ximg = a.x + ((long)n * a.H * a.W * a.x_cs + a.x_co) * ES;
+  const int nchunks = a.Cin / CHUNK;
+  const char* wblk = a.w + (long)cob * nchunks * W_BYTES;
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // previous chunk's fragment reads are done before the tile is overwritten
+    // ---- input halo: 4 planes x PS slots, 64 slots (1 KiB) per LDS-DMA piece, pieces dealt round-robin to the 4 waves
+    constexpr int IN_PIECES = 4 * T::PS / 64;
+    for (int pc = wave; pc < IN_PIECES; pc += 4) {
+      const int gq = pc / (T::PS / 64);
+      const int sl = (pc - gq * (T::PS / 64)) * 64 + lane;
+      int r, c;
+      if constexpr (S == 1) {
+        r = sl / T::ROWP;
+        c = sl - r * T::ROWP;
+      } else {
+        const int rr = sl / T::ROWP;  // = r*2 + parity
+        const int pos = sl - rr * T::ROWP;
+        r = rr >> 1;
+        c = pos * 2 + (rr & 1);
+      }
+      const int iy = iy0 + r, ix = ix0 + c;
+      const bool ok = sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const char* src = ok ? ximg + (((long)iy * a.W + ix) * a.x_cs + cc * CHUNK) * ES + gq * 16 : (const char*)msl_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s_in + pc * 1024), 16, 0, 0);
+    }
+    // ---- weights: contiguous copy of this (cout block, chunk) slab
+    constexpr int W_PIECES = W_BYTES / 1024;
+    const char* wsrc = wblk + (long)cc * W_BYTES;
+    for (int pc = wave; pc < W_PIECES; pc += 4) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + pc * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- 9 taps
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        uint4 av[COT], bv[PT];
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+          av[c] = *(const uint4*)(s_w + ((((ty * 3 + tx) * 4 + g) * COB) + c * 16 + lp) * 16);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          const int row = wave * RW + (p >> 1);     // output row inside the tile
+          const int col = (p & 1) * 16 + lp;        // output col inside the tile
+          int slot;
+          if constexpr (S == 1) slot = (row + ty) * T::ROWP + col + tx;
+          else slot = ((2 * row + ty) * 2 + (tx & 1)) * T::ROWP + col + (tx >> 1);
+          bv[p] = *(const uint4*)(s_in + ((long)g * T::PS + slot) * 16);
+        }
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) {
+            if constexpr (F32) {
+              f32x4 af = __builtin_bit_cast(f32x4, av[c]), bf = __builtin_bit_cast(f32x4, bv[p]);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][p], 0, 0, 0);
+            } else {
+              acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[c]), __builtin_bit_cast(bf16x8, bv[p]),
+                                                                  acc[c][p], 0, 0, 0);
+            }
+          }
+      }
+    }
+  }
+
+  // ---- epilogue: bias + SiLU (+ residual); 4 consecutive channels per lane and tile
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
+    if (oy >= a.Ho || ox >= a.Wo) continue;
+    const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      const int co0 = cob * COB + c * 16 + g * 4;
+      if (co0 >= a.Cout) continue;
+      float v[4];
+      const float4 b4 = *(const float4*)(a.bias + co0);
+      v[0] = acc[c][p][0] + b4.x; v[1] = acc[c][p][1] + b4.y; v[2] = acc[c][p][2] + b4.z; v[3] = acc[c][p][3] + b4.w;
+      if (a.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (a.res) {
+        float rv[4];
+        ld4<F32>(a.res, pix * a.res_cs + a.res_co + co0, rv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      }
+      const long oi = pix * a.y_cs + a.y_co + co0;
+      if (a.out_f32) st4<true>(a.y, oi, v); else st4<F32>(a.y, oi, v);
+    }
+  }
+}
+
+template <bool F32, int S, int RW, int COT>
+static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
+  using T = Tile3<S, RW>;
+  constexpr int LDS = 4 * T::PS * 16 + 9 * 4 * COT * 16 * 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x), (unsigned)cout_blocks);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT>), grid, dim3(256), LDS, s, a);
+  MSL_CHECK_LAUNCH("conv3x3_lds");
+  return MSL_OK;
+}
+
+// Eligibility + dispatch; called from msl_launch_conv when op.i[25] == 1 (weights packed as the LDS image).
+int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
+  Conv3Args a;
+  a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2]; a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];
+  a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6];
+  const int k = op.i[7], stride = op.i[8], pad = op.i[9];
+  a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
+  a.act = op.i[18]; a.out_f32 = op.i[19];
+  const bool f32 = op.dtype == MSL_F32;
+  const int chunk = f32 ? 16 : 32, v = f32 ? 4 : 8;
+  MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv3x3_lds: null pointer");
+  MSL_REQUIRE(k == 3 && pad == 1 && (stride == 1 || stride == 2) && op.i[20] == 0, "conv3x3_lds: needs k=3 pad=1 stride 1|2, plain store");
+  MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho == (a.H + 2 - 3) / stride + 1 && a.Wo == (a.W + 2 - 3) / stride + 1, "conv3x3_lds: bad dims");
+  MSL_REQUIRE(a.Cin > 0 && a.Cin % chunk == 0 && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs, "conv3x3_lds: Cin must be a multiple of %d", chunk);
+  MSL_REQUIRE(a.Cout % 16 == 0 && a.y_cs % 4 == 0 && a.y_co % 4 == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: Cout must be a multiple of 16");
+  if (a.res) MSL_REQUIRE(a.res_cs % 4 == 0 && a.res_co % 4 == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
+  const int cot = a.Cout % 64 == 0 ? 4 : (a.Cout % 32 == 0 ? 2 : 1);
+  const int cout_blocks = a.Cout / (16 * cot);
+  MSL_REQUIRE(op.i[24] == cot, "conv3x3_lds: weights were packed for COT=%d but the launch needs %d", op.i[24], cot);
+  const int rw = stride == 1 ? 2 : 1;
+  const int TH = 4 * rw;
+  a.tiles_x = (a.Wo + 31) / 32;
+  a.tiles_y = (a.Ho + TH - 1) / TH;
+#define L3(F, S_, RW_)                                                   \
+  do {                                                                   \
+    if (cot == 4) return launch3<F, S_, RW_, 4>(a, cout_blocks, s);      \
+    if (cot == 2) return launch3<F, S_, RW_, 2>(a, cout_blocks, s);      \
+    return launch3<F, S_, RW_, 1>(a, cout_blocks, s);                    \
+  } while (0)
+  if (f32) { if (stride == 1) L3(true, 1, 2); else L3(true, 2, 1); }
+  else     { if (stride == 1) L3(false, 1, 2); else L3(false, 2, 1); }
+#undef L3
+  return MSL_OK;
+}

@@ -174,6 +174,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int msl_launch_conv(const msl_op& op, hipStream_t s) {
+  if (op.i[25] == 1) return msl_launch_conv3x3_lds(op, s);  // weights packed as the LDS image: tiled 3x3 kernel
   ConvArgs a;
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2];
   a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];

@@ -158,7 +158,7 @@ int msl_launch_nms(const msl_op& op, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = (size_t)NMS_CAP * 9;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(1024), lds, s, (const float*)op.p[0], (int*)op.p[1], (int*)op.p[2], (float*)op.p[3], A, max_det,

@@ -82,6 +82,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 
 // op launchers (one per translation unit)
 int msl_launch_conv(const msl_op& op, hipStream_t s);
+int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s);
 int msl_launch_stem(const msl_op& op, hipStream_t s);
 int msl_launch_dwconv(const msl_op& op, hipStream_t s);
 int msl_launch_sppf_pool(const msl_op& op, hipStream_t s);

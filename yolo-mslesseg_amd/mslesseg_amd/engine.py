@@ -57,10 +57,27 @@ def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
     return wp.to(_dt(dtype)).contiguous().to(device), bp.to(device), dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
 
 
+def lds3x3_eligible(cin: int, cout: int, k: int, dtype: int) -> bool:
+    chunk = 16 if dtype == MSL_F32 else 32
+    return k == 3 and cin % chunk == 0 and cout % 16 == 0
+
+
+def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
+    """[Cout,Cin,3,3] → the LDS image of conv3x3_lds.hip: [cout_blk][chunk][tap][g][COB][CH] (include/mslesseg_hip.h)."""
+    cout, cin, _, _ = w.shape
+    ch = 4 if dtype == MSL_F32 else 8
+    chunk = 4 * ch
+    cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
+    cob = 16 * cot
+    wv = w.reshape(cout // cob, cob, cin // chunk, 4, ch, 3, 3)          # [blk, col, cc, g, e, ky, kx]
+    img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
+    return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
+
+
 class PackedWeights:
     """Folded Conv+BN weights laid out for the kernels, per dtype; shape independent."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], scale: str, nc: int, dtype: int, device):
+    def __init__(self, state: Dict[str, torch.Tensor], scale: str, nc: int, dtype: int, device, use_lds3x3: bool = True):
         self.scale, self.nc, self.dtype, self.device = scale, nc, dtype, device
         self.specs = params.param_specs(scale, nc)
         self.t: Dict[str, Tuple[torch.Tensor, torch.Tensor, dict]] = {}
@@ -80,7 +97,10 @@ class PackedWeights:
                 self.t[name] = (wg.to(device), b.contiguous().to(device), {})
             else:
                 cout, cin, k = s["cout"], s["cin"], s["k"]
-                self._pack_gemm(name, pack_conv_weight(w), b, kstep)
+                if use_lds3x3 and lds3x3_eligible(cin, cout, k, dtype):
+                    self.t[name] = pack_conv3x3_lds(w, b, dtype, device)
+                else:
+                    self._pack_gemm(name, pack_conv_weight(w), b, kstep)
 
     def _pack_gemm(self, name, wg, b, kstep):
         self.t[name] = pack_gemm(wg, b, self.dtype, self.device)
@@ -130,7 +150,8 @@ class ProgramBuilder(graph.Visitor):
         assert (y.H, y.W, y.C) == (Ho, Wo, cout), (name, (y.H, y.W, y.C), (Ho, Wo, cout))
         wt, bt, m = self.w.t[name]
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
-             16: m["K"], 17: m["Kpad"], 18: 1 if act else 0, 19: 1 if f32_out else 0, 20: 0, 21: m["Cout_pad"]}
+             16: m["K"], 17: m["Kpad"], 18: 1 if act else 0, 19: 1 if f32_out else 0, 20: 0, 21: m["Cout_pad"],
+             24: m.get("cot", 0), 25: m.get("lds", 0)}
         rp = 0
         if res is not None:
             assert (res.H, res.W, res.C) == (Ho, Wo, cout), name
@@ -355,14 +376,14 @@ class LetterBoxProgram:
 class InferEngine:
     """Weights + plan cache.  `dtype` MSL_BF16 (throughput) or MSL_F32 (exact-fp32 parity mode)."""
 
-    def __init__(self, state, scale: str, nc: int, dtype: int = MSL_BF16, device="cuda:0"):
+    def __init__(self, state, scale: str, nc: int, dtype: int = MSL_BF16, device="cuda:0", use_lds3x3: bool = True):
         if not torch.cuda.is_available():
             raise hiplib.MslError("no GPU: the mslesseg_amd inference path runs only on the HIP kernels (no CPU fallback)")
         hiplib.lib()
         self.device = torch.device(device)
         self.scale, self.nc, self.dtype = scale, nc, dtype
         params.validate_state(state, scale, nc)
-        self.weights = PackedWeights(state, scale, nc, dtype, self.device)
+        self.weights = PackedWeights(state, scale, nc, dtype, self.device, use_lds3x3)
         self._plans: Dict[Tuple[int, int, int], Plan] = {}
         self._lb: Dict[Tuple[int, int, int, int], LetterBoxProgram] = {}
 
