@@ -203,7 +203,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const int cot = a.Cout % 64 == 0 ? 4 : (a.Cout % 32 == 0 ? 2 : 1);
   const int cout_blocks = a.Cout / (16 * cot);
   MSL_REQUIRE(op.i[24] == cot, "conv3x3_lds: weights were packed for COT=%d but the launch needs %d", op.i[24], cot);
-  const int rw = stride == 1 ? 2 : 1;
+  // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
+  const int rw = stride == 1 ? (a.Ho >= 32 && cot == 4 ? 4 : 2) : 1;
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;
@@ -213,8 +214,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (cot == 2) return launch3<F, S_, RW_, 2>(a, cout_blocks, s);      \
     return launch3<F, S_, RW_, 1>(a, cout_blocks, s);                    \
   } while (0)
-  if (f32) { if (stride == 1) L3(true, 1, 2); else L3(true, 2, 1); }
-  else     { if (stride == 1) L3(false, 1, 2); else L3(false, 2, 1); }
+  if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else L3(true, 1, 2); }
+  else     { if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
 #undef L3
   return MSL_OK;
 }
