@@ -72,71 +72,86 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   const int nchunks = a.Cin / CHUNK;
   const char* wblk = a.w + (long)cob * nchunks * W_BYTES;
 
+  // ---- per-lane staging sources, computed once: piece j of this wave covers plane gq, slots sl..sl+63
+  constexpr int IN_PIECES = 4 * T::PS / 64;
+  constexpr int IN_PER_WAVE = (IN_PIECES + 3) / 4;
+  constexpr int W_PIECES = W_BYTES / 1024;
+  int in_off[IN_PER_WAVE];  // byte offset inside the image view of this lane's 16 bytes (chunk 0), or -1 → zero page
+#pragma unroll
+  for (int j = 0; j < IN_PER_WAVE; ++j) {
+    const int pc = wave + 4 * j;
+    const int gq = pc / (T::PS / 64);
+    const int sl = (pc - gq * (T::PS / 64)) * 64 + lane;
+    int r, c;
+    if constexpr (S == 1) {
+      r = sl / T::ROWP;
+      c = sl - r * T::ROWP;
+    } else {
+      const int rr = sl / T::ROWP;  // = r*2 + parity
+      const int pos = sl - rr * T::ROWP;
+      r = rr >> 1;
+      c = pos * 2 + (rr & 1);
+    }
+    const int iy = iy0 + r, ix = ix0 + c;
+    const bool ok = pc < IN_PIECES && sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    in_off[j] = ok ? ((iy * a.W + ix) * a.x_cs) * ES + gq * 16 : -1;
+  }
+  const char* wlane = wblk + wave * 1024 + lane * 16;
+
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();  // previous chunk's fragment reads are done before the tile is overwritten
     // ---- input halo: 4 planes x PS slots, 64 slots (1 KiB) per LDS-DMA piece, pieces dealt round-robin to the 4 waves
-    constexpr int IN_PIECES = 4 * T::PS / 64;
-    for (int pc = wave; pc < IN_PIECES; pc += 4) {
-      const int gq = pc / (T::PS / 64);
-      const int sl = (pc - gq * (T::PS / 64)) * 64 + lane;
-      int r, c;
-      if constexpr (S == 1) {
-        r = sl / T::ROWP;
-        c = sl - r * T::ROWP;
-      } else {
-        const int rr = sl / T::ROWP;  // = r*2 + parity
-        const int pos = sl - rr * T::ROWP;
-        r = rr >> 1;
-        c = pos * 2 + (rr & 1);
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      if (pc < IN_PIECES) {
+        const char* src = in_off[j] >= 0 ? ximg + in_off[j] + cc * (CHUNK * ES) : (const char*)msl_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(s_in + pc * 1024), 16, 0, 0);
       }
-      const int iy = iy0 + r, ix = ix0 + c;
-      const bool ok = sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const char* src = ok ? ximg + (((long)iy * a.W + ix) * a.x_cs + cc * CHUNK) * ES + gq * 16 : (const char*)msl_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s_in + pc * 1024), 16, 0, 0);
     }
     // ---- weights: contiguous copy of this (cout block, chunk) slab
-    constexpr int W_PIECES = W_BYTES / 1024;
-    const char* wsrc = wblk + (long)cc * W_BYTES;
-    for (int pc = wave; pc < W_PIECES; pc += 4) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + pc * 1024 + lane * 16),
+    const char* wsrc = wlane + (long)cc * W_BYTES;
+    for (int pc = wave; pc < W_PIECES; pc += 4, wsrc += 4096) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
                                        (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- 9 taps
+    // ---- 9 taps; the fragments of tap t+1 are fetched while tap t's MFMAs issue
+    uint4 av[2][COT], bv[2][PT];
+    auto fetch = [&](int t, uint4 (&A)[COT], uint4 (&B)[PT]) {
+      const int ty = t / 3, tx = t - ty * 3;
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
+      for (int c = 0; c < COT; ++c) A[c] = *(const uint4*)(s_w + (((t * 4 + g) * COB) + c * 16 + lp) * 16);
 #pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        uint4 av[COT], bv[PT];
+      for (int p = 0; p < PT; ++p) {
+        const int row = wave * RW + (p >> 1);     // output row inside the tile
+        const int col = (p & 1) * 16 + lp;        // output col inside the tile
+        int slot;
+        if constexpr (S == 1) slot = (row + ty) * T::ROWP + col + tx;
+        else slot = ((2 * row + ty) * 2 + (tx & 1)) * T::ROWP + col + (tx >> 1);
+        B[p] = *(const uint4*)(s_in + (g * T::PS + slot) * 16);
+      }
+    };
+    fetch(0, av[0], bv[0]);
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
-          av[c] = *(const uint4*)(s_w + ((((ty * 3 + tx) * 4 + g) * COB) + c * 16 + lp) * 16);
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) fetch(t + 1, av[(t + 1) & 1], bv[(t + 1) & 1]);
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-          const int row = wave * RW + (p >> 1);     // output row inside the tile
-          const int col = (p & 1) * 16 + lp;        // output col inside the tile
-          int slot;
-          if constexpr (S == 1) slot = (row + ty) * T::ROWP + col + tx;
-          else slot = ((2 * row + ty) * 2 + (tx & 1)) * T::ROWP + col + (tx >> 1);
-          bv[p] = *(const uint4*)(s_in + ((long)g * T::PS + slot) * 16);
-        }
+          if constexpr (F32) {
+            f32x4 af = __builtin_bit_cast(f32x4, av[t & 1][c]), bf = __builtin_bit_cast(f32x4, bv[t & 1][p]);
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
-#pragma unroll
-          for (int p = 0; p < PT; ++p) {
-            if constexpr (F32) {
-              f32x4 af = __builtin_bit_cast(f32x4, av[c]), bf = __builtin_bit_cast(f32x4, bv[p]);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][p], 0, 0, 0);
-            } else {
-              acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[c]), __builtin_bit_cast(bf16x8, bv[p]),
-                                                                  acc[c][p], 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][p], 0, 0, 0);
+          } else {
+            acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[t & 1][c]), __builtin_bit_cast(bf16x8, bv[t & 1][p]),
+                                                                acc[c][p], 0, 0, 0);
           }
-      }
+        }
     }
   }
 
@@ -204,7 +219,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const int cout_blocks = a.Cout / (16 * cot);
   MSL_REQUIRE(op.i[24] == cot, "conv3x3_lds: weights were packed for COT=%d but the launch needs %d", op.i[24], cot);
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
-  const int rw = stride == 1 ? (a.Ho >= 32 && cot == 4 ? 4 : 2) : 1;
+  const int rw = stride == 1 ? (op.i[23] == 4 && cot == 4 ? 4 : 2) : 1;  // i[23]=4 opts into the 16x32 tile (measured slower: kept for experiments)
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;

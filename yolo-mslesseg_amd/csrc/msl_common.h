@@ -78,7 +78,8 @@ __device__ __forceinline__ void st4(void* p, long i, const float (&v)[4]) {
   }
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU = x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each): 5 VALU instead of the ~15 of an IEEE division.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // op launchers (one per translation unit)
 int msl_launch_conv(const msl_op& op, hipStream_t s);
