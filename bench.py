@@ -112,8 +112,8 @@ def main():
     if args.target_kept > 0:
         # Real MS slices carry a handful of lesions; the calibrated-random weights keep 300 boxes on every noise slice.
         # Bisect a class-bias shift (weights only — conf/iou/max_det stay the reference's) on a 16-slice probe batch.
-        lo, hi = -12.0, 0.0
-        for _ in range(10):
+        lo, hi = -60.0, 0.0
+        for _ in range(14):
             mid = 0.5 * (lo + hi)
             st = dict(state)
             for i in range(3):
