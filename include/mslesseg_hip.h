@@ -57,7 +57,8 @@ enum {
    * i: 0 N,1 H,2 W,3 Cin,4 Ho,5 Wo,6 Cout,7 k,8 stride,9 pad,10 x_cs,11 x_co,12 y_cs,13 y_co,14 res_cs,15 res_co,
    *    16 K(=k*k*Cin),17 Kpad,18 act(0 none,1 SiLU),19 out_f32(0/1),20 store_mode(0 plain, 1 pixel-shuffle 2x2:
    *    GEMM channel q*C+c with q=dy*2+dx goes to pixel (2y+dy,2x+dx) channel c, C=Cout/4 — ConvTranspose2d k2 s2),
-   *    21 Cout_pad (multiple of 16),
+   *    21 Cout_pad (multiple of 16), 22 dgrad (0 forward gather; 1 transposed-conv gather: source = (out+pad-tap)/stride when
+   *       divisible, (H,W) = gradient read, (Ho,Wo) = tensor produced, weights packed [Cin][(ky,kx,co)]), k may also be 2,
    *    25 weight layout: 0 = GEMM rows above (generic kernel); 1 = LDS image for the tiled 3x3 kernel (k=3, pad=1, stride 1|2,
    *       Cin % chunk == 0 with chunk = 32 bf16 / 16 fp32, Cout % 16 == 0):
    *       w[cout_blk][chunk][tap=ky*3+kx][g 0..3][COB][16 bytes], element e of (.., g, col, .) = W[cout_blk*COB+col][chunk*CH*4+g*CH+e][ky][kx],
@@ -71,7 +72,9 @@ enum {
    * p: 0 x, 1 w f32 [9][C], 2 bias f32[C], 3 res|NULL, 4 y
    * i: 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 y_cs,13 y_co,14 res_cs,15 res_co,18 act,
    *    22 gsz,23 gstride,24 goff : input channel of output channel c is (c/gsz)*gstride + goff + c%gsz
-   *    (gsz=0 ⇒ identity) — lets Attention.pe read the v part of the qkv buffer in place. */
+   *    (gsz=0 ⇒ identity) — lets Attention.pe read the v part of the qkv buffer in place;
+   *    20 flip (use tap 8-t: the transposed depthwise conv of the backward pass), 21 omap (the channel map applies to the
+   *    output/residual side instead of the input side) */
   MSL_OP_DWCONV = 3,
   /* SPPF pooling: from the C-channel view at co, write the 5x5, 9x9, 13x13 stride-1 max pools
    * (= three chained 5x5 pools with -inf padding) at co+C, co+2C, co+3C of the same buffer.
@@ -120,7 +123,29 @@ enum {
   MSL_OP_VOL_CONSENSUS = 14,
   /* DICE partial sums: acc u64[3] += (sum gt*pred, sum gt, sum pred) over n voxels (binary volumes).
    * p: 0 gt u8, 1 pred u8, 4 acc u64[3] ; i: 0 n_lo,1 n_hi */
-  MSL_OP_VOL_DICE = 15
+  MSL_OP_VOL_DICE = 15,
+
+  /* ---- training leg (csrc/train_kernels.hip; slot lists are beside each launcher there) ------------------------------
+   * Train-mode Conv = CONV(raw, no bias/act) → BN_STATS → BN_FINALIZE → BN_ACT; its backward = BN_ACT_BWD_REDUCE →
+   * BN_ACT_BWD_APPLY (dz, dgamma, dbeta) → CONV_WGRAD + CONV with i[22]=1 (dgrad: transposed-conv gather, weights packed
+   * [Cin][(ky,kx,co)]).  ConvTranspose2d(2,2) backward = CONV k=2 s=2 p=0 (dgrad) and CONV_WGRAD with the operands swapped. */
+  MSL_OP_BN_STATS = 16,           /* acc f64[2C] += (sum z, sum z^2) per channel over N*H*W */
+  MSL_OP_BN_FINALIZE = 17,        /* stats f32[2C] = (mean, 1/sqrt(var+eps)); running stats update; acc = 0 */
+  MSL_OP_BN_ACT = 18,             /* y = act(gamma*zhat+beta) (+res) */
+  MSL_OP_BN_ACT_BWD_REDUCE = 19,  /* acc f64[2C] += (sum g, sum g*zhat), g = dy*act'(u) */
+  MSL_OP_BN_ACT_BWD_APPLY = 20,   /* dz = gamma*invstd*(g - s1/M - zhat*s2/M); dgamma = s2, dbeta = s1 */
+  MSL_OP_COLSUM = 21,             /* acc f64[C] += column sums of a view (bias gradients) */
+  MSL_OP_F64_DRAIN = 22,          /* dst f32[n] = src f64[n*stride]; src = 0 */
+  MSL_OP_ADD_VIEW = 23,           /* dst view (+)= src view (residual / concat gradient fan-in) */
+  MSL_OP_UPSAMPLE2X_BWD = 24,     /* dx += 2x2 sums of dy */
+  MSL_OP_SPPF_POOL_BWD = 25,      /* arg-max routing of the three pooled gradients into a fp32 scratch */
+  MSL_OP_CONV_WGRAD = 26,         /* dW f32[Cout][(ky,kx,ci)] += sum_p dz[p][co]*x[pix(p,ky,kx)][ci]  (fp32 MFMA, pixel contraction) */
+  MSL_OP_DW_WGRAD = 27,           /* depthwise 3x3 weight gradient */
+  MSL_OP_STEM_WGRAD = 28,         /* stem weight gradient from the uint8 image */
+  MSL_OP_CAST_PAD = 29,           /* fp32 [R][K] → op dtype [Rpad][Kpad] (optionally transposed) */
+  MSL_OP_GATHER_CAST = 30,        /* dst[i] = idx[i]>=0 ? src[idx[i]] : 0, cast to op dtype: packs weight images from the flat master buffer */
+  MSL_OP_ADAMW = 31,              /* fused AdamW step over a flat fp32 range */
+  MSL_OP_EMA = 32                 /* e = d*e + (1-d)*p over a flat fp32 range */
 };
 
 #define MSL_PRED_STRIDE 40 /* floats per anchor row: x,y,w,h | conf | cls | 32 coeffs | 2 pad */

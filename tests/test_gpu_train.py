@@ -1,0 +1,141 @@
+"""Training leg parity (-m gpu): the HIP forward/backward programs against the oracle network's autograd.
+
+The oracle is the PyTorch-CPU fp32 restatement in train mode (BatchNorm batch statistics).  A linear probe loss
+L = sum_i <out_i, R_i> with fixed random R makes dL/d(out) = R exactly, so the comparison isolates the network's own
+forward + backward arithmetic (conv dgrad/wgrad, BN+SiLU backward, pooling/upsample/attention/ConvT backward, fan-in)
+from the detection loss, which has its own parity test.
+fp32 engine: every parameter gradient within 2e-3 of the tensor's max |grad|; forward outputs within 1e-4 rel.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mslesseg_amd import trainprog as TP  # noqa: E402
+from mslesseg_amd.hiplib import MSL_BF16, MSL_F32  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def synth_state(golden_dir):
+    st = torch.load(golden_dir / "synth_n_nc1.pt", map_location="cpu", weights_only=True)
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
+
+
+def _oracle_run(state, img_rgb, R):
+    from oracle import yolo11seg as Y
+
+    m = Y.build("n", 1)
+    m.load_state_dict(state)
+    m.train()
+    x = torch.from_numpy(img_rgb).permute(0, 3, 1, 2).float() / 255
+    feats, mc, p = m(x)
+    loss = sum((f * r).sum() for f, r in zip(feats, R["feats"])) + (mc * R["mc"]).sum() + (p * R["p"]).sum()
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+    bufs = {k: v.detach().clone() for k, v in m.named_buffers()}
+    return feats, mc, p, grads, bufs
+
+
+def _probe(N, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(H // s, W // s) for s in (8, 16, 32)]
+    R = {"feats": [torch.randn(N, 65, h, w, generator=g) for h, w in shapes],
+         "mc": torch.randn(N, 32, sum(h * w for h, w in shapes), generator=g),
+         "p": torch.randn(N, 32, H // 4, W // 4, generator=g) * 0.1}
+    return R, shapes
+
+
+def _run_plan(state, img_rgb, R, shapes, dtype):
+    N, H, W, _ = img_rgb.shape
+    store = TP.ParamStore("n", 1, DEV)
+    store.load_state(state)
+    plan = TP.TrainPlan(store, N, H, W, dtype)
+    plan.in_view.t.copy_(torch.from_numpy(img_rgb).reshape(-1))
+    plan.pack()
+    plan.forward()
+    torch.cuda.synchronize()
+    outs = plan.head_outputs()
+    fw = {"levels": [tuple(t.float().cpu().clone() for t in lv) for lv in outs["levels"]], "proto": outs["proto"].float().cpu().clone()}
+    # seed the backward: dL/d(out) = R
+    a0 = 0
+    for li, (h, w) in enumerate(shapes):
+        box, cls, coef = plan.levels[li]
+        for v in (box, cls, coef):
+            plan.G(v).t.zero_()
+        gb, gc, gm = (plan.G(v).torch() for v in (box, cls, coef))
+        gb.copy_(R["feats"][li][:, :64].permute(0, 2, 3, 1))
+        gc.copy_(R["feats"][li][:, 64:].permute(0, 2, 3, 1))
+        gm.copy_(R["mc"][:, :, a0 : a0 + h * w].reshape(N, 32, h, w).permute(0, 2, 3, 1))
+        a0 += h * w
+    plan.G(plan.proto_view).torch().copy_(R["p"].permute(0, 2, 3, 1))
+    store.g.zero_()
+    plan.backward()
+    torch.cuda.synchronize()
+    return store, plan, fw
+
+
+def test_param_store_roundtrip_cpu_layouts(synth_state):
+    store = TP.ParamStore("n", 1, DEV)
+    store.load_state(synth_state)
+    back = store.state_dict()
+    for k, v in synth_state.items():
+        if v.is_floating_point():
+            assert torch.equal(back[k], v), k
+
+
+@pytest.mark.parametrize("hw", [(64, 96), (96, 64)])
+def test_train_forward_backward_fp32_matches_oracle_autograd(synth_state, hw):
+    rng = np.random.default_rng(1)
+    N, (H, W) = 2, hw
+    img = rng.integers(0, 256, size=(N, H, W, 3), dtype=np.uint8)
+    R, shapes = _probe(N, H, W)
+    feats, mc, p, grads, bufs = _oracle_run(synth_state, img, R)
+    store, plan, fw = _run_plan(synth_state, img, R, shapes, MSL_F32)
+    # ---- forward
+    a0 = 0
+    for li, (h, w) in enumerate(shapes):
+        box, cls, coef = fw["levels"][li]
+        ref_box = feats[li][:, :64].permute(0, 2, 3, 1).detach()
+        ref_cls = feats[li][:, 64:].permute(0, 2, 3, 1).detach()
+        ref_coef = mc[:, :, a0 : a0 + h * w].reshape(N, 32, h, w).permute(0, 2, 3, 1).detach()
+        a0 += h * w
+        for got, ref, nm in ((box, ref_box, "box"), (cls, ref_cls, "cls"), (coef, ref_coef, "coef")):
+            err = float((got - ref).abs().max() / (1 + ref.abs().max()))
+            assert err < 1e-4, f"forward level {li} {nm}: {err:.2e}"
+    perr = float((fw["proto"] - p.permute(0, 2, 3, 1).detach()).abs().max() / (1 + p.abs().max()))
+    assert perr < 1e-4, f"proto {perr:.2e}"
+    # ---- BN running statistics after one step
+    sd = store.state_dict()
+    for k in ("model.0.bn.running_mean", "model.4.cv2.bn.running_var", "model.10.m.0.attn.pe.bn.running_mean", "model.23.cv3.1.0.0.bn.running_var"):
+        assert torch.allclose(sd[k], bufs[k], rtol=1e-4, atol=1e-6), k
+    # ---- gradients
+    gsd = store.state_dict(p=store.g)
+    worst = []
+    for k, ref in grads.items():
+        if k == "model.23.dfl.conv.weight":
+            continue
+        got = gsd[k]
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((got - ref).abs().max()) / scale
+        worst.append((err, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-3, f"worst gradient mismatches: {worst[:8]}"
+
+
+def test_train_step_bf16_gradients_are_close_in_direction(synth_state):
+    """bf16 activations/weights, fp32 accumulation and fp32 master gradients: cosine similarity with the fp32 oracle."""
+    rng = np.random.default_rng(2)
+    N, H, W = 2, 64, 96
+    img = rng.integers(0, 256, size=(N, H, W, 3), dtype=np.uint8)
+    R, shapes = _probe(N, H, W)
+    _, _, _, grads, _ = _oracle_run(synth_state, img, R)
+    store, plan, fw = _run_plan(synth_state, img, R, shapes, MSL_BF16)
+    gsd = store.state_dict(p=store.g)
+    assert all(torch.isfinite(v).all() for v in gsd.values())
+    for k in ("model.23.proto.cv2.conv.weight", "model.23.cv2.0.1.conv.weight", "model.22.cv2.conv.weight", "model.23.cv4.0.2.weight"):
+        a, b = gsd[k].flatten(), grads[k].flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-20))
+        assert cos > 0.97, (k, cos)

@@ -30,6 +30,23 @@ static int dispatch(const msl_op& op, hipStream_t s) {
     case MSL_OP_VOL_INSERT: return msl_launch_vol_insert(op, s);
     case MSL_OP_VOL_CONSENSUS: return msl_launch_vol_consensus(op, s);
     case MSL_OP_VOL_DICE: return msl_launch_vol_dice(op, s);
+    case MSL_OP_BN_STATS: return msl_launch_bn_stats(op, s);
+    case MSL_OP_BN_FINALIZE: return msl_launch_bn_finalize(op, s);
+    case MSL_OP_BN_ACT: return msl_launch_bn_act(op, s);
+    case MSL_OP_BN_ACT_BWD_REDUCE: return msl_launch_bn_act_bwd_reduce(op, s);
+    case MSL_OP_BN_ACT_BWD_APPLY: return msl_launch_bn_act_bwd_apply(op, s);
+    case MSL_OP_COLSUM: return msl_launch_colsum(op, s);
+    case MSL_OP_F64_DRAIN: return msl_launch_f64_drain(op, s);
+    case MSL_OP_ADD_VIEW: return msl_launch_add_view(op, s);
+    case MSL_OP_UPSAMPLE2X_BWD: return msl_launch_upsample2x_bwd(op, s);
+    case MSL_OP_SPPF_POOL_BWD: return msl_launch_sppf_pool_bwd(op, s);
+    case MSL_OP_CONV_WGRAD: return msl_launch_conv_wgrad(op, s);
+    case MSL_OP_DW_WGRAD: return msl_launch_dw_wgrad(op, s);
+    case MSL_OP_STEM_WGRAD: return msl_launch_stem_wgrad(op, s);
+    case MSL_OP_CAST_PAD: return msl_launch_cast_pad(op, s);
+    case MSL_OP_GATHER_CAST: return msl_launch_gather_cast(op, s);
+    case MSL_OP_ADAMW: return msl_launch_adamw(op, s);
+    case MSL_OP_EMA: return msl_launch_ema(op, s);
     default:
       msl_set_error("unknown op kind %d", op.kind);
       return MSL_ENOSYS;

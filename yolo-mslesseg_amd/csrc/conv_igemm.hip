@@ -28,7 +28,7 @@ struct ConvArgs {
   char* y;
   int N, H, W, Cin, Ho, Wo, Cout, k, stride, pad;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
-  int K, Kpad, act, out_f32, store_mode, Cout_pad;
+  int K, Kpad, act, out_f32, store_mode, Cout_pad, dgrad;
 };
 
 template <bool F32, int COT, int PT>
@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     int n = (int)(pp / HoWo);
     int r = (int)(pp - (long)n * HoWo);
     int oy = r / a.Wo, ox = r - oy * a.Wo;
-    iy0[pt] = oy * a.stride - a.pad;
-    ix0[pt] = ox * a.stride - a.pad;
+    // forward: source = out*stride - pad + tap.  dgrad (transposed conv): source = (out + pad - tap) / stride when divisible.
+    iy0[pt] = a.dgrad ? oy + a.pad : oy * a.stride - a.pad;
+    ix0[pt] = a.dgrad ? ox + a.pad : ox * a.stride - a.pad;
     xoff[pt] = (long)n * a.H * a.W * a.x_cs + a.x_co;
   }
   f32x4 acc[COT][PT];
@@ -83,7 +84,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       int iy = iy0[pt] + ty, ix = ix0[pt] + tx;
-      bool ok = pv[pt] && kin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      bool ok = pv[pt] && kin;
+      if (a.dgrad) {
+        const int ny = iy0[pt] - ty, nx = ix0[pt] - tx, sm = a.stride - 1;  // stride is 1 or 2
+        ok = ok && ny >= 0 && nx >= 0 && ((ny | nx) & sm) == 0;
+        iy = ny >> sm;
+        ix = nx >> sm;
+      }
+      ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (ok) v = *(const uint4*)(a.x + (xoff[pt] + ((long)iy * a.W + ix) * a.x_cs + ci) * ES);
       bv[pt] = v;
@@ -181,16 +189,20 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
   a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6];
   a.k = op.i[7]; a.stride = op.i[8]; a.pad = op.i[9]; a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12];
   a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15]; a.K = op.i[16]; a.Kpad = op.i[17]; a.act = op.i[18];
-  a.out_f32 = op.i[19]; a.store_mode = op.i[20]; a.Cout_pad = op.i[21];
+  a.out_f32 = op.i[19]; a.store_mode = op.i[20]; a.Cout_pad = op.i[21]; a.dgrad = op.i[22];
   const bool f32 = op.dtype == MSL_F32;
   const int ch = f32 ? 4 : 8, kstep = f32 ? 16 : 32;
   MSL_REQUIRE(op.dtype == MSL_F32 || op.dtype == MSL_BF16, "conv: bad dtype %d", op.dtype);
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv: null pointer");
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.Cout > 0 && a.Cin > 0, "conv: bad dims");
-  MSL_REQUIRE(a.k == 1 || a.k == 3, "conv: k=%d unsupported", a.k);
+  MSL_REQUIRE(a.k >= 1 && a.k <= 3, "conv: k=%d unsupported", a.k);
   MSL_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride=%d unsupported", a.stride);
-  MSL_REQUIRE(a.Ho == (a.H + 2 * a.pad - a.k) / a.stride + 1 && a.Wo == (a.W + 2 * a.pad - a.k) / a.stride + 1,
-              "conv: output dims %dx%d inconsistent with input %dx%d k%d s%d p%d", a.Ho, a.Wo, a.H, a.W, a.k, a.stride, a.pad);
+  if (!a.dgrad)
+    MSL_REQUIRE(a.Ho == (a.H + 2 * a.pad - a.k) / a.stride + 1 && a.Wo == (a.W + 2 * a.pad - a.k) / a.stride + 1,
+                "conv: output dims %dx%d inconsistent with input %dx%d k%d s%d p%d", a.Ho, a.Wo, a.H, a.W, a.k, a.stride, a.pad);
+  else  // dgrad: (H,W) is the gradient being read, (Ho,Wo) the forward input being produced
+    MSL_REQUIRE(a.H == (a.Ho + 2 * a.pad - a.k) / a.stride + 1 && a.W == (a.Wo + 2 * a.pad - a.k) / a.stride + 1 && a.store_mode == 0,
+                "conv dgrad: source dims %dx%d inconsistent with destination %dx%d k%d s%d p%d", a.H, a.W, a.Ho, a.Wo, a.k, a.stride, a.pad);
   MSL_REQUIRE(a.Cin % ch == 0 && a.x_cs % ch == 0 && a.x_co % ch == 0, "conv: Cin/x_cs/x_co must be multiples of %d", ch);
   MSL_REQUIRE(a.x_co + a.Cin <= a.x_cs, "conv: input view exceeds channel stride");
   MSL_REQUIRE(a.K == a.k * a.k * a.Cin && a.Kpad % kstep == 0 && a.Kpad >= a.K, "conv: K=%d Kpad=%d inconsistent", a.K, a.Kpad);

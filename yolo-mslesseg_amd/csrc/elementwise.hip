@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
                                                      const float* __restrict__ bias, const void* __restrict__ res,
                                                      void* __restrict__ y, int N, int H, int W, int C, int x_cs, int x_co,
                                                      int y_cs, int y_co, int res_cs, int res_co, int act, int gsz,
-                                                     int gstride, int goff) {
+                                                     int gstride, int goff, int flip, int omap) {
   const int C4 = C >> 2;
   long t = (long)blockIdx.x * 256 + threadIdx.x;
   long total = (long)N * H * W * C4;
@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   long q = p / W;
   int iy = (int)(q % H);
   int n = (int)(q / H);
-  int cin = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
+  const int cmap = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
+  const int cin = omap ? c : cmap;    // channel map on the input side (Attention.pe forward) ...
+  const int cdst = omap ? cmap : c;   // ... or on the output/residual side (its backward: gradient lands in the v slots of qkv)
   float4 b4 = *(const float4*)(bias + c);
   float acc[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
       if ((unsigned)xx >= (unsigned)W) continue;
       float v[4];
       ld4<F32>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin, v);
-      float4 w4 = *(const float4*)(w + (ky * 3 + kx) * C + c);
+      float4 w4 = *(const float4*)(w + (flip ? 8 - (ky * 3 + kx) : ky * 3 + kx) * C + c);
       acc[0] = fmaf(v[0], w4.x, acc[0]); acc[1] = fmaf(v[1], w4.y, acc[1]);
       acc[2] = fmaf(v[2], w4.z, acc[2]); acc[3] = fmaf(v[3], w4.w, acc[3]);
     }
@@ -119,11 +121,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   }
   if (res) {
     float rv[4];
-    ld4<F32>(res, p * res_cs + res_co + c, rv);
+    ld4<F32>(res, p * res_cs + res_co + cdst, rv);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] += rv[r];
   }
-  st4<F32>(y, p * y_cs + y_co + c, acc);
+  st4<F32>(y, p * y_cs + y_co + cdst, acc);
 }
 
 int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
@@ -131,16 +133,18 @@ int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
   int res_cs = op.i[14], res_co = op.i[15], act = op.i[18], gsz = op.i[22], gstride = op.i[23], goff = op.i[24];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4], "dwconv: null pointer");
   MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv: bad dims");
-  MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && y_co + C <= y_cs, "dwconv: bad views");
-  if (gsz) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && x_co + (C / gsz - 1) * gstride + goff + gsz <= x_cs, "dwconv: bad group map");
+  MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && (op.i[21] || y_co + C <= y_cs), "dwconv: bad views");
+  const int flip = op.i[20], omap = op.i[21];
+  if (gsz && !omap) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && x_co + (C / gsz - 1) * gstride + goff + gsz <= x_cs, "dwconv: bad group map");
   else MSL_REQUIRE(x_co + C <= x_cs, "dwconv: input view exceeds stride");
+  if (gsz && omap) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && y_co + (C / gsz - 1) * gstride + goff + gsz <= y_cs, "dwconv: bad output group map");
   if (op.p[3]) MSL_REQUIRE(res_cs % 4 == 0 && res_co % 4 == 0 && res_co + C <= res_cs, "dwconv: bad residual view");
   long total = (long)N * H * W * (C / 4);
   unsigned grid = (unsigned)((total + 255) / 256);
   if (op.dtype == MSL_F32)
-    hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff);
+    hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap);
   else
-    hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff);
+    hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap);
   MSL_CHECK_LAUNCH("dwconv");
   return MSL_OK;
 }

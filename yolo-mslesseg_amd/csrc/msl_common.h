@@ -98,3 +98,20 @@ int msl_launch_letterbox(const msl_op& op, hipStream_t s);
 int msl_launch_vol_insert(const msl_op& op, hipStream_t s);
 int msl_launch_vol_consensus(const msl_op& op, hipStream_t s);
 int msl_launch_vol_dice(const msl_op& op, hipStream_t s);
+int msl_launch_bn_stats(const msl_op& op, hipStream_t s);
+int msl_launch_bn_finalize(const msl_op& op, hipStream_t s);
+int msl_launch_bn_act(const msl_op& op, hipStream_t s);
+int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s);
+int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s);
+int msl_launch_colsum(const msl_op& op, hipStream_t s);
+int msl_launch_f64_drain(const msl_op& op, hipStream_t s);
+int msl_launch_add_view(const msl_op& op, hipStream_t s);
+int msl_launch_upsample2x_bwd(const msl_op& op, hipStream_t s);
+int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s);
+int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s);
+int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s);
+int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s);
+int msl_launch_cast_pad(const msl_op& op, hipStream_t s);
+int msl_launch_gather_cast(const msl_op& op, hipStream_t s);
+int msl_launch_adamw(const msl_op& op, hipStream_t s);
+int msl_launch_ema(const msl_op& op, hipStream_t s);

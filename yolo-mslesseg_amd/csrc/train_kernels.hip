@@ -1,0 +1,669 @@
+// Training-leg kernels: BatchNorm (batch statistics) + SiLU forward/backward, weight gradients, the small
+// reductions and scatter steps of the backward pass, weight packing, AdamW and EMA over flat buffers.
+// Replaces the arithmetic of ultralytics' trainer loop under model.train(...)  [REF yolo_mslesseg/scripts/train.py:358-366]:
+// nn.BatchNorm2d(train) / SiLU / Conv2d backward, optim.AdamW, ModelEMA  [UPSTREAM engine/trainer.py, utils/torch_utils.py].
+//
+// All of these are HBM-bound streams or reductions except CONV_WGRAD (a GEMM whose contraction axis is the pixel axis).
+#include <string.h>
+
+#include "msl_common.h"
+
+// =========================================================================================================
+// Per-channel reductions over the pixel axis of an NHWC view.  Block = 256 threads laid out as (C/4 channel
+// quads) x (pixel lanes); fp32 partials per thread, LDS tree over pixel lanes, one fp64 atomicAdd per channel
+// and block (fp64 so that E[z^2]-E[z]^2 and the long sums keep fp32-level accuracy at M ~ 3e6 pixels).
+// =========================================================================================================
+template <bool F32, int MODE>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ acc,
+                                                          long M, int C, int a_cs, int a_co, int b_cs, int b_co, int act, int a_f32) {
+  __shared__ float red[2][256][4];
+  const int C4 = C >> 2;
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int c = cq * 4;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+  if (MODE == 1 && pl < PL) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
+  }
+  if (pl < PL) {
+    for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
+      float va[4], vb[4];
+      if (MODE == 2 && a_f32) ld4<true>(a, p * a_cs + a_co + c, va); else ld4<F32>(a, p * a_cs + a_co + c, va);
+      if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] += va[r]; s2[r] = fmaf(va[r], va[r], s2[r]); }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[r] += va[r];
+      } else {  // a = dy, b = z
+        ld4<F32>(b, p * b_cs + b_co + c, vb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zh = (vb[r] - mu[r]) * is[r];
+          float g = va[r];
+          if (act) {
+            const float u = fmaf(ga[r], zh, be[r]);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+            g *= sg * (1.0f + u * (1.0f - sg));
+          }
+          s1[r] += g;
+          s2[r] = fmaf(g, zh, s2[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+    for (int j = 0; j < PL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { t1[r] += red[0][j * C4 + threadIdx.x][r]; t2[r] += red[1][j * C4 + threadIdx.x][r]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (MODE == 2) atomicAdd(acc + c + r, (double)t1[r]);
+      else { atomicAdd(acc + 2 * (c + r), (double)t1[r]); atomicAdd(acc + 2 * (c + r) + 1, (double)t2[r]); }
+    }
+  }
+}
+
+static int reduce_grid(long M, int C) {
+  const int PL = 256 / (C / 4);
+  long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+// BN_STATS: p 0 z, 1 acc f64[2C] ; i 0 N,1 H,2 W,3 C,10 cs,11 co
+int msl_launch_bn_stats(const msl_op& op, hipStream_t s) {
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3], cs = op.i[10], co = op.i[11];
+  MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && cs % 4 == 0 && co % 4 == 0 && co + C <= cs, "bn_stats: bad args");
+  dim3 grid(reduce_grid(M, C));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0);
+  else hipLaunchKernelGGL((chan_reduce_kernel<false, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0);
+  MSL_CHECK_LAUNCH("bn_stats");
+  return MSL_OK;
+}
+
+// BN_FINALIZE: mean / invstd from the sums, running-stat update, accumulator reset.
+__global__ void bn_finalize_kernel(double* __restrict__ acc, float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar, int C,
+                                   double M, float eps, float mom) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double mean = acc[2 * c] / M;
+  double var = acc[2 * c + 1] / M - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * c] = (float)mean;
+  stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    rmean[c] = (1.f - mom) * rmean[c] + mom * (float)mean;
+    rvar[c] = (1.f - mom) * rvar[c] + mom * (float)(var * (M > 1 ? M / (M - 1) : 1.0));
+  }
+  acc[2 * c] = 0.0;
+  acc[2 * c + 1] = 0.0;
+}
+
+// BN_FINALIZE: p 0 acc, 1 stats f32[2C], 2 running_mean|NULL, 3 running_var ; i 0 N,1 H,2 W,3 C ; f 0 eps, 1 momentum
+int msl_launch_bn_finalize(const msl_op& op, hipStream_t s) {
+  const double M = (double)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && (!op.p[2] || op.p[3]), "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[1], (float*)op.p[2], (float*)op.p[3], C, M, op.f[0], op.f[1]);
+  MSL_CHECK_LAUNCH("bn_finalize");
+  return MSL_OK;
+}
+
+// BN_ACT forward: y = act(gamma * (z - mean) * invstd + beta) (+ res)
+template <bool F32>
+__global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y, long M, int C,
+                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act) {
+  const int C4 = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * C4) return;
+  const int c = (int)(t % C4) * 4;
+  const long p = t / C4;
+  float v[4];
+  ld4<F32>(z, p * z_cs + z_co + c, v);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u = fmaf(gamma[c + r], (v[r] - stats[2 * (c + r)]) * stats[2 * (c + r) + 1], beta[c + r]);
+    v[r] = act ? silu_f(u) : u;
+  }
+  if (res) {
+    float rv[4];
+    ld4<F32>(res, p * r_cs + r_co + c, rv);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+  }
+  st4<F32>(y, p * y_cs + y_co + c, v);
+}
+
+// BN_ACT: p 0 z, 1 stats, 2 gamma, 3 res|NULL, 4 y, 5 beta ; i 0 N,1 H,2 W,3 C,10 z_cs,11 z_co,12 y_cs,13 y_co,14 r_cs,15 r_co,18 act
+int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4] && op.p[5] && M > 0 && C > 0 && C % 4 == 0, "bn_act: bad args");
+  MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "bn_act: bad views");
+  if (op.p[3]) MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14], "bn_act: bad residual view");
+  const long total = M * (C / 4);
+  dim3 grid((unsigned)((total + 255) / 256));
+#define BA(F) hipLaunchKernelGGL(bn_act_kernel<F>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18])
+  if (op.dtype == MSL_F32) BA(true); else BA(false);
+#undef BA
+  MSL_CHECK_LAUNCH("bn_act");
+  return MSL_OK;
+}
+
+// BN_ACT_BWD_REDUCE: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc f64[2C] ; i 0 N,1 H,2 W,3 C,10 z_cs,11 z_co,12 dy_cs,13 dy_co,18 act
+int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s) {
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_reduce: bad args");
+  MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "bn_act_bwd_reduce: bad views");
+  dim3 grid(reduce_grid(M, C));
+#define BR(F) hipLaunchKernelGGL((chan_reduce_kernel<F, 1>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0)
+  if (op.dtype == MSL_F32) BR(true); else BR(false);
+#undef BR
+  MSL_CHECK_LAUNCH("bn_act_bwd_reduce");
+  return MSL_OK;
+}
+
+// BN_ACT_BWD_APPLY: dz = gamma*invstd*(g - s1/M - zhat*s2/M), g = dy*act'(u).  Also writes dgamma = s2, dbeta = s1 (block 0).
+template <bool F32>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ z, const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
+                                                               int dz_cs, int dz_co, int act) {
+  const int C4 = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)acc[2 * c]; dgamma[c] = (float)acc[2 * c + 1]; }
+  }
+  if (t >= M * C4) return;
+  const int c = (int)(t % C4) * 4;
+  const long p = t / C4;
+  float g[4], v[4];
+  ld4<F32>(dy, p * dy_cs + dy_co + c, g);
+  ld4<F32>(z, p * z_cs + z_co + c, v);
+  const float invM = 1.0f / (float)M;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float is = stats[2 * (c + r) + 1], ga = gamma[c + r];
+    const float zh = (v[r] - stats[2 * (c + r)]) * is;
+    float gg = g[r];
+    if (act) {
+      const float u = fmaf(ga, zh, beta[c + r]);
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+      gg *= sg * (1.0f + u * (1.0f - sg));
+    }
+    const float s1 = (float)acc[2 * (c + r)], s2 = (float)acc[2 * (c + r) + 1];
+    v[r] = ga * is * (gg - s1 * invM - zh * s2 * invM);
+  }
+  st4<F32>(dz, p * dz_cs + dz_co + c, v);
+}
+
+// BN_ACT_BWD_APPLY: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc, 6 dz, 7 dgamma (dbeta = dgamma + i[20]) ; i as REDUCE + 14 dz_cs,15 dz_co, 20 dbeta offset (elements)
+int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0, "bn_act_bwd_apply: bad args");
+  MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14], "bn_act_bwd_apply: bad dz view");
+  const long total = M * (C / 4);
+  dim3 grid((unsigned)((total + 255) / 256));
+  float* dgamma = (float*)op.p[7];
+  float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
+#define BB(F) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<F>, grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18])
+  if (op.dtype == MSL_F32) BB(true); else BB(false);
+#undef BB
+  MSL_CHECK_LAUNCH("bn_act_bwd_apply");
+  return MSL_OK;
+}
+
+// COLSUM: out f32[C] += sum over pixels of a view (bias gradients).  p 0 a, 4 acc f64[C] ; i 0 N,1 H,2 W,3 C,10 cs,11 co,19 a_is_f32
+int msl_launch_colsum(const msl_op& op, hipStream_t s) {
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[4] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[11] + C <= op.i[10], "colsum: bad args");
+  dim3 grid(reduce_grid(M, C));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19]);
+  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19]);
+  MSL_CHECK_LAUNCH("colsum");
+  return MSL_OK;
+}
+
+// F64_TO_F32: dst f32[n] = (float)src f64[n]; src = 0 (drains a reduction accumulator into the flat gradient buffer)
+__global__ void f64_drain_kernel(double* __restrict__ src, float* __restrict__ dst, int n, int stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  dst[i] = (float)src[(long)i * stride];
+  src[(long)i * stride] = 0.0;
+}
+// p 0 src f64, 4 dst f32 ; i 0 n, 1 stride
+int msl_launch_f64_drain(const msl_op& op, hipStream_t s) {
+  MSL_REQUIRE(op.p[0] && op.p[4] && op.i[0] > 0 && op.i[1] > 0, "f64_drain: bad args");
+  hipLaunchKernelGGL(f64_drain_kernel, dim3((op.i[0] + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[4], op.i[0], op.i[1]);
+  MSL_CHECK_LAUNCH("f64_drain");
+  return MSL_OK;
+}
+
+// =========================================================================================================
+// Elementwise / scatter helpers of the backward pass
+// =========================================================================================================
+// ADD_VIEW: dst += src (views of equal shape; src may be fp32 while dst is the op dtype)
+template <bool F32>
+__global__ __launch_bounds__(256) void add_view_kernel(void* __restrict__ dst, const void* __restrict__ src, long M, int C, int d_cs, int d_co,
+                                                       int s_cs, int s_co, int src_f32, int overwrite) {
+  const int C4 = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * C4) return;
+  const int c = (int)(t % C4) * 4;
+  const long p = t / C4;
+  float a[4] = {0, 0, 0, 0}, b[4];
+  if (!overwrite) ld4<F32>(dst, p * d_cs + d_co + c, a);
+  if (src_f32) ld4<true>(src, p * s_cs + s_co + c, b); else ld4<F32>(src, p * s_cs + s_co + c, b);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] += b[r];
+  st4<F32>(dst, p * d_cs + d_co + c, a);
+}
+// p 0 dst, 1 src ; i 0 N,1 H,2 W,3 C,10 d_cs,11 d_co,12 s_cs,13 s_co,19 src_f32, 20 overwrite (dst = src)
+int msl_launch_add_view(const msl_op& op, hipStream_t s) {
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  const int C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && C % 4 == 0 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 &&
+                  op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "add_view: bad args");
+  const long total = M * (C / 4);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(add_view_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[19], op.i[20]);
+  else hipLaunchKernelGGL(add_view_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[19], op.i[20]);
+  MSL_CHECK_LAUNCH("add_view");
+  return MSL_OK;
+}
+
+// UPSAMPLE2X_BWD: dx[n,y,x,c] += dy[2y,2x] + dy[2y,2x+1] + dy[2y+1,2x] + dy[2y+1,2x+1]
+template <bool F32>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(void* __restrict__ dx, const void* __restrict__ dy, int N, int H, int W, int C, int x_cs,
+                                                             int x_co, int y_cs, int y_co) {
+  const int C4 = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * H * W * C4) return;
+  const int c = (int)(t % C4) * 4;
+  const long p = t / C4;
+  const int x = (int)(p % W);
+  const long q = p / W;
+  const int y = (int)(q % H), n = (int)(q / H);
+  float a[4];
+  ld4<F32>(dx, p * x_cs + x_co + c, a);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float b[4];
+    ld4<F32>(dy, (((long)n * 2 * H + 2 * y + (k >> 1)) * 2 * W + 2 * x + (k & 1)) * y_cs + y_co + c, b);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] += b[r];
+  }
+  st4<F32>(dx, p * x_cs + x_co + c, a);
+}
+// p 0 dx, 1 dy ; i 0 N,1 H,2 W (of dx),3 C,10 x_cs,11 x_co,12 y_cs,13 y_co
+int msl_launch_upsample2x_bwd(const msl_op& op, hipStream_t s) {
+  const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0,
+              "upsample2x_bwd: bad args");
+  const long total = (long)N * H * W * (C / 4);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  else hipLaunchKernelGGL(upsample2x_bwd_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  MSL_CHECK_LAUNCH("upsample2x_bwd");
+  return MSL_OK;
+}
+
+// SPPF_POOL_BWD: dy of the 5x5/9x9/13x13 pools (views at co+C, co+2C, co+3C of the grad buffer) is routed to the arg-max
+// position of each window in the forward view (first maximum in row-major scan order) and accumulated into a fp32 scratch
+// [N,H,W,C], which ADD_VIEW then folds into the grad view at co.  (Chained 5x5 pools route to an equal-valued element.)
+template <bool F32>
+__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const void* __restrict__ ybuf, const void* __restrict__ gbuf, float* __restrict__ scratch,
+                                                            int N, int H, int W, int C, int cs, int co, int g_cs, int g_co) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * H * W * C) return;
+  const int c = (int)(t % C);
+  const long p = t / C;
+  const int ix = (int)(p % W);
+  const long q = p / W;
+  const int iy = (int)(q % H), n = (int)(q / H);
+  float best[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  int arg[3] = {0, 0, 0};
+  for (int dy = -6; dy <= 6; ++dy) {
+    const int yy = iy + dy;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int xx = ix + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float v = Elem<F32>::ld(ybuf, (((long)n * H + yy) * W + xx) * cs + co + c);
+      const int ad = max(abs(dy), abs(dx)), pos = yy * W + xx;
+      if (v > best[2]) { best[2] = v; arg[2] = pos; }
+      if (ad <= 4 && v > best[1]) { best[1] = v; arg[1] = pos; }
+      if (ad <= 2 && v > best[0]) { best[0] = v; arg[0] = pos; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float g = Elem<F32>::ld(gbuf, p * g_cs + g_co + (k + 1) * C + c);
+    if (g != 0.f) atomicAdd(scratch + ((long)n * H * W + arg[k]) * C + c, g);
+  }
+}
+// p 0 y buffer (forward concat buffer), 1 grad buffer, 4 scratch f32 [N,H,W,C] (zeroed by the caller) ; i 0 N,1 H,2 W,3 C,10 cs,11 co,12 g_cs,13 g_co
+int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s) {
+  const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && op.i[11] + 4 * C <= op.i[10] && op.i[13] + 4 * C <= op.i[12], "sppf_pool_bwd: bad args");
+  const long total = (long)N * H * W * C;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_bwd_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  else hipLaunchKernelGGL(sppf_pool_bwd_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  MSL_CHECK_LAUNCH("sppf_pool_bwd");
+  return MSL_OK;
+}
+
+// =========================================================================================================
+// Weight gradients
+// =========================================================================================================
+// CONV_WGRAD: dW[co][(ky,kx,ci)] += sum_p dz[p][co] * x[pix(p,ky,kx)][ci]  — a GEMM contracting over the PIXEL axis.
+// Operands come from NHWC tensors whose contiguous axis is the channel, i.e. the GEMM's M/N axes, so the fp32-input MFMA
+// (v_mfma_f32_16x16x4_f32: one element per lane, lane = (row l&15, k l>>4)) takes them with naturally coalesced loads:
+// 16 lanes read 16 consecutive channels of one pixel.  bf16 tensors are widened on load; accumulation is exact fp32.
+// A wave owns a 64(co) x 64(ci) block of one tap and a contiguous pixel range; partial sums go out with fp32 atomics
+// (few: the gradient tensor is tiny compared with the pixel stream).
+struct WgradArgs {
+  const char* x;
+  const char* dz;
+  float* dw;
+  int N, H, W, Cin, Ho, Wo, Cout, k, stride, pad;
+  int x_cs, x_co, z_cs, z_co, K, pix_per_wave, dz_f32;
+};
+
+template <bool F32>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  // blockIdx.y enumerates (tap, ci-block of 64, co-block of 64)
+  const int ciB = (a.Cin + 63) / 64, coB = (a.Cout + 63) / 64;
+  int by = blockIdx.y;
+  const int cob = by % coB; by /= coB;
+  const int cib = by % ciB;
+  const int tap = by / ciB;
+  const int ty = tap / a.k, tx = tap - ty * a.k;
+  const long M = (long)a.N * a.Ho * a.Wo;
+  const long p_begin = ((long)blockIdx.x * 4 + wave) * a.pix_per_wave;
+  if (p_begin >= M) return;
+  const long p_end = min(M, p_begin + a.pix_per_wave);
+  const int HoWo = a.Ho * a.Wo;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bool cov[4], civ[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { cov[i] = cob * 64 + i * 16 + l15 < a.Cout; civ[i] = cib * 64 + i * 16 + l15 < a.Cin; }
+
+  for (long p0 = p_begin; p0 < p_end; p0 += 4) {
+    const long p = p0 + kq;
+    const bool pv = p < p_end;
+    long xoff = 0;
+    bool xin = false;
+    if (pv) {
+      const int n = (int)(p / HoWo);
+      const int r = (int)(p - (long)n * HoWo);
+      const int oy = r / a.Wo, ox = r - oy * a.Wo;
+      const int iy = oy * a.stride - a.pad + ty, ix = ox * a.stride - a.pad + tx;
+      xin = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      xoff = (((long)n * a.H + iy) * a.W + ix) * a.x_cs + a.x_co + cib * 64 + l15;
+    }
+    const long zoff = p * a.z_cs + a.z_co + cob * 64 + l15;
+    float av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[i] = (pv && cov[i]) ? (a.dz_f32 ? ((const float*)a.dz)[zoff + i * 16] : Elem<F32>::ld(a.dz, zoff + i * 16)) : 0.f;
+      bv[i] = (xin && civ[i]) ? Elem<F32>::ld(a.x, xoff + i * 16) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+  }
+  // D[row = co][col = ci]: col = lane&15, row = 4*(lane>>4)+reg
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = cib * 64 + j * 16 + l15;
+      if (ci >= a.Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cob * 64 + i * 16 + kq * 4 + r;
+        if (co < a.Cout) atomicAdd(a.dw + (long)co * a.K + tap * a.Cin + ci, acc[i][j][r]);
+      }
+    }
+}
+
+// p 0 x, 1 dz, 4 dW f32 [Cout][K] ; i 0 N,1 H,2 W,3 Cin,4 Ho,5 Wo,6 Cout,7 k,8 stride,9 pad,10 x_cs,11 x_co,12 z_cs,13 z_co,19 dz_is_f32
+int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
+  WgradArgs a;
+  a.x = (const char*)op.p[0]; a.dz = (const char*)op.p[1]; a.dw = (float*)op.p[4];
+  a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6]; a.k = op.i[7]; a.stride = op.i[8]; a.pad = op.i[9];
+  a.x_cs = op.i[10]; a.x_co = op.i[11]; a.z_cs = op.i[12]; a.z_co = op.i[13]; a.dz_f32 = op.i[19];
+  a.K = a.k * a.k * a.Cin;
+  MSL_REQUIRE(a.x && a.dz && a.dw, "conv_wgrad: null pointer");
+  MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0 && a.k >= 1 && a.k <= 3 && a.stride >= 1 && a.stride <= 2, "conv_wgrad: bad dims");
+  MSL_REQUIRE(a.Ho == (a.H + 2 * a.pad - a.k) / a.stride + 1 && a.Wo == (a.W + 2 * a.pad - a.k) / a.stride + 1, "conv_wgrad: inconsistent output dims");
+  MSL_REQUIRE(a.x_co + a.Cin <= a.x_cs && a.z_co + a.Cout <= a.z_cs, "conv_wgrad: views exceed strides");
+  const long M = (long)a.N * a.Ho * a.Wo;
+  const int ny = a.k * a.k * ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
+  // enough pixel splits to fill the chip (~2048 waves in flight) but at least 256 pixels per wave
+  long waves_x = (2048 + ny - 1) / ny;
+  long ppw = (M + waves_x - 1) / waves_x;
+  if (ppw < 256) ppw = 256;
+  ppw = (ppw + 3) / 4 * 4;
+  a.pix_per_wave = (int)ppw;
+  const long gx = (M + ppw * 4 - 1) / (ppw * 4);
+  dim3 grid((unsigned)gx, (unsigned)ny);
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, s, a);
+  MSL_CHECK_LAUNCH("conv_wgrad");
+  return MSL_OK;
+}
+
+// DW_WGRAD: dW[tap][c] += sum_p dz[p][c] * x[p + tap][c]   (depthwise 3x3, stride 1, pad 1; optional input channel map as DWCONV)
+template <bool F32>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const void* __restrict__ x, const void* __restrict__ dz, float* __restrict__ dw, int N, int H, int W,
+                                                       int C, int x_cs, int x_co, int z_cs, int z_co, int gsz, int gstride, int goff) {
+  __shared__ float red[9][256];
+  const int CL = C < 256 ? C : 256;  // channels per block (C <= 256 or multiple of 256)
+  const int c = blockIdx.y * CL + threadIdx.x % CL, pl = threadIdx.x / CL, PL = 256 / CL;
+  const int cin = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
+  float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const long M = (long)N * H * W;
+  if (pl < PL) {
+    for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
+      const int ix = (int)(p % W);
+      const long q = p / W;
+      const int iy = (int)(q % H), n = (int)(q / H);
+      const float g = Elem<F32>::ld(dz, p * z_cs + z_co + c);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = iy - 1 + t / 3, xx = ix - 1 + t % 3;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) s[t] = fmaf(g, Elem<F32>::ld(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin), s[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = s[t];
+  __syncthreads();
+  if (threadIdx.x < CL) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      for (int j = 0; j < PL; ++j) v += red[t][j * CL + threadIdx.x];
+      atomicAdd(dw + t * C + c, v);
+    }
+  }
+}
+// p 0 x, 1 dz, 4 dW f32 [9][C] ; i 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 z_cs,13 z_co,22 gsz,23 gstride,24 goff
+int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
+  const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "dw_wgrad: bad args (C must divide or be a multiple of 256)");
+  const long M = (long)N * H * W;
+  const int CL = C < 256 ? C : 256, PL = 256 / CL;
+  long bx = (M + (long)PL * 64 - 1) / ((long)PL * 64);
+  if (bx > 1024) bx = 1024;
+  dim3 grid((unsigned)bx, (unsigned)(C / CL));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(dw_wgrad_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24]);
+  else hipLaunchKernelGGL(dw_wgrad_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24]);
+  MSL_CHECK_LAUNCH("dw_wgrad");
+  return MSL_OK;
+}
+
+// STEM_WGRAD: dW[(ky,kx,ci)][co] += sum_p (u8[pix(p,ky,kx)][ci] / 255) * dz[p][co]   (3x3 stride 2 pad 1 on the uint8 image)
+template <bool F32, int COUT>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restrict__ x, const void* __restrict__ dz, float* __restrict__ dw, int N, int H, int W,
+                                                         int Ho, int Wo, int z_cs, int z_co) {
+  __shared__ float red[27 * COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int co = threadIdx.x % COUT, pl = threadIdx.x / COUT;
+  constexpr int PL = 256 / COUT;
+  float s[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) s[t] = 0.f;
+  const long M = (long)N * Ho * Wo;
+  for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
+    const int ox = (int)(p % Wo);
+    const long q = p / Wo;
+    const int oy = (int)(q % Ho), n = (int)(q / Ho);
+    const float g = Elem<F32>::ld(dz, p * z_cs + z_co + co);
+    const uint8_t* img = x + (long)n * H * W * 3;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const uint8_t* px = img + ((long)iy * W + ix) * 3;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) s[(ky * 3 + kx) * 3 + ci] = fmaf((float)px[ci] / 255.0f, g, s[(ky * 3 + kx) * 3 + ci]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) atomicAdd(&red[t * COUT + co], s[t]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) atomicAdd(dw + i, red[i]);
+}
+// p 0 x u8 [N,H,W,3], 1 dz, 4 dW f32 [27][Cout] ; i 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout,12 z_cs,13 z_co
+int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
+  const int N = op.i[0], H = op.i[1], W = op.i[2], Ho = op.i[4], Wo = op.i[5], Cout = op.i[6];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && (Cout == 16 || Cout == 32) && op.i[13] + Cout <= op.i[12], "stem_wgrad: bad args");
+  const long M = (long)N * Ho * Wo;
+  long bx = (M + 1023) / 1024;
+  if (bx > 2048) bx = 2048;
+#define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13])
+  if (op.dtype == MSL_F32) { if (Cout == 16) SW(true, 16); else SW(true, 32); }
+  else { if (Cout == 16) SW(false, 16); else SW(false, 32); }
+#undef SW
+  MSL_CHECK_LAUNCH("stem_wgrad");
+  return MSL_OK;
+}
+
+// =========================================================================================================
+// Weight packing, optimizer, EMA — flat fp32 master buffers
+// =========================================================================================================
+// CAST_PAD: dst[r][0..Kpad) (op dtype) = src f32 [r][0..K) zero padded; rows >= R are zero.  transpose=1: src is [K][R].
+template <bool F32>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, void* __restrict__ dst, int R, int K, int Rpad, int Kpad, int transpose) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)Rpad * Kpad) return;
+  const int r = (int)(t / Kpad), k = (int)(t - (long)r * Kpad);
+  float v = 0.f;
+  if (r < R && k < K) v = transpose ? src[(long)k * R + r] : src[(long)r * K + k];
+  Elem<F32>::st(dst, t, v);
+}
+// p 0 src f32, 4 dst ; i 0 R,1 K,2 Rpad,3 Kpad,4 transpose
+int msl_launch_cast_pad(const msl_op& op, hipStream_t s) {
+  MSL_REQUIRE(op.p[0] && op.p[4] && op.i[0] > 0 && op.i[1] > 0 && op.i[2] >= op.i[0] && op.i[3] >= op.i[1], "cast_pad: bad args");
+  const long total = (long)op.i[2] * op.i[3];
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(cast_pad_kernel<true>, grid, dim3(256), 0, s, (const float*)op.p[0], op.p[4], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+  else hipLaunchKernelGGL(cast_pad_kernel<false>, grid, dim3(256), 0, s, (const float*)op.p[0], op.p[4], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+  MSL_CHECK_LAUNCH("cast_pad");
+  return MSL_OK;
+}
+
+// ADAMW over a flat range: p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p), grads pre-scaled by `gscale` (clip factor / world size).
+// [UPSTREAM torch.optim.AdamW: decoupled decay p *= 1 - lr*wd, bias corrections 1-beta^t]
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ gscale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gs = gscale ? *gscale : 1.0f;
+  const float gi = g[i] * gs;
+  float pi = p[i];
+  pi *= 1.0f - lr * wd;
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+// p 0 params, 1 grads, 2 m, 3 v, 5 gscale f32[1]|NULL ; i 0 n_lo,1 n_hi ; f 0 lr,1 beta1,2 beta2,3 eps ; i 2 = float bits of wd, 3 = bits of bc1, 4 = bits of bc2
+int msl_launch_adamw(const msl_op& op, hipStream_t s) {
+  const long n = ((long)op.i[1] << 31) | (long)op.i[0];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && n > 0, "adamw: bad args");
+  float wd, bc1, bc2;
+  memcpy(&wd, &op.i[2], 4); memcpy(&bc1, &op.i[3], 4); memcpy(&bc2, &op.i[4], 4);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float*)op.p[0], (const float*)op.p[1], (float*)op.p[2], (float*)op.p[3], n,
+                     op.f[0], op.f[1], op.f[2], op.f[3], wd, bc1, bc2, (const float*)op.p[5]);
+  MSL_CHECK_LAUNCH("adamw");
+  return MSL_OK;
+}
+
+// EMA: e = d*e + (1-d)*p over a flat range  [UPSTREAM ModelEMA.update]
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long n, float d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) e[i] = d * e[i] + (1.0f - d) * p[i];
+}
+// p 0 ema, 1 params ; i 0 n_lo,1 n_hi ; f 0 decay
+int msl_launch_ema(const msl_op& op, hipStream_t s) {
+  const long n = ((long)op.i[1] << 31) | (long)op.i[0];
+  MSL_REQUIRE(op.p[0] && op.p[1] && n > 0, "ema: bad args");
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float*)op.p[0], (const float*)op.p[1], n, op.f[0]);
+  MSL_CHECK_LAUNCH("ema");
+  return MSL_OK;
+}
+
+// GATHER_CAST: dst[i] (op dtype) = idx[i] >= 0 ? src[idx[i]] : 0 — packs any kernel-side weight image (GEMM rows, LDS image,
+// transposed dgrad rows) from the flat fp32 master buffer with a host-built index table.
+template <bool F32>
+__global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restrict__ src, const int* __restrict__ idx, void* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = idx[i];
+  Elem<F32>::st(dst, i, j >= 0 ? src[j] : 0.f);
+}
+// p 0 src f32, 1 idx i32[n], 4 dst ; i 0 n_lo,1 n_hi
+int msl_launch_gather_cast(const msl_op& op, hipStream_t s) {
+  const long n = ((long)op.i[1] << 31) | (long)op.i[0];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && n > 0, "gather_cast: bad args");
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(gather_cast_kernel<true>, grid, dim3(256), 0, s, (const float*)op.p[0], (const int*)op.p[1], op.p[4], n);
+  else hipLaunchKernelGGL(gather_cast_kernel<false>, grid, dim3(256), 0, s, (const float*)op.p[0], (const int*)op.p[1], op.p[4], n);
+  MSL_CHECK_LAUNCH("gather_cast");
+  return MSL_OK;
+}

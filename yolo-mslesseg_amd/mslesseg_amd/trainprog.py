@@ -1,0 +1,625 @@
+"""Training programs: flat fp32 master parameters + forward/backward op programs for a fixed (N, H, W).
+
+Replaces the arithmetic under ``model.train(...)`` [REF yolo_mslesseg/scripts/train.py:358-366]: train-mode
+Conv+BatchNorm+SiLU forward, the whole backward pass, and the flat buffers AdamW/EMA/RCCL operate on.
+
+Layout decisions
+* ONE flat fp32 buffer each for parameters, gradients and Adam moments (`ParamStore`): the optimizer is one kernel
+  launch per decay group and the data-parallel exchange is ONE all-reduce of `grads`.  Conv weights are
+  stored [Cout][ky][kx][Cin] (the implicit-GEMM row layout), so CONV_WGRAD writes straight into the flat gradient.
+* Compute-dtype weight images (GEMM rows, LDS image, transposed dgrad rows) are re-packed from the master buffer every
+  step by GATHER_CAST with host-built index tables.
+* Activation gradients mirror the activation buffers (same views); whether a backward op overwrites or accumulates
+  into a gradient view is decided at build time (`_Init`), so nothing is memset per step.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import graph, hiplib, params
+from .engine import View, _dt
+from .hiplib import MSL_BF16, MSL_F32
+
+BN_EPS, BN_MOM = params.BN_EPS, params.BN_MOMENTUM
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class ParamStore:
+    """Flat fp32 master buffers.  Order: [decayed conv weights | BN gammas, BN betas, conv biases] (AdamW groups,
+    [UPSTREAM build_optimizer: weights with decay / norm weights / biases without])."""
+
+    def __init__(self, scale: str, nc: int, device):
+        self.scale, self.nc, self.device = scale, nc, torch.device(device)
+        self.specs = params.param_specs(scale, nc)
+        self.entries: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()  # key → (offset, logical shape)
+        off = 0
+        for name, s in self.specs.items():  # decayed weights
+            if s["kind"] == "convT":
+                shp = (s["cin"], 2, 2, s["cout"])  # [Cin][dy][dx][Cout]
+            elif s.get("stem"):
+                shp = (3, 3, 3, s["cout"])  # [(ky,kx,ci)][Cout]
+            elif s["groups"] > 1:
+                shp = (3, 3, s["cout"])  # [9][C]
+            else:
+                shp = (s["cout"], s["k"], s["k"], s["cin"])  # [Cout][ky][kx][Cin]
+            self.entries[name + ".w"] = (off, shp)
+            off = _align4(off + math.prod(shp))
+        self.n_decay = off
+        for name, s in self.specs.items():
+            if s["kind"] == "conv" and s["bn"]:
+                for t in ("gamma", "beta"):
+                    self.entries[f"{name}.{t}"] = (off, (s["cout"],))
+                    off = _align4(off + s["cout"])
+            else:
+                self.entries[name + ".bias"] = (off, (s["cout"],))
+                off = _align4(off + s["cout"])
+        self.n = off
+        boff = 0
+        self.bentries: "OrderedDict[str, int]" = OrderedDict()
+        for name, s in self.specs.items():
+            if s["kind"] == "conv" and s["bn"]:
+                for t in ("mean", "var"):
+                    self.bentries[f"{name}.{t}"] = boff
+                    boff = _align4(boff + s["cout"])
+        self.nb = boff
+        dev = self.device
+        self.p = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.b = torch.zeros(self.nb, dtype=torch.float32, device=dev)  # BN running stats
+
+    # -- addressing
+    def off(self, key: str) -> int:
+        return self.entries[key][0]
+
+    def ptr(self, key: str, buf: Optional[torch.Tensor] = None) -> int:
+        t = self.p if buf is None else buf
+        return t.data_ptr() + 4 * self.entries[key][0]
+
+    def bptr(self, key: str) -> int:
+        return self.b.data_ptr() + 4 * self.bentries[key]
+
+    def view(self, key: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        t = self.p if buf is None else buf
+        o, shp = self.entries[key]
+        return t[o : o + math.prod(shp)].view(shp)
+
+    # -- ultralytics state_dict ↔ flat buffers
+    def load_state(self, state: Dict[str, torch.Tensor]) -> None:
+        params.validate_state(state, self.scale, self.nc)
+        cpu_p, cpu_b = torch.zeros(self.n), torch.zeros(self.nb)
+
+        def put(key, t):
+            o, shp = self.entries[key]
+            cpu_p[o : o + t.numel()] = t.reshape(-1).float()
+
+        for name, s in self.specs.items():
+            if s["kind"] == "convT":
+                put(name + ".w", state[f"{name}.weight"].permute(0, 2, 3, 1))
+                put(name + ".bias", state[f"{name}.bias"])
+                continue
+            w = state[f"{name}.conv.weight"] if s["bn"] else state[f"{name}.weight"]
+            if s.get("stem"):
+                put(name + ".w", w.permute(2, 3, 1, 0))
+            elif s["groups"] > 1:
+                put(name + ".w", w[:, 0].permute(1, 2, 0))
+            else:
+                put(name + ".w", w.permute(0, 2, 3, 1))
+            if s["bn"]:
+                put(name + ".gamma", state[f"{name}.bn.weight"])
+                put(name + ".beta", state[f"{name}.bn.bias"])
+                for t, k in (("mean", "running_mean"), ("var", "running_var")):
+                    o = self.bentries[f"{name}.{t}"]
+                    cpu_b[o : o + s["cout"]] = state[f"{name}.bn.{k}"].float()
+            else:
+                put(name + ".bias", state[f"{name}.bias"])
+        self.p.copy_(cpu_p)
+        self.b.copy_(cpu_b)
+
+    def state_dict(self, p: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None) -> "OrderedDict[str, torch.Tensor]":
+        P = (self.p if p is None else p).detach().cpu()
+        B = (self.b if b is None else b).detach().cpu()
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+        def get(key):
+            o, shp = self.entries[key]
+            return P[o : o + math.prod(shp)].view(shp).clone()
+
+        for name, s in self.specs.items():
+            if s["kind"] == "convT":
+                out[f"{name}.weight"] = get(name + ".w").permute(0, 3, 1, 2).contiguous()
+                out[f"{name}.bias"] = get(name + ".bias")
+                continue
+            wk = f"{name}.conv.weight" if s["bn"] else f"{name}.weight"
+            w = get(name + ".w")
+            if s.get("stem"):
+                out[wk] = w.permute(3, 2, 0, 1).contiguous()
+            elif s["groups"] > 1:
+                out[wk] = w.permute(2, 0, 1).unsqueeze(1).contiguous()
+            else:
+                out[wk] = w.permute(0, 3, 1, 2).contiguous()
+            if s["bn"]:
+                out[f"{name}.bn.weight"] = get(name + ".gamma")
+                out[f"{name}.bn.bias"] = get(name + ".beta")
+                for t, k in (("mean", "running_mean"), ("var", "running_var")):
+                    o = self.bentries[f"{name}.{t}"]
+                    out[f"{name}.bn.{k}"] = B[o : o + s["cout"]].clone()
+                out[f"{name}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+            else:
+                out[f"{name}.bias"] = get(name + ".bias")
+        out["model.23.dfl.conv.weight"] = torch.arange(graph.REG_MAX, dtype=torch.float32).view(1, graph.REG_MAX, 1, 1)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# index tables: apply a weight-image permutation to flat offsets instead of values (-1 = zero padding)
+# ---------------------------------------------------------------------------------------------------------------
+def _idx_oihw(off: int, cout: int, cin: int, k: int) -> torch.Tensor:
+    """int64 [Cout,Cin,k,k] of flat offsets for a conv weight stored [Cout][ky][kx][Cin]."""
+    return (off + torch.arange(cout * k * k * cin, dtype=torch.int64).view(cout, k, k, cin)).permute(0, 3, 1, 2)
+
+
+def _gemm_rows_idx(idx2d: torch.Tensor, dtype: int):
+    kstep = 16 if dtype == MSL_F32 else 32
+    r, K = idx2d.shape
+    rpad, kpad = (r + 15) // 16 * 16, (K + kstep - 1) // kstep * kstep
+    out = torch.full((rpad, kpad), -1, dtype=torch.int64)
+    out[:r, :K] = idx2d
+    return out.reshape(-1).to(torch.int32), dict(K=K, Kpad=kpad, Cout_pad=rpad)
+
+
+def _lds_image_idx(idx4: torch.Tensor, dtype: int):
+    """idx4 [Cout,Cin,3,3] → LDS image [blk][cc][ky][kx][g][col][e] (engine.pack_conv3x3_lds)."""
+    cout, cin = idx4.shape[:2]
+    ch = 4 if dtype == MSL_F32 else 8
+    chunk = 4 * ch
+    cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
+    cob = 16 * cot
+    v = idx4.reshape(cout // cob, cob, cin // chunk, 4, ch, 3, 3).permute(0, 2, 5, 6, 3, 1, 4).contiguous()
+    return v.reshape(-1).to(torch.int32), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
+
+
+def _lds_ok(cin, cout, k, dtype):
+    chunk = 16 if dtype == MSL_F32 else 32
+    return k == 3 and cin % chunk == 0 and cout % 16 == 0
+
+
+class _Init:
+    """Build-time record of which channels of each gradient buffer already hold a value in backward order."""
+
+    def __init__(self):
+        self.done: Dict[int, torch.Tensor] = {}
+
+    def first_write(self, v: View) -> bool:
+        """True ⇒ this write must OVERWRITE (nothing there yet); marks the range initialised."""
+        m = self.done.setdefault(id(v.t), torch.zeros(v.cs, dtype=torch.bool))
+        seg = m[v.co : v.co + v.C]
+        if seg.all():
+            return False
+        assert not seg.any(), "partially initialised gradient range: backward order broken"
+        seg[:] = True
+        return True
+
+    def mark(self, v: View, chans=None):
+        m = self.done.setdefault(id(v.t), torch.zeros(v.cs, dtype=torch.bool))
+        if chans is None:
+            m[v.co : v.co + v.C] = True
+        else:
+            m[chans] = True
+
+    def is_done(self, v: View) -> bool:
+        m = self.done.get(id(v.t))
+        return m is not None and bool(m[v.co : v.co + v.C].all())
+
+
+class TrainPlan(graph.Visitor):
+    """Forward + backward programs of YOLO11-seg in training mode for a fixed batch shape.
+
+    step order:  pack() → forward() → [loss: fills head gradients] → backward()  → grads in `store.g`
+    `forward/backward` are lists of segments: hiplib.Program or a Python callable (the PSA attention core, < 1 % of
+    the FLOPs, still runs through rocBLAS batched GEMMs via torch in training — see DESIGN.md)."""
+
+    def __init__(self, store: ParamStore, N: int, H: int, W: int, dtype: int = MSL_BF16):
+        assert H % 32 == 0 and W % 32 == 0
+        self.store, self.N, self.H, self.W, self.dtype = store, N, H, W, dtype
+        self.device = store.device
+        self.zeros = torch.zeros(4096, dtype=torch.float32, device=self.device)
+        self.dump = torch.zeros(4096, dtype=torch.float32, device=self.device)  # sink of F64_DRAIN when only the reset matters
+        self._fwd: List = [[]]
+        self._bwd: List[List] = []  # per layer, list of ops / callables (emitted forward, replayed reversed)
+        self._pack: List = []
+        self._keep: List[torch.Tensor] = []
+        self.grads: Dict[int, torch.Tensor] = {}
+        self.levels, self.proto_view, self.in_view = {}, None, None
+        self.taps: Dict[str, View] = {}
+        self._init = _Init()
+        self._bw_builders: List[Callable[[], None]] = []
+        graph.walk(self, store.scale, store.nc)
+        self._finish()
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, H, W, C, f32=False) -> View:
+        t = torch.empty(self.N * H * W * C, dtype=torch.float32 if f32 else _dt(self.dtype), device=self.device)
+        return View(t, self.N, H, W, C, C, 0, f32)
+
+    def G(self, v: View) -> View:
+        """Gradient view mirroring an activation view."""
+        g = self.grads.get(id(v.t))
+        if g is None:
+            g = torch.empty_like(v.t)
+            self.grads[id(v.t)] = g
+        return View(g, v.N, v.H, v.W, v.C, v.cs, v.co, v.f32)
+
+    def _f(self, op):
+        self._fwd[-1].append(op)
+
+    def _acc(self, C) -> torch.Tensor:
+        t = torch.zeros(2 * C, dtype=torch.float64, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _packed(self, idx: torch.Tensor, dtype: Optional[int] = None) -> torch.Tensor:
+        """Register a GATHER_CAST from the master buffer; returns the destination tensor."""
+        dt = self.dtype if dtype is None else dtype
+        idx_d = idx.to(self.device)
+        dst = torch.empty(idx.numel(), dtype=_dt(dt), device=self.device)
+        self._keep += [idx_d, dst]
+        n = idx.numel()
+        self._pack.append(hiplib.make_op(hiplib.OP_GATHER_CAST, dt, p=(self.store.p.data_ptr(), idx_d.data_ptr(), 0, 0, dst.data_ptr()),
+                                         i={0: n & 0x7FFFFFFF, 1: n >> 31}))
+        return dst
+
+    def _conv_op(self, x: View, y: View, wt, bias_ptr, m, k, s, pad, act=0, res: Optional[View] = None, out_f32=False, store_mode=0, dgrad=0, cout=None):
+        cout = y.C if cout is None else cout
+        i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: (y.H // 2 if store_mode else y.H), 5: (y.W // 2 if store_mode else y.W), 6: cout, 7: k, 8: s, 9: pad,
+             10: x.cs, 11: x.co, 12: y.cs, 13: y.co, 16: m["K"], 17: m["Kpad"], 18: act, 19: 1 if out_f32 else 0, 20: store_mode, 21: m["Cout_pad"],
+             22: dgrad, 24: m.get("cot", 0), 25: m.get("lds", 0)}
+        rp = 0
+        if res is not None:
+            i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
+        return hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bias_ptr, rp, y.t.data_ptr()), i=i)
+
+    def _bn_forward(self, name, z: View, y: View, C, act, res):
+        st = self.store
+        acc = self._acc(C)
+        stats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
+        self._keep.append(stats)
+        dims = {0: self.N, 1: z.H, 2: z.W, 3: C}
+        self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co}))
+        self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var")),
+                               i=dims, f=(BN_EPS, BN_MOM)))
+        i = {**dims, 10: z.cs, 11: z.co, 12: y.cs, 13: y.co, 18: 1 if act else 0}
+        rp = 0
+        if res is not None:
+            i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
+        self._f(hiplib.make_op(hiplib.OP_BN_ACT, self.dtype, p=(z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), rp, y.t.data_ptr(), st.ptr(name + ".beta")), i=i))
+        return stats
+
+    def _bn_backward(self, ops, name, z: View, y: View, C, act, stats, res: Optional[View], res_inplace=False):
+        """dy = G(y) → dz written in place over z; dgamma/dbeta into the flat gradient; residual fan-out."""
+        st = self.store
+        gy = self.G(y)
+        if res is not None and not res_inplace:
+            gr = self.G(res)
+            first = self._init.first_write(gr)
+            ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gr.t.data_ptr(), gy.t.data_ptr()),
+                                      i={0: self.N, 1: y.H, 2: y.W, 3: C, 10: gr.cs, 11: gr.co, 12: gy.cs, 13: gy.co, 20: 1 if first else 0}))
+        acc = self._acc(C)
+        dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0}
+        pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
+        ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
+        ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=pcommon + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
+                                  i={**dims, 14: z.cs, 15: z.co, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
+        ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, self.dump.data_ptr()), i={0: 2 * C, 1: 1}))  # reset acc for the next step
+
+    # ------------------------------------------------------------------ Visitor
+    def input(self):
+        t = torch.empty(self.N * self.H * self.W * 3, dtype=torch.uint8, device=self.device)
+        self.in_view = View(t, self.N, self.H, self.W, 3, 3, 0)
+        return self.in_view
+
+    def stem(self, name, x, cout):
+        st = self.store
+        Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        z, y = self._new(Ho, Wo, cout), self._new(Ho, Wo, cout)
+        self._f(hiplib.make_op(hiplib.OP_STEM, self.dtype, p=(x.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), 0, z.t.data_ptr()),
+                               i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 18: 0}))
+        stats = self._bn_forward(name, z, y, cout, True, None)
+        self.taps[name] = y
+
+        def bw():
+            ops = []
+            self._bn_backward(ops, name, z, y, cout, True, stats, None)
+            ops.append(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
+                                      i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co}))
+            return ops
+
+        self._bw_builders.append(bw)
+        return y
+
+    def conv(self, name, x, cout, k=1, s=1, act=True, bn=True, out=None, res=None, f32_out=False):
+        st = self.store
+        pad = k // 2
+        Ho, Wo = (x.H + 2 * pad - k) // s + 1, (x.W + 2 * pad - k) // s + 1
+        cpad = cout if (bn or cout % 8 == 0) else (cout + 7) // 8 * 8  # narrow plain heads (cls, nc=1) are stored 8 channels wide
+        if out is not None:
+            y = out
+        elif cpad != cout:
+            wide = self._new(Ho, Wo, cpad, f32=f32_out)
+            wide.t.zero_()
+            y = View(wide.t, self.N, Ho, Wo, cout, cpad, 0, f32_out)
+        else:
+            y = self._new(Ho, Wo, cout, f32=f32_out)
+        cin = x.C
+        idx4 = _idx_oihw(st.off(name + ".w"), cout, cin, k)
+        if _lds_ok(cin, cout, k, self.dtype):
+            widx, wm = _lds_image_idx(idx4, self.dtype)
+        else:
+            widx, wm = _gemm_rows_idx(idx4.permute(0, 2, 3, 1).reshape(cout, -1), self.dtype)
+        wt = self._packed(widx)
+        # dgrad weights: rows = ci, K = (ky,kx,co)
+        if k == 3 and s == 1 and _lds_ok(cout, cin, 3, self.dtype):
+            didx, dm = _lds_image_idx(idx4.permute(1, 0, 2, 3).flip(2, 3), self.dtype)  # forward-style conv of dz with flipped taps
+            d_mode = 0
+        else:
+            drows = idx4.permute(1, 2, 3, 0)  # [ci][ky][kx][co]
+            if cpad != cout:
+                padded = torch.full((cin, k, k, cpad), -1, dtype=torch.int64)
+                padded[..., :cout] = drows
+                drows = padded
+            didx, dm = _gemm_rows_idx(drows.reshape(cin, -1), self.dtype)
+            d_mode = 1
+        wd = self._packed(didx)
+        self.taps[name] = y
+        if bn:
+            z = self._new(Ho, Wo, cout)
+            self._f(self._conv_op(x, z, wt, self.zeros.data_ptr(), wm, k, s, pad))
+            stats = self._bn_forward(name, z, y, cout, act, res)
+        else:
+            z, stats = None, None
+            self._f(self._conv_op(x, y, wt, st.ptr(name + ".bias"), wm, k, s, pad, act=1 if act else 0, res=res, out_f32=f32_out))
+            assert res is None and not act
+
+        def bw():
+            ops = []
+            if bn:
+                self._bn_backward(ops, name, z, y, cout, act, stats, res)
+                dz, dz_f32 = z, 0
+            else:  # plain conv + bias: dz = dy (the loss writes it, zeros in the padding channels)
+                gy = self.G(y)
+                gyw = View(gy.t, gy.N, gy.H, gy.W, cpad, gy.cs, gy.co, gy.f32)
+                acc = self._acc(cpad)
+                ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gyw.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
+                                          i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0}))
+                ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
+                if cpad != cout:
+                    ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, self.dump.data_ptr()), i={0: cpad, 1: 1}))
+                dz, dz_f32 = gyw, 1 if gy.f32 else 0
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
+                                      i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32}))
+            if dz_f32 and self.dtype != MSL_F32:  # the MFMA operand must be the compute dtype
+                dzc = self._new(Ho, Wo, dz.C)
+                ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dzc.t.data_ptr(), dz.t.data_ptr()),
+                                          i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
+                dz = dzc
+            gx = self.G(x)
+            first = self._init.first_write(gx)
+            gres = None if first else gx
+            if d_mode == 0:
+                ops.append(self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, 3, 1, 1, res=gres, cout=cin))
+            else:
+                op = self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, k, s, pad, res=gres, dgrad=1, cout=cin)
+                ops.append(op)
+            return ops
+
+        self._bw_builders.append(bw)
+        return y
+
+    def convT2x2(self, name, x, cout):
+        st = self.store
+        y = self._new(2 * x.H, 2 * x.W, cout)
+        cin = x.C
+        off = st.off(name + ".w")
+        idx = off + torch.arange(cin * 4 * cout, dtype=torch.int64).view(cin, 2, 2, cout)  # [ci][dy][dx][co]
+        fidx, fm = _gemm_rows_idx(idx.permute(1, 2, 3, 0).reshape(4 * cout, cin), self.dtype)  # rows (q,co), K = ci
+        wt = self._packed(fidx)
+        bias_idx = (st.off(name + ".bias") + torch.arange(cout, dtype=torch.int64)).repeat(4)
+        bpad = torch.full(((4 * cout + 15) // 16 * 16,), -1, dtype=torch.int64)
+        bpad[: 4 * cout] = bias_idx
+        bt = self._packed(bpad.to(torch.int32), dtype=MSL_F32)
+        didx, dm = _gemm_rows_idx(idx.reshape(cin, 4 * cout), self.dtype)  # rows ci, K = (dy,dx,co): conv k2 s2 p0 over dy
+        wd = self._packed(didx)
+        self._f(self._conv_op(x, y, wt, bt.data_ptr(), fm, 1, 1, 0, store_mode=1, cout=4 * cout))
+        self.taps[name] = y
+
+        def bw():
+            ops = []
+            gy = self.G(y)
+            acc = self._acc(cout)
+            ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gy.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
+                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co}))
+            ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
+            # dW[ci][(dy,dx,co)] = sum_p x[p][ci] * dy[(2y+dy,2x+dx)][co]: CONV_WGRAD with the operands swapped
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
+                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co}))
+            gx = self.G(x)
+            first = self._init.first_write(gx)
+            ops.append(self._conv_op(gy, gx, wd, self.zeros.data_ptr(), dm, 2, 2, 0, res=None if first else gx, cout=cin))
+            return ops
+
+        self._bw_builders.append(bw)
+        return y
+
+    def dwconv(self, name, x, act=True, res=None, gmap=None, out=None):
+        st = self.store
+        C = x.C if gmap is None else x.C // gmap[1] * gmap[0]
+        y = out if out is not None else self._new(x.H, x.W, C)
+        z = self._new(x.H, x.W, C)
+        gm = {22: gmap[0], 23: gmap[1], 24: gmap[2]} if gmap is not None else {}
+        self._f(hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(x.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), 0, z.t.data_ptr()),
+                               i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 18: 0, **gm}))
+        inplace = res is not None and out is not None and res.t is out.t and res.co == out.co
+        stats = self._bn_forward(name, z, y, C, act, res)
+        self.taps[name] = y
+
+        def bw():
+            ops = []
+            self._bn_backward(ops, name, z, y, C, act, stats, res, res_inplace=inplace)
+            ops.append(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
+                                      i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, **gm}))
+            gx = self.G(x)
+            if gmap is None:
+                first = self._init.first_write(gx)
+                i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: z.cs, 11: z.co, 12: gx.cs, 13: gx.co, 18: 0, 20: 1}
+                rp = 0
+                if not first:
+                    i[14], i[15], rp = gx.cs, gx.co, gx.t.data_ptr()
+            else:  # gradient lands in the mapped (v) channels of the qkv gradient: first writer of those channels
+                chans = torch.tensor([x.co + (c // gmap[0]) * gmap[1] + gmap[2] + c % gmap[0] for c in range(C)])
+                self._init.mark(gx, chans)
+                i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: z.cs, 11: z.co, 12: gx.cs, 13: gx.co, 18: 0, 20: 1, 21: 1, **gm}
+                rp = 0
+            ops.append(hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(z.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), rp, gx.t.data_ptr()), i=i))
+            return ops
+
+        self._bw_builders.append(bw)
+        return y
+
+    def cat_buffer(self, like, C, scale=1.0):
+        return self._new(like.H, like.W, C)
+
+    def view(self, buf, c0, c):
+        return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32)
+
+    def upsample2x(self, x, out):
+        self._f(hiplib.make_op(hiplib.OP_UPSAMPLE2X, self.dtype, p=(x.t.data_ptr(), 0, 0, 0, out.t.data_ptr()),
+                               i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: x.cs, 11: x.co, 12: out.cs, 13: out.co}))
+
+        def bw():
+            gx, go = self.G(x), self.G(out)
+            assert self._init.is_done(gx), "upsample backward expects an initialised destination gradient"
+            return [hiplib.make_op(hiplib.OP_UPSAMPLE2X_BWD, self.dtype, p=(gx.t.data_ptr(), go.t.data_ptr()),
+                                   i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: gx.cs, 11: gx.co, 12: go.cs, 13: go.co})]
+
+        self._bw_builders.append(bw)
+        return out
+
+    def sppf_pool(self, buf, c):
+        self._f(hiplib.make_op(hiplib.OP_SPPF_POOL, self.dtype, p=(buf.t.data_ptr(),), i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co}))
+        scratch = torch.zeros(self.N * buf.H * buf.W * c, dtype=torch.float32, device=self.device)
+        self._keep.append(scratch)
+
+        def bw():
+            g = self.G(buf)
+            y0 = View(g.t, g.N, g.H, g.W, c, g.cs, g.co, False)
+            assert self._init.is_done(y0)
+            return [
+                (lambda: scratch.zero_()),
+                hiplib.make_op(hiplib.OP_SPPF_POOL_BWD, self.dtype, p=(buf.t.data_ptr(), g.t.data_ptr(), 0, 0, scratch.data_ptr()),
+                               i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co, 12: g.cs, 13: g.co}),
+                hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(g.t.data_ptr(), scratch.data_ptr()),
+                               i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: g.cs, 11: g.co, 12: c, 13: 0, 19: 1, 20: 0}),
+            ]
+
+        self._bw_builders.append(bw)
+
+    def attention(self, qkv, heads, kd, hd):
+        """PSA attention core through torch (batched GEMMs + softmax), forward and backward."""
+        y = self._new(qkv.H, qkv.W, heads * hd)
+        HW, N = qkv.H * qkv.W, self.N
+        scale = kd**-0.5
+        saved = {}
+
+        def split():
+            t = qkv.torch().reshape(N, HW, heads, 2 * kd + hd).float().permute(0, 2, 1, 3)  # [N,heads,HW,128]
+            return t[..., :kd], t[..., kd : 2 * kd], t[..., 2 * kd :]
+
+        def fwd():
+            q, k, v = split()
+            p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+            saved["p"] = p
+            o = p @ v  # [N,heads,HW,hd]
+            y.torch().copy_(o.permute(0, 2, 1, 3).reshape(N, qkv.H, qkv.W, heads * hd))
+
+        self._fwd.append(fwd)
+        self._fwd.append([])
+
+        def bw():
+            def run():
+                q, k, v = split()
+                p = saved["p"]
+                do = self.G(y).torch().reshape(N, HW, heads, hd).float().permute(0, 2, 1, 3)
+                dv = p.transpose(-1, -2) @ do
+                dp = do @ v.transpose(-1, -2)
+                ds = p * (dp - (dp * p).sum(-1, keepdim=True))
+                dq = (ds @ k) * scale
+                dk = (ds.transpose(-1, -2) @ q) * scale
+                g = self.G(qkv).torch().reshape(N, HW, heads, 2 * kd + hd)
+                g[..., :kd] = dq.permute(0, 2, 1, 3)
+                g[..., kd : 2 * kd] = dk.permute(0, 2, 1, 3)
+                g[..., 2 * kd :] += dv.permute(0, 2, 1, 3)  # v slots already hold the pe gradient
+            self._init.mark(self.G(qkv))
+            return [run]
+
+        self._bw_builders.append(bw)
+        return y
+
+    def head_level(self, i, box, cls, coef):
+        self.levels[i] = (box, cls, coef)
+
+    def proto(self, p):
+        self.proto_view = p
+
+    # ------------------------------------------------------------------ assembly
+    def _finish(self):
+        # head outputs and protos receive their gradients from the loss step
+        for li in self.levels:
+            for v in self.levels[li]:
+                self._init.mark(self.G(v))
+        self._init.mark(self.G(self.proto_view))
+        bwd_segments: List = [[]]
+        for build in reversed(self._bw_builders):
+            for op in build():
+                if callable(op):
+                    bwd_segments.append(op)
+                    bwd_segments.append([])
+                else:
+                    bwd_segments[-1].append(op)
+        self.forward_segments = [hiplib.Program(s) if isinstance(s, list) and s else s for s in self._fwd if not (isinstance(s, list) and not s)]
+        self.backward_segments = [hiplib.Program(s) if isinstance(s, list) and s else s for s in bwd_segments if not (isinstance(s, list) and not s)]
+        self.pack_program = hiplib.Program(self._pack)
+        self.A = sum(v[0].H * v[0].W for v in self.levels.values())
+
+    def _run(self, segments):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        for seg in segments:
+            if isinstance(seg, hiplib.Program):
+                seg.run(s)
+            else:
+                seg()
+
+    def pack(self):
+        self.pack_program.run(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def forward(self):
+        self._run(self.forward_segments)
+
+    def backward(self):
+        """Head/proto gradient buffers must have been filled (see `head_grad_views`); weight gradients ACCUMULATE into store.g,
+        so the caller zeroes store.g once per optimizer step."""
+        self._run(self.backward_segments)
+
+    def head_outputs(self):
+        """→ dict of torch views: per level (box [N,H,W,64] f32, cls [N,H,W,nc] f32, coef [N,H,W,32] f32) and proto [N,mh,mw,32]."""
+        return {"levels": [tuple(v.torch() for v in self.levels[i]) for i in sorted(self.levels)], "proto": self.proto_view.torch()}
+
+    def head_grads(self):
+        return {"levels": [tuple(self.G(v).torch() for v in self.levels[i]) for i in sorted(self.levels)], "proto": self.G(self.proto_view).torch()}
