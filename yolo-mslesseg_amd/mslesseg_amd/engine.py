@@ -195,6 +195,12 @@ class ProgramBuilder(graph.Visitor):
                                               i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: x.cs, 11: x.co, 12: out.cs, 13: out.co}))
         return out
 
+    def copy(self, src, dst):
+        assert (src.H, src.W, src.C) == (dst.H, dst.W, dst.C)
+        self._emit("copy", hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dst.t.data_ptr(), src.t.data_ptr()),
+                                          i={0: self.N, 1: src.H, 2: src.W, 3: src.C, 10: dst.cs, 11: dst.co, 12: src.cs, 13: src.co, 20: 1}))
+        return dst
+
     def sppf_pool(self, buf, c):
         self._emit("sppf_pool", hiplib.make_op(hiplib.OP_SPPF_POOL, self.dtype, p=(buf.t.data_ptr(),),
                                                i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co}))

@@ -49,6 +49,7 @@ class Visitor:
     def cat_buffer(self, like, C, scale=1.0): ...
     def view(self, buf, c0, c): ...
     def upsample2x(self, x, out): ...
+    def copy(self, src, dst): ...
     def sppf_pool(self, buf, c): ...
     def attention(self, qkv, heads, kd, hd): ...
     def head_level(self, i, box, cls, coef): ...
@@ -98,6 +99,10 @@ def _c2psa(v, name, x, n, out=None):
     cat = v.cat_buffer(x, 2 * c)
     v.conv(f"{name}.cv1", x, 2 * c, 1, 1, out=v.view(cat, 0, 2 * c))
     b = v.view(cat, c, c)
+    # The PSA chain must not overwrite `b`: training's backward still reads it (qkv weight gradient, residuals).  The
+    # second concat buffer costs one copy of `a` (c channels at P5 resolution).
+    cat2 = v.cat_buffer(x, 2 * c)
+    v.copy(v.view(cat, 0, c), v.view(cat2, 0, c))
     heads, hd, kd = c // 64, 64, 32
     for j in range(n):
         blk = f"{name}.m.{j}"
@@ -108,8 +113,8 @@ def _c2psa(v, name, x, n, out=None):
         b1 = v.conv(f"{blk}.attn.proj", att, c, 1, 1, act=False, res=b)  # b + attn(b)
         f = v.conv(f"{blk}.ffn.0", b1, 2 * c, 1, 1)
         last = j == n - 1
-        b = v.conv(f"{blk}.ffn.1", f, c, 1, 1, act=False, res=b1, out=v.view(cat, c, c) if last else None)
-    return v.conv(f"{name}.cv2", cat, x.C, 1, 1, out=out)
+        b = v.conv(f"{blk}.ffn.1", f, c, 1, 1, act=False, res=b1, out=v.view(cat2, c, c) if last else None)
+    return v.conv(f"{name}.cv2", cat2, x.C, 1, 1, out=out)
 
 
 def walk(v: Visitor, scale: str = "n", nc: int = 1):

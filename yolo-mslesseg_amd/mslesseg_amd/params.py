@@ -61,6 +61,9 @@ class SpecVisitor(graph.Visitor):
     def upsample2x(self, x, out):
         return out
 
+    def copy(self, src, dst):
+        return dst
+
     def sppf_pool(self, buf, c):
         return None
 

@@ -512,6 +512,20 @@ class TrainPlan(graph.Visitor):
         self._bw_builders.append(bw)
         return out
 
+    def copy(self, src, dst):
+        dims = {0: self.N, 1: src.H, 2: src.W, 3: src.C}
+        self._f(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dst.t.data_ptr(), src.t.data_ptr()),
+                               i={**dims, 10: dst.cs, 11: dst.co, 12: src.cs, 13: src.co, 20: 1}))
+
+        def bw():
+            gs, gd = self.G(src), self.G(dst)
+            first = self._init.first_write(gs)
+            return [hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gs.t.data_ptr(), gd.t.data_ptr()),
+                                   i={**dims, 10: gs.cs, 11: gs.co, 12: gd.cs, 13: gd.co, 20: 1 if first else 0})]
+
+        self._bw_builders.append(bw)
+        return dst
+
     def sppf_pool(self, buf, c):
         self._f(hiplib.make_op(hiplib.OP_SPPF_POOL, self.dtype, p=(buf.t.data_ptr(),), i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co}))
         scratch = torch.zeros(self.N * buf.H * buf.W * c, dtype=torch.float32, device=self.device)
