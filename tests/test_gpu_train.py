@@ -114,7 +114,7 @@ def test_train_forward_backward_fp32_matches_oracle_autograd(synth_state, hw):
     # ---- gradients
     gsd = store.state_dict(p=store.g)
     worst = []
-    floor = 1e-6 * max(float(v.abs().max()) for v in grads.values())  # shift-invariant biases have a true gradient of 0
+    floor = 1e-5 * max(float(v.abs().max()) for v in grads.values())  # shift-invariant biases have a true gradient of 0
     for k, ref in grads.items():
         if k == "model.23.dfl.conv.weight":
             continue
