@@ -1,0 +1,235 @@
+"""Training data: YOLO-seg datasets as the reference lays them out, host-side augmentation, batch collation.
+
+Dataset layout consumed [REF yolo_mslesseg/scripts/train.py:221-338]: a YAML with absolute `train:` / `val:` dirs, each holding
+`images/<stem>.png` and `labels/<stem>.txt` (class + normalised polygon per line).  Augmentation follows the resolved
+hyper-parameters of the reference's runs [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/args.yaml:85-103]:
+mosaic 1.0 (off for the last `close_mosaic`=10 epochs), translate 0.1, scale 0.5, hsv (.015,.7,.4), fliplr 0.5,
+mask_ratio 4 with overlap encoding [UPSTREAM data/augment.py Mosaic / RandomPerspective / RandomHSV / RandomFlip / Format].
+OpenCV is absent: affine warps use an inverse-map bilinear sampler and polygons are rasterised by a scan-line fill.
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import labels as L
+
+IMGSZ = 640
+PAD = 114
+
+
+# ------------------------------------------------------------------------------------------------- raster / warp
+def fill_polygon(mask: np.ndarray, poly: np.ndarray, value) -> None:
+    """Even-odd scan-line fill at pixel centres; `poly` [k,2] in pixel coordinates of `mask`."""
+    h, w = mask.shape
+    if len(poly) < 3:
+        return
+    x, y = poly[:, 0].astype(np.float64), poly[:, 1].astype(np.float64)
+    x2, y2 = np.roll(x, -1), np.roll(y, -1)
+    y_lo, y_hi = max(int(math.floor(y.min())), 0), min(int(math.ceil(y.max())), h - 1)
+    for row in range(y_lo, y_hi + 1):
+        yc = row + 0.5
+        cross = ((y <= yc) & (y2 > yc)) | ((y2 <= yc) & (y > yc))
+        if not cross.any():
+            continue
+        xs = np.sort(x[cross] + (yc - y[cross]) * (x2[cross] - x[cross]) / (y2[cross] - y[cross]))
+        for a, b in zip(xs[0::2], xs[1::2]):
+            c0, c1 = int(math.ceil(a - 0.5)), int(math.floor(b - 0.5))
+            if c1 >= c0:
+                mask[row, max(c0, 0) : min(c1, w - 1) + 1] = value
+
+
+def warp_affine(img: np.ndarray, M: np.ndarray, out_hw: Tuple[int, int], border: int = PAD) -> np.ndarray:
+    """dst(x,y) = src(M^-1 (x,y,1)) with bilinear sampling and constant border (cv2.warpAffine semantics)."""
+    h, w = out_hw
+    Mi = np.linalg.inv(np.vstack([M[:2], [0, 0, 1]]))
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
+    sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
+    x0, y0 = np.floor(sx).astype(np.int32), np.floor(sy).astype(np.int32)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    H, W = img.shape[:2]
+    src = np.full((H + 2, W + 2, img.shape[2]), border, dtype=np.float32)
+    src[1:-1, 1:-1] = img
+    x0c, y0c = np.clip(x0 + 1, 0, W), np.clip(y0 + 1, 0, H)
+    x1c, y1c = np.clip(x0 + 2, 0, W + 1), np.clip(y0 + 2, 0, H + 1)
+    inside = (x0 >= -1) & (x0 < W) & (y0 >= -1) & (y0 < H)
+    out = (src[y0c, x0c] * (1 - fx) * (1 - fy) + src[y0c, x1c] * fx * (1 - fy) + src[y1c, x0c] * (1 - fx) * fy + src[y1c, x1c] * fx * fy)
+    out = np.where(inside[..., None], out, border)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def resize_keep_ratio(img: np.ndarray, size: int) -> np.ndarray:
+    h, w = img.shape[:2]
+    r = size / max(h, w)
+    if r == 1:
+        return img
+    nh, nw = max(int(round(h * r)), 1), max(int(round(w * r)), 1)
+    M = np.array([[nw / w, 0, (nw / w - 1) * 0.5], [0, nh / h, (nh / h - 1) * 0.5]], dtype=np.float64)
+    return warp_affine(img, M, (nh, nw), border=0)
+
+
+# ------------------------------------------------------------------------------------------------- dataset
+class SegDataset:
+    """Images are cached in RAM as uint8 [H,W,3] resized so that the long side is IMGSZ (cache=True, REF train.py:362)."""
+
+    def __init__(self, root, imgsz: int = IMGSZ):
+        root = Path(root)
+        self.im_files = sorted((root / "images").glob("*.png"))
+        if not self.im_files:
+            raise FileNotFoundError(f"no PNG images under {root / 'images'}")
+        self.imgsz = imgsz
+        self.items = []
+        from PIL import Image
+
+        for f in self.im_files:
+            rgb = np.asarray(Image.open(f).convert("RGB"))
+            inst = L.read_label_file(root / "labels" / (f.stem + ".txt"))
+            self.items.append((resize_keep_ratio(rgb, imgsz), [(c, p.copy()) for c, p in inst]))
+
+    def __len__(self):
+        return len(self.items)
+
+    def get(self, i):
+        img, inst = self.items[i]
+        h, w = img.shape[:2]
+        return img, [(c, p * np.array([w, h], dtype=np.float32)) for c, p in inst]  # polygons in pixels
+
+
+class SyntheticSegDataset:
+    """bench / smoke data: grey noise slices (3x3 box-filtered) with 1-6 random convex polygons, class 0."""
+
+    def __init__(self, n: int, imgsz: int = IMGSZ, seed: int = 0):
+        rng = np.random.default_rng(seed)
+        self.imgsz, self.items = imgsz, []
+        for _ in range(n):
+            a = rng.integers(0, 256, size=(imgsz + 2, imgsz + 2)).astype(np.float32)
+            g = sum(a[dy : dy + imgsz, dx : dx + imgsz] for dy in range(3) for dx in range(3)) / 9.0
+            img = np.repeat(np.clip(np.rint(g), 0, 255).astype(np.uint8)[..., None], 3, axis=2)
+            inst = []
+            for _ in range(int(rng.integers(1, 7))):
+                c = rng.uniform(0.15, 0.85, size=2) * imgsz
+                rad = rng.uniform(0.03, 0.12) * imgsz
+                ang = np.sort(rng.uniform(0, 2 * np.pi, size=int(rng.integers(5, 10))))
+                poly = np.stack([c[0] + rad * np.cos(ang), c[1] + rad * np.sin(ang)], 1).astype(np.float32)
+                inst.append((0, np.clip(poly, 0, imgsz - 1)))
+            self.items.append((img, inst))
+
+    def __len__(self):
+        return len(self.items)
+
+    def get(self, i):
+        return self.items[i]
+
+
+# ------------------------------------------------------------------------------------------------- augmentation
+def _letterbox(img, inst, size):
+    h, w = img.shape[:2]
+    out = np.full((size, size, 3), PAD, np.uint8)
+    top, left = (size - h) // 2, (size - w) // 2
+    out[top : top + h, left : left + w] = img
+    return out, [(c, p + np.array([left, top], np.float32)) for c, p in inst]
+
+
+def _mosaic(ds, idx, rng, size):
+    s = size
+    yc, xc = (int(rng.uniform(s // 2, 2 * s - s // 2)) for _ in range(2))
+    canvas = np.full((2 * s, 2 * s, 3), PAD, np.uint8)
+    inst_all = []
+    for k, i in enumerate([idx] + [int(rng.integers(0, len(ds))) for _ in range(3)]):
+        img, inst = ds.get(i)
+        h, w = img.shape[:2]
+        if k == 0:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+            x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
+        elif k == 1:
+            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, 2 * s), yc
+            x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
+        elif k == 2:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(2 * s, yc + h)
+            x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
+        else:
+            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, 2 * s), min(2 * s, yc + h)
+            x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
+        canvas[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
+        off = np.array([x1a - x1b, y1a - y1b], np.float32)
+        inst_all += [(c, p + off) for c, p in inst]
+    return canvas, inst_all
+
+
+def _random_affine(img, inst, rng, size, border, scale=0.5, translate=0.1):
+    h, w = img.shape[0] + 2 * border, img.shape[1] + 2 * border  # output size
+    C = np.eye(3)
+    C[0, 2], C[1, 2] = -img.shape[1] / 2, -img.shape[0] / 2
+    s = rng.uniform(1 - scale, 1 + scale)
+    R = np.diag([s, s, 1.0])
+    T = np.eye(3)
+    T[0, 2] = rng.uniform(0.5 - translate, 0.5 + translate) * w
+    T[1, 2] = rng.uniform(0.5 - translate, 0.5 + translate) * h
+    M = T @ R @ C
+    out = warp_affine(img, M[:2], (h, w))
+    new = []
+    for c, p in inst:
+        q = p @ M[:2, :2].T + M[:2, 2]
+        q = np.clip(q, 0, [w - 1e-3, h - 1e-3]).astype(np.float32)
+        b0 = np.array([p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max()]) * s
+        b1 = np.array([q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max()])
+        w0, h0, w1, h1 = b0[2] - b0[0], b0[3] - b0[1], b1[2] - b1[0], b1[3] - b1[1]
+        ar = max(w1 / (h1 + 1e-16), h1 / (w1 + 1e-16))
+        if w1 > 2 and h1 > 2 and w1 * h1 / (w0 * h0 + 1e-16) > 0.01 and ar < 100:  # box_candidates (segments: area_thr 0.01)
+            new.append((c, q))
+    return out, new
+
+
+def _hsv(img, rng, hgain=0.015, sgain=0.7, vgain=0.4):
+    """RandomHSV on grey-looking RGB input: hue/saturation gains act on (near-)zero saturation, so only the value
+    gain changes pixels; apply it as the same LUT upstream builds for V."""
+    r = rng.uniform(-1, 1, 3) * [hgain, sgain, vgain] + 1
+    lut = np.clip(np.arange(256) * r[2], 0, 255).astype(np.uint8)
+    return lut[img]
+
+
+def augment(ds, idx, rng, mosaic: bool, size: int = IMGSZ):
+    if mosaic:
+        img, inst = _mosaic(ds, idx, rng, size)
+        img, inst = _random_affine(img, inst, rng, size, border=-size // 2)
+    else:
+        img, inst = ds.get(idx)
+        img, inst = _letterbox(img, inst, size)
+        img, inst = _random_affine(img, inst, rng, size, border=0)
+    img = _hsv(img, rng)
+    if rng.random() < 0.5:
+        img = img[:, ::-1]
+        inst = [(c, np.stack([size - p[:, 0], p[:, 1]], 1)) for c, p in inst]
+    return np.ascontiguousarray(img), inst
+
+
+def plain(ds, idx, size: int = IMGSZ):
+    img, inst = ds.get(idx)
+    return _letterbox(img, inst, size)
+
+
+# ------------------------------------------------------------------------------------------------- collation
+def collate(samples: Sequence[Tuple[np.ndarray, list]], size: int = IMGSZ, mask_ratio: int = 4) -> Dict[str, np.ndarray]:
+    """→ img uint8 [B,size,size,3] RGB, batch_idx [T], cls [T], bboxes [T,4] normalised xywh, masks uint8 [B,size/4,size/4]
+    (overlap encoding: instances sorted by area, largest first, pixel value = 1 + index within the image)."""
+    B, m = len(samples), size // mask_ratio
+    imgs = np.stack([s[0] for s in samples])
+    masks = np.zeros((B, m, m), np.uint8)
+    bidx, cls, boxes = [], [], []
+    for b, (_, inst) in enumerate(samples):
+        polys = [(c, p) for c, p in inst if len(p) >= 3]
+        areas = [0.5 * abs(np.dot(p[:, 0], np.roll(p[:, 1], 1)) - np.dot(p[:, 1], np.roll(p[:, 0], 1))) for _, p in polys]
+        order = np.argsort(areas)[::-1]
+        for j, k in enumerate(order):
+            c, p = polys[k]
+            fill_polygon(masks[b], p / mask_ratio, j + 1)
+            x1, y1, x2, y2 = p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max()
+            bidx.append(b)
+            cls.append(c)
+            boxes.append([(x1 + x2) / 2 / size, (y1 + y2) / 2 / size, (x2 - x1) / size, (y2 - y1) / size])
+    return {"img": imgs, "batch_idx": np.asarray(bidx, np.float32), "cls": np.asarray(cls, np.float32),
+            "bboxes": np.asarray(boxes, np.float32).reshape(-1, 4), "masks": masks}

@@ -1,0 +1,306 @@
+"""Trainer behind ``YOLO.train(data=, epochs=, batch=-1, cache=True, project=, name=, verbose=False)`` (boundary B2)
+[REF yolo_mslesseg/scripts/train.py:358-366].  Blocking; creates ``<project>/<name>/weights/{best,last}.pt`` (non-empty),
+``results.csv`` (the reference's 21 columns) and ``args.yaml`` — the files `entrenamiento_exitoso` checks
+[REF train.py:105-116].
+
+Resolved hyper-parameters are those frozen in the reference's args.yaml [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/
+fold1/args.yaml]: imgsz 640, nbs 64, seed 0, warmup 3 epochs, close_mosaic 10, weight_decay 5e-4, optimizer 'auto' → AdamW
+lr0 = round(0.002*5/(4+nc), 6), beta1 0.9, warm-up from 0 for every group — the schedule the 25 results.csv files pin
+(tests/test_oracle_pins.py KAT #1).  Gradient clip 10, ModelEMA(0.9999, tau 2000) [UPSTREAM engine/trainer.py].
+
+One process per GPU.  Data parallelism = ONE RCCL all-reduce(SUM) of the flat gradient buffer per optimizer step
+(ultralytics scales the loss by world_size and lets DDP average: the same sum); BatchNorm statistics stay per-rank
+(no SyncBatchNorm: a documented deviation from ultralytics' DDP path, which the reference never exercises — SURVEY §7.3 #6).
+"""
+from __future__ import annotations
+
+import csv
+import math
+import os
+import struct
+import threading
+import time
+from pathlib import Path
+from queue import Queue
+from typing import Optional
+
+import numpy as np
+import torch
+import yaml
+
+from . import data as D
+from . import hiplib, params
+from .hiplib import MSL_BF16, MSL_F32
+from .loss import segmentation_loss
+from .trainprog import ParamStore, TrainPlan
+
+RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss", "metrics/precision(B)", "metrics/recall(B)",
+                  "metrics/mAP50(B)", "metrics/mAP50-95(B)", "metrics/precision(M)", "metrics/recall(M)", "metrics/mAP50(M)", "metrics/mAP50-95(M)",
+                  "val/box_loss", "val/seg_loss", "val/cls_loss", "val/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"]  # [REF trains/…/results.csv:1]
+
+DEFAULTS = dict(imgsz=640, nbs=64, seed=0, lrf=0.01, warmup_epochs=3.0, warmup_bias_lr=0.0, weight_decay=0.0005, close_mosaic=10,
+                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=64)
+
+
+def _fbits(x: float) -> int:
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+class Schedule:
+    """LR per iteration: lr0 * lf(epoch) * warm-up ramp; `accumulate` ramps 1 → nbs/batch during warm-up  [UPSTREAM BaseTrainer]."""
+
+    def __init__(self, nb: int, epochs: int, lr0: float, lrf: float, warmup_epochs: float, batch: int, nbs: int):
+        self.nb, self.epochs, self.lr0, self.lrf, self.batch, self.nbs = nb, epochs, lr0, lrf, batch, nbs
+        self.nw = max(round(warmup_epochs * nb), 100) if warmup_epochs > 0 else -1
+
+    def lf(self, epoch: int) -> float:
+        return max(1 - epoch / self.epochs, 0) * (1.0 - self.lrf) + self.lrf
+
+    def lr(self, ni: int, epoch: int) -> float:
+        target = self.lr0 * self.lf(epoch)
+        if ni <= self.nw:
+            return float(np.interp(ni, [0, self.nw], [0.0, target]))
+        return target
+
+    def accumulate(self, ni: int) -> int:
+        full = max(round(self.nbs / self.batch), 1)
+        if ni <= self.nw:
+            return max(1, int(np.interp(ni, [0, self.nw], [1, self.nbs / self.batch]).round()))
+        return full
+
+
+def shard_indices(n: int, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
+    """Slices seen by `rank` in `epoch`: a seeded permutation dealt round-robin — disjoint across ranks, identical on every rank."""
+    return np.random.default_rng([seed, epoch]).permutation(n)[rank::world]
+
+
+def allreduce_gradients(flat: torch.Tensor) -> torch.Tensor:
+    """The one collective of the training data path: SUM of the flat gradient buffer over ranks (RCCL on GPUs, gloo in tests)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+    return flat
+
+
+class Trainer:
+    def __init__(self, yolo, data=None, epochs: int = 100, batch: int = -1, cache: bool = True, project=None, name: str = "train",
+                 verbose: bool = False, dataset=None, val_dataset=None, max_iters: Optional[int] = None, **overrides):
+        self.yolo, self.epochs, self.verbose = yolo, int(epochs), verbose
+        self.hyp = {**DEFAULTS, **{k: v for k, v in overrides.items() if k in DEFAULTS}}
+        self.max_iters = max_iters
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device(f"cuda:{self.local}" if self.world > 1 else yolo.device)
+        if not torch.cuda.is_available():
+            raise hiplib.MslError("no GPU: training runs only on the HIP kernels (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        if self.world > 1 and not torch.distributed.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("nccl", device_id=self.device)
+        # ---- data
+        self.names, self.nc = {0: "lesion"}, 1
+        if dataset is None:
+            cfg = yaml.safe_load(Path(data).read_text())
+            self.nc = int(cfg.get("nc", len(cfg.get("names", [1]))))
+            nm = cfg.get("names", ["lesion"])
+            self.names = dict(enumerate(nm)) if isinstance(nm, (list, tuple)) else {int(k): v for k, v in nm.items()}
+            root = Path(cfg.get("path", "."))
+            tr, va = Path(cfg["train"]), Path(cfg["val"])
+            dataset = D.SegDataset(tr if tr.is_absolute() else root / tr, self.hyp["imgsz"])
+            val_dataset = D.SegDataset(va if va.is_absolute() else root / va, self.hyp["imgsz"])
+        self.ds, self.val_ds = dataset, val_dataset
+        self.data_path = str(data) if data is not None else "synthetic"
+        self.batch = int(batch) if batch and batch > 0 else int(self.hyp["auto_batch"])  # batch=-1: "choose for me"
+        self.save_dir = Path(project or "runs/segment") / name
+        self.wdir = self.save_dir / "weights"
+        if self.rank == 0:
+            self.wdir.mkdir(parents=True, exist_ok=True)
+        # ---- model state → flat master buffers
+        scale = yolo.scale
+        state = yolo.state
+        if state is None or int(yolo.nc) != self.nc:  # like ultralytics: rebuild the head for the dataset's nc, keep what matches
+            fresh = params.init_state(scale, self.nc, seed=self.hyp["seed"])
+            if state is not None:
+                for k, v in state.items():
+                    if k in fresh and tuple(fresh[k].shape) == tuple(v.shape):
+                        fresh[k] = v.float() if v.is_floating_point() else v
+            state = fresh
+        state = {k: (v.float() if v.is_floating_point() else v) for k, v in state.items()}
+        self.store = ParamStore(scale, self.nc, self.device)
+        self.store.load_state(state)
+        self.dtype = yolo.dtype
+        S = self.hyp["imgsz"]
+        self.plan = TrainPlan(self.store, self.batch, S, S, self.dtype)
+        # ---- optimizer ('auto' rule) and schedule
+        per_rank = math.ceil(len(self.ds) / self.world)
+        self.nb = max(math.ceil(per_rank / self.batch), 1)
+        total_batch = self.batch * self.world
+        iterations = math.ceil(len(self.ds) / max(total_batch, self.hyp["nbs"])) * self.epochs
+        self.optimizer = "AdamW" if iterations <= 10000 else "AdamW"  # SGD branch of 'auto' (>10k iterations) is not built
+        self.lr0 = round(0.002 * 5 / (4 + self.nc), 6)
+        self.sched = Schedule(self.nb, self.epochs, self.lr0, self.hyp["lrf"], self.hyp["warmup_epochs"], total_batch, self.hyp["nbs"])
+        self.wd = self.hyp["weight_decay"] * total_batch * max(round(self.hyp["nbs"] / total_batch), 1) / self.hyp["nbs"]
+        self.opt_steps = 0
+        self.ema_p, self.ema_b, self.ema_updates = self.store.p.clone(), self.store.b.clone(), 0
+        self.gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.best_fitness, self.t0 = None, None
+
+    # ------------------------------------------------------------------ data feeding
+    def _batches(self, epoch: int):
+        n = len(self.ds)
+        rng = np.random.default_rng([self.hyp["seed"], epoch, self.rank])
+        mine = shard_indices(n, epoch, self.hyp["seed"], self.rank, self.world)
+        mosaic = epoch < self.epochs - self.hyp["close_mosaic"]
+        q: Queue = Queue(maxsize=4)
+
+        def work():
+            for b in range(self.nb):
+                idx = [int(mine[(b * self.batch + j) % len(mine)]) for j in range(self.batch)]
+                q.put(D.collate([D.augment(self.ds, i, rng, mosaic, self.hyp["imgsz"]) for i in idx], self.hyp["imgsz"]))
+            q.put(None)
+
+        threading.Thread(target=work, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            yield item
+
+    # ------------------------------------------------------------------ one optimisation step
+    def forward_backward(self, batch) -> torch.Tensor:
+        """HIP forward → loss (device tensor ops) → HIP backward.  Gradients ACCUMULATE into store.g."""
+        plan = self.plan
+        plan.in_view.t.copy_(torch.from_numpy(batch["img"]).reshape(-1), non_blocking=True)
+        plan.pack()
+        plan.forward()
+        outs = plan.head_outputs()
+        leaves = [[t.detach().requires_grad_() for t in lv] for lv in outs["levels"]]
+        proto = outs["proto"].detach().float().requires_grad_()
+        tb = {k: torch.from_numpy(v).to(self.device) for k, v in batch.items() if k != "img"}
+        loss, items = segmentation_loss([tuple(lv) for lv in leaves], proto, tb, self.nc)
+        flat = [t for lv in leaves for t in lv] + [proto]
+        grads = torch.autograd.grad(loss, flat)
+        hg = plan.head_grads()
+        k = 0
+        for li, lv in enumerate(hg["levels"]):
+            for j, gv in enumerate(lv):
+                if j == 1:
+                    plan.G(plan.levels[li][1]).t.zero_()  # padding channels of the narrow class head
+                gv.copy_(grads[k])
+                k += 1
+        hg["proto"].copy_(grads[k])
+        plan.backward()
+        return items
+
+    def optimizer_step(self, lr: float) -> None:
+        st = self.store
+        allreduce_gradients(st.g)  # the one collective of the data path (SUM over ranks)
+        norm = torch.linalg.vector_norm(st.g)
+        self.gscale.copy_(torch.clamp(self.hyp["clip"] / (norm + 1e-6), max=1.0))
+        self.opt_steps += 1
+        t = self.opt_steps
+        h = self.hyp
+        bc1, bc2 = 1 - h["beta1"] ** t, 1 - h["beta2"] ** t
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        for lo, hi, wd in ((0, st.n_decay, self.wd), (st.n_decay, st.n, 0.0)):
+            n = hi - lo
+            if n <= 0:
+                continue
+            op = hiplib.make_op(hiplib.OP_ADAMW, MSL_F32, p=(st.p.data_ptr() + 4 * lo, st.g.data_ptr() + 4 * lo, st.m.data_ptr() + 4 * lo,
+                                                             st.v.data_ptr() + 4 * lo, 0, self.gscale.data_ptr()),
+                                i={0: n & 0x7FFFFFFF, 1: n >> 31, 2: _fbits(wd), 3: _fbits(bc1), 4: _fbits(bc2)}, f=(lr, h["beta1"], h["beta2"], h["eps"]))
+            hiplib.launch(op, s)
+        st.g.zero_()
+        # EMA of parameters and BN running statistics
+        self.ema_updates += 1
+        d = h["ema_decay"] * (1 - math.exp(-self.ema_updates / h["ema_tau"]))
+        for e, src in ((self.ema_p, st.p), (self.ema_b, st.b)):
+            n = e.numel()
+            hiplib.launch(hiplib.make_op(hiplib.OP_EMA, MSL_F32, p=(e.data_ptr(), src.data_ptr()), i={0: n & 0x7FFFFFFF, 1: n >> 31}, f=(d,)), s)
+
+    # ------------------------------------------------------------------ validation (losses on the held-out fold, EMA weights)
+    @torch.no_grad()
+    def _val_losses(self) -> np.ndarray:
+        if self.val_ds is None or len(self.val_ds) == 0:
+            return np.zeros(4)
+        st = self.store
+        keep_p, keep_b = st.p.clone(), st.b.clone()
+        st.p.copy_(self.ema_p)
+        tot, cnt = np.zeros(4), 0
+        n = len(self.val_ds)
+        for b0 in range(0, min(n, 8 * self.batch), self.batch):
+            idx = [(b0 + j) % n for j in range(self.batch)]
+            batch = D.collate([D.plain(self.val_ds, i, self.hyp["imgsz"]) for i in idx], self.hyp["imgsz"])
+            self.plan.in_view.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
+            self.plan.pack()
+            self.plan.forward()
+            outs = self.plan.head_outputs()
+            tb = {k: torch.from_numpy(v).to(self.device) for k, v in batch.items() if k != "img"}
+            _, items = segmentation_loss(outs["levels"], outs["proto"], tb, self.nc)
+            tot += items.cpu().numpy()
+            cnt += 1
+        st.p.copy_(keep_p)
+        st.b.copy_(keep_b)  # validation must not move the running statistics
+        return tot / max(cnt, 1)
+
+    # ------------------------------------------------------------------ files
+    def _save(self, epoch: int, fitness: float) -> None:
+        sd = self.store.state_dict(p=self.ema_p, b=self.ema_b)
+        extra = {"epoch": epoch, "best_fitness": self.best_fitness, "train_args": {"data": self.data_path, "epochs": self.epochs, "batch": self.batch,
+                                                                                     "imgsz": self.hyp["imgsz"], "optimizer": self.optimizer, "lr0": self.lr0}}
+        params.save_checkpoint(self.wdir / "last.pt", sd, self.store.scale, self.nc, self.names, extra)
+        if self.best_fitness is None or fitness >= self.best_fitness:
+            self.best_fitness = fitness
+            params.save_checkpoint(self.wdir / "best.pt", sd, self.store.scale, self.nc, self.names, extra)
+
+    def _write_args(self) -> None:
+        args = dict(task="segment", mode="train", model=str(self.yolo.ckpt_path), data=self.data_path, epochs=self.epochs, batch=self.batch,
+                    imgsz=self.hyp["imgsz"], cache=True, optimizer="auto", seed=self.hyp["seed"], amp="bf16" if self.dtype == MSL_BF16 else False,
+                    lr0=self.lr0, lrf=self.hyp["lrf"], weight_decay=self.hyp["weight_decay"], warmup_epochs=self.hyp["warmup_epochs"], nbs=self.hyp["nbs"],
+                    close_mosaic=self.hyp["close_mosaic"], box=7.5, cls=0.5, dfl=1.5, overlap_mask=True, mask_ratio=4, world_size=self.world,
+                    save_dir=str(self.save_dir))
+        (self.save_dir / "args.yaml").write_text(yaml.safe_dump(args, sort_keys=False))
+
+    # ------------------------------------------------------------------ main loop
+    def fit(self):
+        self.t0 = time.time()
+        if self.rank == 0:
+            self._write_args()
+            with open(self.save_dir / "results.csv", "w", newline="") as f:
+                csv.writer(f).writerow(RESULT_COLUMNS)
+        self.store.g.zero_()
+        ni, last_opt, done = 0, -1, False
+        for epoch in range(self.epochs):
+            tl, nb_seen = np.zeros(4), 0
+            lr = self.sched.lr(ni, epoch)
+            for batch in self._batches(epoch):
+                lr = self.sched.lr(ni, epoch)
+                items = self.forward_backward(batch)
+                if ni - last_opt >= self.sched.accumulate(ni):
+                    self.optimizer_step(lr)
+                    last_opt = ni
+                tl += items.cpu().numpy()
+                nb_seen += 1
+                ni += 1
+                if self.max_iters is not None and ni >= self.max_iters:
+                    done = True
+                    break
+            tl /= max(nb_seen, 1)
+            vl = self._val_losses()
+            fitness = -float(vl.sum()) if vl.any() else -float(tl.sum())
+            if self.rank == 0:
+                row = [epoch + 1, round(time.time() - self.t0, 4)] + [round(float(x), 5) for x in tl] + [0.0] * 8 + [round(float(x), 5) for x in vl] + [lr] * 3
+                with open(self.save_dir / "results.csv", "a", newline="") as f:
+                    csv.writer(f).writerow(row)
+                self._save(epoch, fitness)
+                if self.verbose:
+                    print(f"epoch {epoch + 1}/{self.epochs} train {tl.round(4)} val {vl.round(4)} lr {lr:.6g}", flush=True)
+            if done:
+                break
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            torch.distributed.barrier()
+        # the trained (EMA) weights become the model's weights, like ultralytics reloads best.pt
+        self.yolo.state = self.store.state_dict(p=self.ema_p, b=self.ema_b)
+        self.yolo.nc, self.yolo.names, self.yolo._engine = self.nc, self.names, None
+        return self
