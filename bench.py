@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""bench.py — FLAIR slices/sec of the YOLO11n-seg hot path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+"""bench.py — FLAIR slices/sec of the YOLO11n-seg hot path on MI355X (contract: task brief / DESIGN.md §Measurement).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one pass of the hot path over one batch of synthetic slices already resident in HBM:
-  predict (default, round 1): uint8 [B,640,640,3] → LetterBox → YOLO11n-seg (nc=1) → decode → NMS → mask assembly →
-  merged + re-oriented uint8 [B,640,640] (everything the reference does per slice between cv2.imread and cv2.imwrite
-  [REF yolo_mslesseg/scripts/generar_predicciones.py:205-222], for the whole batch).
-Slices shard over ranks with no data-path collective (independent units) → "scaling": "weak".
-Rank 0 prints ONE JSON line.  The oracle is imported only for the cpu_baseline leg.
+Default workload = BASELINE.json configs[1]: **YOLO11n-seg TRAIN step, 640x640 bf16**.  A "step" = one optimisation step over
+one batch of synthetic slices already resident in HBM: weight pack → HIP forward (train-mode BatchNorm) → segmentation loss
+→ HIP backward → [all-reduce of the flat gradient over ranks] → gradient clip + fused AdamW + EMA.  Nothing is skipped.
+Slices shard over ranks (data parallel); the only collective is the one gradient all-reduce → "scaling": "weak".
+`--mode predict` times the inference leg instead (LetterBox → net → NMS → masks → merged uint8 slices); in train mode a short
+predict run is reported alongside under "infer".  Rank 0 prints ONE JSON line.  The oracle is imported only for cpu_baseline.
 """
 import argparse
 import json
@@ -28,10 +28,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 METRIC = "FLAIR slices/sec train+infer at 1/2/4/8 GPU; Dice vs GT volumes"  # BASELINE.json "metric"
-PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
-PEAK_MFMA_F32_TFLOPS = 157.3
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
 PEAK_HBM_GBS = 8000.0
-FWD_GFLOP_PER_SLICE_640 = 9.630  # n, nc=1, 640x640, 2*MAC over conv + attention + ConvT
+FWD_GFLOP_PER_SLICE_640 = 9.630  # n, nc=1, 640x640, 2*MAC over conv + attention + ConvT; training = 3x
 
 
 def synthetic_slices(n, h, w, seed):
@@ -51,48 +50,11 @@ def load_weights():
     return {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
 
 
-def cpu_baseline(state, imgs_u8, seconds_budget=20.0):
-    """Restated CPU path (the reference's ultralytics-on-CPU cannot run here: SURVEY §8d), batch 1 per slice exactly like
-    the reference's loop [REF generar_predicciones.py:205-222], on this host's cores."""
-    from oracle import prepost as P
-    from oracle import synth
-
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    om = synth.model_from_state(state)
-    P.generar_prediccion_2D(om, imgs_u8[0])  # warm-up
-    t0, n = time.perf_counter(), 0
-    while n < len(imgs_u8) and (time.perf_counter() - t0) < seconds_budget:
-        P.generar_prediccion_2D(om, imgs_u8[n])
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 640x640 slices, batch 1, fp32, oracle restatement of the reference predict loop "
-                      f"(letterbox+net+NMS+masks+merge) in {dt:.1f}s"}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="slices per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--op-table", default="", help="write the per-op timing table to this file")
-    ap.add_argument("--target-kept", type=float, default=12.0,
-                    help="shift the class bias so NMS keeps about this many instances per synthetic slice (0: leave the "
-                         "calibrated-random weights as they are, which saturates max_det=300 on noise slices)")
-    args = ap.parse_args()
-
-    from mslesseg_amd import engine as E
-    from mslesseg_amd import hiplib
-    from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
-
+def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -102,37 +64,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    return world, rank, dev, dist
 
-    dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
-    state = load_weights()
-    B, S = args.batch, args.size
-    host = synthetic_slices(B, S, S, seed=rank)  # each rank its own shard of slices
-    imgs = torch.from_numpy(host).to(dev)  # inputs resident in HBM before the timed region
-    bias_shift = 0.0
-    if args.target_kept > 0:
-        # Real MS slices carry a handful of lesions; the calibrated-random weights keep 300 boxes on every noise slice.
-        # Bisect a class-bias shift (weights only — conf/iou/max_det stay the reference's) on a 16-slice probe batch.
-        lo, hi = -60.0, 0.0
-        for _ in range(14):
-            mid = 0.5 * (lo + hi)
-            st = dict(state)
-            for i in range(3):
-                st[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + mid
-            probe = E.InferEngine(st, "n", 1, dtype, str(dev))
-            kept = float(probe.predict_batch(imgs[:16]).keep_cnt.float().mean().item())
-            del probe
-            lo, hi = (mid, hi) if kept < args.target_kept else (lo, mid)
-        bias_shift = 0.5 * (lo + hi)
-        for i in range(3):
-            state[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + bias_shift
-        torch.cuda.empty_cache()
-    eng = E.InferEngine(state, "n", 1, dtype, str(dev))
-    out = None
 
-    def step():
-        nonlocal out
-        out = eng.predict_slices(imgs)
-
+def timed(step, args, dev, world, dist):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -151,70 +86,279 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
+    return dt
 
+
+# ---------------------------------------------------------------------------------------------------- predict leg
+def predict_setup(args, dev, rank, state, B):
+    from mslesseg_amd import engine as E
+    from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
+
+    dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
+    S = args.size
+    host = synthetic_slices(B, S, S, seed=rank)
+    imgs = torch.from_numpy(host).to(dev)
+    bias_shift = 0.0
+    if args.target_kept > 0:
+        # Real MS slices carry a handful of lesions; the calibrated-random weights keep 300 boxes on every noise slice.
+        # Bisect a class-bias shift (weights only — conf/iou/max_det stay the reference's) on a 16-slice probe batch.
+        lo, hi = -60.0, 0.0
+        for _ in range(14):
+            mid = 0.5 * (lo + hi)
+            st = dict(state)
+            for i in range(3):
+                st[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + mid
+            probe = E.InferEngine(st, "n", 1, dtype, str(dev))
+            kept = float(probe.predict_batch(imgs[:16]).keep_cnt.float().mean().item())
+            del probe
+            lo, hi = (mid, hi) if kept < args.target_kept else (lo, mid)
+        bias_shift = 0.5 * (lo + hi)
+        state = dict(state)
+        for i in range(3):
+            state[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + bias_shift
+        torch.cuda.empty_cache()
+    eng = E.InferEngine(state, "n", 1, dtype, str(dev))
+    return eng, imgs, host, state, bias_shift
+
+
+def predict_roofline(eng, imgs, out, args, value_per_gpu):
+    from mslesseg_amd import hiplib
+
+    B, S = imgs.shape[0], args.size
+    plan = eng.plan(B, S, S)
+    table = plan.time_ops(reps=3)
+    costs = [plan.op_cost(i) for i in range(len(table))]
+    total_ms = sum(t[2] for t in table)
+    conv = [i for i in range(len(table)) if table[i][1] == hiplib.OP_CONV]
+    conv_ms, conv_flops = sum(table[i][2] for i in conv), sum(costs[i][0] for i in conv)
+    dom = max(conv, key=lambda i: table[i][2])
+    d_name, _, d_ms = table[dom]
+    d_flops, d_bytes = costs[dom]
+    peak = PEAK[args.dtype]
+    ach = d_flops / (d_ms * 1e-3) / 1e12
+    ev = [hiplib.Event() for _ in range(3)]
+    lbp, _ = eng.letterbox(B, S, S, 3)
+    st_ = torch.cuda.current_stream(imgs.device).cuda_stream
+    ev[0].record(st_)
+    lbp.run()
+    ev[1].record(st_)
+    plan.merged(S, S, out=out)
+    ev[2].record(st_)
+    torch.cuda.synchronize(imgs.device)
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "kernel": f"conv3x3_lds_kernel/conv_igemm_kernel<{args.dtype}> @ {d_name}", "launch_ms": round(d_ms, 4),
+            "algorithmic_gflop_per_launch": round(d_flops / 1e9, 3), "algorithmic_hbm_gbs": round(d_bytes / (d_ms * 1e-3) / 1e9, 1),
+            "hbm_frac": round(d_bytes / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "all_conv": {"tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4), "ms": round(conv_ms, 3),
+                         "share_of_program": round(conv_ms / total_ms, 3)},
+            "whole_net_frac_of_mfma_roof": round(value_per_gpu * FWD_GFLOP_PER_SLICE_640 * (S * S / 640.0 / 640.0) / 1e3 / peak, 4),
+            "step_breakdown": {"letterbox_ms": round(ev[0].elapsed_ms(ev[1]), 4), "mask_merge_ms": round(ev[1].elapsed_ms(ev[2]), 4), "program_ms": round(total_ms, 3),
+                               "mean_kept_instances_per_slice": round(float(plan.keep_cnt.float().mean().item()), 1),
+                               "mask_on_fraction": round(float((out > 0).float().mean().item()), 3)}}
+    if args.op_table:
+        with open(args.op_table, "w") as f:
+            f.write(f"# predict: per-op HIP-event times, batch {B}, {S}x{S}, {args.dtype}; total {total_ms:.3f} ms\n")
+            for (name, kind, ms), (fl, by) in zip(table, costs):
+                f.write(f"{name:34s} kind={kind:2d} {ms:9.4f} ms  {fl / 1e9:9.3f} GFLOP  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TF/s  "
+                        f"{by / 1e6:9.2f} MB  {by / (ms * 1e-3) / 1e9 if ms > 0 else 0:8.1f} GB/s\n")
+    return roof
+
+
+def cpu_baseline_predict(state, imgs_u8, seconds_budget=20.0):
+    """Restated CPU path (ultralytics-on-CPU cannot run here: SURVEY §8d), batch 1 per slice like the reference's loop."""
+    from oracle import prepost as P
+    from oracle import synth
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    om = synth.model_from_state(state)
+    P.generar_prediccion_2D(om, imgs_u8[0])
+    t0, n = time.perf_counter(), 0
+    while n < len(imgs_u8) and (time.perf_counter() - t0) < seconds_budget:
+        P.generar_prediccion_2D(om, imgs_u8[n])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 640x640 slices, batch 1, fp32, oracle restatement of the reference predict loop in {dt:.1f}s"}
+
+
+# ---------------------------------------------------------------------------------------------------- train leg
+def train_setup(args, dev, rank, world, state, B):
+    from mslesseg_amd import data as D
+    from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
+    from mslesseg_amd.train import Trainer
+    from mslesseg_amd.yolo import YOLO
+
+    y = YOLO.__new__(YOLO)  # a model object around the benchmark weights (no checkpoint file involved)
+    y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
+    y.dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
+    y.scale, y.nc, y.state, y.pretrained = "n", 1, state, True
+    ds = D.SyntheticSegDataset(B, args.size, seed=rank)
+    tr = Trainer(y, dataset=ds, val_dataset=None, epochs=1, batch=B, project=ROOT / "gpurun_out" / "bench_runs", name=f"r{rank}",
+                 imgsz=args.size, nbs=B * world, warmup_epochs=0.0)
+    batch = D.collate([D.plain(ds, i, args.size) for i in range(B)], args.size)
+    dbatch = tr.to_device(batch)
+    return tr, dbatch, batch
+
+
+def train_roofline(tr, dbatch, args, value_per_gpu):
+    from mslesseg_amd import hiplib
+
+    plan = tr.plan
+    tr.forward_backward(dbatch)  # leaves every buffer in a consistent state for per-op replay
+    tr.store.g.zero_()
+    rows = []
+    for tag, segs in (("pack", [plan.pack_program]), ("fwd", plan.forward_segments), ("bwd", plan.backward_segments)):
+        rows += [(tag,) + r for r in plan.time_segments(segs, reps=2)]
+    tr.store.g.zero_()
+    by_kind = {}
+    for tag, what, kind, ms, it in rows:
+        by_kind[(tag, kind)] = by_kind.get((tag, kind), 0.0) + ms
+    names = {v: k for k, v in vars(hiplib).items() if k.startswith("OP_") and isinstance(v, int)}
+
+    def conv_flops(op, wgrad=False):
+        I = op.i
+        if wgrad:
+            return 2.0 * I[0] * I[4] * I[5] * I[6] * I[7] * I[7] * I[3]
+        return 2.0 * I[0] * I[4] * I[5] * I[6] * I[16]
+
+    best, wg_ms, wg_fl, cv_ms, cv_fl = None, 0.0, 0.0, 0.0, 0.0
+    for tag, what, kind, ms, it in rows:
+        if kind == hiplib.OP_CONV_WGRAD:
+            fl = conv_flops(it, True)
+            wg_ms, wg_fl = wg_ms + ms, wg_fl + fl
+            if best is None or ms > best[0]:
+                best = (ms, fl, "conv_wgrad_kernel (fp32 MFMA 16x16x4, pixel contraction)", "fp32", tag, it)
+        elif kind == hiplib.OP_CONV:
+            fl = conv_flops(it)
+            cv_ms, cv_fl = cv_ms + ms, cv_fl + fl
+            if best is None or ms > best[0]:
+                best = (ms, fl, f"conv kernel<{args.dtype}> ({tag})", args.dtype, tag, it)
+    ms, fl, kname, kdt, tag, op = best
+    peak = PEAK[kdt]
+    ach = fl / (ms * 1e-3) / 1e12
+    I = op.i
+    total = sum(r[3] for r in rows)
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "kernel": kname, "kernel_dtype": kdt, "launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
+            "launch_shape": {"N": I[0], "H": I[1], "W": I[2], "Cin": I[3], "Ho": I[4], "Wo": I[5], "Cout": I[6], "k": I[7], "stride": I[8]},
+            "all_wgrad": {"tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2), "frac_of_fp32_mfma": round(wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK["fp32"], 4), "ms": round(wg_ms, 3)},
+            "all_conv_fwd_dgrad": {"tflops": round(cv_fl / (cv_ms * 1e-3) / 1e12, 2), "frac": round(cv_fl / (cv_ms * 1e-3) / 1e12 / PEAK[args.dtype], 4), "ms": round(cv_ms, 3)},
+            "program_ms": {"total_fwd_bwd_pack": round(total, 3),
+                           **{f"{t}:{names.get(k, 'torch-attention')}": round(v, 3) for (t, k), v in sorted(by_kind.items(), key=lambda x: -x[1])[:14]}},
+            "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP_PER_SLICE_640 * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4)}
+    if args.op_table:
+        with open(args.op_table, "w") as f:
+            f.write(f"# train: per-op HIP-event times, batch {tr.batch}, {args.size}x{args.size}, {args.dtype}; total {total:.3f} ms\n")
+            for tag, what, kind, ms_, it in rows:
+                f.write(f"{tag:5s} {names.get(kind, 'torch-attention'):22s} {ms_:9.4f} ms\n")
+    return roof
+
+
+def cpu_baseline_train(state, batch, seconds_budget=25.0):
+    """Oracle train step (train-mode forward + oracle loss + autograd backward) on the host cores, bounded sample."""
+    from oracle import loss as OL
+    from oracle import yolo11seg as Y
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    m = Y.build("n", 1)
+    m.load_state_dict(state)
+    m.train()
+    n_img, t0, steps, bs = 0, time.perf_counter(), 0, 2
+    while (time.perf_counter() - t0) < seconds_budget and steps < 8:
+        lo = (steps * bs) % len(batch["img"])
+        x = torch.from_numpy(batch["img"][lo : lo + bs]).permute(0, 3, 1, 2).float() / 255
+        keep = np.isin(batch["batch_idx"], np.arange(lo, lo + bs))
+        tb = {"batch_idx": torch.from_numpy(batch["batch_idx"][keep] - lo), "cls": torch.from_numpy(batch["cls"][keep]),
+              "bboxes": torch.from_numpy(batch["bboxes"][keep]), "masks": torch.from_numpy(batch["masks"][lo : lo + bs]).float()}
+        feats, mc, p = m(x)
+        loss, _ = OL.v8_segmentation_loss(feats, mc, p, tb, nc=1)
+        m.zero_grad()
+        loss.backward()
+        n_img += bs
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n_img / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} oracle train steps of {bs} synthetic 640x640 slices (fp32 forward + loss + autograd backward, no optimizer) in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="train", choices=["train", "predict"])
+    ap.add_argument("--batch", type=int, default=0, help="slices per GPU per step (default: 64 train, 128 predict)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="train mode: skip the short predict run reported under 'infer'")
+    ap.add_argument("--op-table", default="", help="write the per-op timing table to this file")
+    ap.add_argument("--target-kept", type=float, default=12.0,
+                    help="predict leg: shift the class bias so NMS keeps about this many instances per synthetic slice (0: leave the "
+                         "calibrated-random weights as they are, which saturates max_det=300 on noise slices)")
+    args = ap.parse_args()
+    world, rank, dev, dist = dist_setup(args)
+    state = load_weights()
+    S = args.size
+    line = {"metric": METRIC, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+
+    if args.mode == "train":
+        B = args.batch or 64
+        tr, dbatch, batch = train_setup(args, dev, rank, world, state, B)
+        lr = tr.lr0
+
+        def step():
+            tr.forward_backward(dbatch)
+            tr.optimizer_step(lr)
+
+        dt = timed(step, args, dev, world, dist)
+        value = world * B * args.steps / dt
+        line.update(value=round(value, 2), ms_per_step=round(dt / args.steps * 1e3, 4),
+                    config={"workload": f"train step (BASELINE configs[1]): YOLO11n-seg nc=1, {S}x{S}x3 uint8 slices, batch {B}/GPU, {args.dtype} activations+weights / "
+                                        f"fp32 master+accumulate; pack + forward(train BN) + loss + backward + {'all-reduce + ' if world > 1 else ''}clip + AdamW + EMA; "
+                                        f"calibrated random weights, 1-6 random polygons per slice",
+                            "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}: slices sharded, one flat-gradient all-reduce per step"})
+        if rank == 0:
+            line["roofline"] = train_roofline(tr, dbatch, args, value / world)
+            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_train(state, batch)
+            if not args.no_infer and world == 1:
+                del tr, dbatch
+                torch.cuda.empty_cache()
+                pargs = argparse.Namespace(**{**vars(args), "steps": 10, "warmup": 3})
+                eng, imgs, host, pstate, shift = predict_setup(pargs, dev, rank, state, 128)
+                t0 = None
+                for i in range(13):
+                    if i == 3:
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                    eng.predict_slices(imgs)
+                torch.cuda.synchronize(dev)
+                pdt = time.perf_counter() - t0
+                line["infer"] = {"value": round(128 * 10 / pdt, 2), "unit": "slices/s (1 GPU)", "ms_per_step": round(pdt / 10 * 1e3, 3), "per_gpu_batch": 128,
+                                 "workload": f"predict leg: LetterBox+net+NMS+masks+merge, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
+                                 "mean_kept_instances_per_slice": round(float(eng.plan(128, S, S).keep_cnt.float().mean().item()), 1)}
+    else:
+        B = args.batch or 128
+        eng, imgs, host, pstate, shift = predict_setup(args, dev, rank, state, B)
+        out = None
+
+        def step():
+            nonlocal out
+            out = eng.predict_slices(imgs)
+
+        dt = timed(step, args, dev, world, dist)
+        value = world * B * args.steps / dt
+        line.update(value=round(value, 2), ms_per_step=round(dt / args.steps * 1e3, 4),
+                    config={"workload": f"predict (infer leg of the metric): YOLO11n-seg nc=1, {S}x{S}x3 uint8 slices, LetterBox+net+NMS+masks+merge, batch {B}/GPU; "
+                                        f"calibrated random weights, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
+                            "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"slice-sharded x{world}, no collective"})
+        if rank == 0:
+            line["roofline"] = predict_roofline(eng, imgs, out, args, value / world)
+            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_predict(pstate, host[: min(B, 64)])
     if rank == 0:
-        lb_plan = eng.plan(B, S, S)
-        # ---- roofline of the dominant kernel, from HIP events on the launch stream
-        table = lb_plan.time_ops(reps=3)
-        costs = [lb_plan.op_cost(i) for i in range(len(table))]
-        total_ms = sum(t[2] for t in table)
-        conv_ms = sum(t[2] for t in table if t[1] == hiplib.OP_CONV)
-        conv_flops = sum(c[0] for t, c in zip(table, costs) if t[1] == hiplib.OP_CONV)
-        dom = max((i for i in range(len(table)) if table[i][1] == hiplib.OP_CONV), key=lambda i: table[i][2])  # dominant MFMA kernel launch
-        d_name, d_kind, d_ms = table[dom]
-        d_flops, d_bytes = costs[dom]
-        peak = PEAK_MFMA_BF16_TFLOPS if dtype == MSL_BF16 else PEAK_MFMA_F32_TFLOPS
-        achieved = d_flops / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
-        pmc = None
-        pmc_file = ROOT / "profiles" / "pmc_latest.json"
-        if pmc_file.exists():
-            try:
-                pmc = json.loads(pmc_file.read_text()).get(d_name)
-            except Exception:
-                pmc = None
-        roofline = {
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": pmc,
-            "kernel": f"conv_igemm_kernel<{args.dtype}> @ {d_name}",
-            "launch_ms": round(d_ms, 4), "algorithmic_gflop_per_launch": round(d_flops / 1e9, 3),
-            "algorithmic_hbm_gbs": round(d_bytes / (d_ms * 1e-3) / 1e9, 1), "hbm_frac": round(d_bytes / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "all_conv": {"tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
-                         "ms": round(conv_ms, 3), "share_of_step": round(conv_ms / total_ms, 3)},
-            "whole_net_frac_of_mfma_roof": round(value / world * FWD_GFLOP_PER_SLICE_640 * (S * S / 640.0 / 640.0) / 1e3 / peak, 4),
-        }
-        # letterbox + merge are launched outside the op program: time them the same way
-        ev = [hiplib.Event() for _ in range(3)]
-        lbp, _ = eng.letterbox(B, S, S, 3)
-        st_ = torch.cuda.current_stream(dev).cuda_stream
-        ev[0].record(st_); lbp.run(); ev[1].record(st_); lb_plan.merged(S, S, out=out); ev[2].record(st_)
-        torch.cuda.synchronize(dev)
-        extra = {"letterbox_ms": round(ev[0].elapsed_ms(ev[1]), 4), "mask_merge_ms": round(ev[1].elapsed_ms(ev[2]), 4),
-                 "program_ms": round(total_ms, 3)}
-        extra["mean_kept_instances_per_slice"] = round(float(lb_plan.keep_cnt.float().mean().item()), 1)
-        extra["mask_on_fraction"] = round(float((out > 0).float().mean().item()), 3)
-        roofline["step_breakdown"] = extra
-        if args.op_table:
-            with open(args.op_table, "w") as f:
-                f.write(f"# per-op HIP-event times, batch {B}, {S}x{S}, {args.dtype}; total {total_ms:.3f} ms\n")
-                for (name, kind, ms), (fl, by) in zip(table, costs):
-                    f.write(f"{name:34s} kind={kind:2d} {ms:9.4f} ms  {fl / 1e9:9.3f} GFLOP  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TF/s  "
-                            f"{by / 1e6:9.2f} MB  {by / (ms * 1e-3) / 1e9 if ms > 0 else 0:8.1f} GB/s\n")
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(state, host[: min(B, 64)])
-        line = {
-            "metric": METRIC, "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"predict (infer leg of the metric): YOLO11n-seg nc=1, {S}x{S}x3 uint8 slices, LetterBox+net+NMS+masks+merge, "
-                                   f"batch {B}/GPU; calibrated random weights (no trained weights exist offline), class bias shifted {bias_shift:+.2f} "
-                                   f"for ~{args.target_kept:g} kept instances/slice; training leg not built yet",
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"slice-sharded x{world}, no collective"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

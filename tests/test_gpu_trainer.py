@@ -15,18 +15,19 @@ from mslesseg_amd import data as D  # noqa: E402
 def test_train_synthetic_losses_decrease_and_files_exist(tmp_path, precision):
     from ultralytics import YOLO
 
-    ds = D.SyntheticSegDataset(48, 128, seed=0)
+    ds = D.SyntheticSegDataset(16, 128, seed=0)
     val = D.SyntheticSegDataset(16, 128, seed=1)
     model = YOLO("yolo11n-seg.pt", precision=precision)  # no such file: seeded random init, nothing is downloaded
-    model.train(data=None, dataset=ds, val_dataset=val, epochs=6, batch=8, project=tmp_path / "trains", name="fold1", verbose=False,
-                imgsz=128, warmup_epochs=1.0, close_mosaic=2)
+    # 2 fixed batches (augmentation off, no warm-up) for 12 epochs: the optimiser must be able to fit them
+    model.train(data=None, dataset=ds, val_dataset=val, epochs=12, batch=8, project=tmp_path / "trains", name="fold1", verbose=False,
+                imgsz=128, warmup_epochs=0.0, close_mosaic=0, augment=False, nbs=8)
     run = tmp_path / "trains" / "fold1"
     for f in ("weights/best.pt", "weights/last.pt", "results.csv", "args.yaml"):  # entrenamiento_exitoso [REF train.py:105-116]
         assert (run / f).exists() and (run / f).stat().st_size > 0, f
     rows = list(csv.DictReader(open(run / "results.csv")))
-    assert len(rows) == 6 and len(rows[0]) == 21
+    assert len(rows) == 12 and len(rows[0]) == 21
     tot = [sum(float(r[k]) for k in ("train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss")) for r in rows]
-    assert all(np.isfinite(tot)) and tot[-1] < 0.85 * tot[0], tot
+    assert all(np.isfinite(tot)) and tot[-1] < 0.75 * tot[0], tot
     assert float(rows[-1]["val/cls_loss"]) > 0 and float(rows[1]["lr/pg0"]) > 0
     # reload what was written, at the path convention the reference uses, and predict with it
     m2 = YOLO(run / "weights" / "best.pt", precision=precision)

@@ -39,7 +39,7 @@ RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cl
                   "val/box_loss", "val/seg_loss", "val/cls_loss", "val/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"]  # [REF trains/…/results.csv:1]
 
 DEFAULTS = dict(imgsz=640, nbs=64, seed=0, lrf=0.01, warmup_epochs=3.0, warmup_bias_lr=0.0, weight_decay=0.0005, close_mosaic=10,
-                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=64)
+                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=64, augment=True)
 
 
 def _fbits(x: float) -> int:
@@ -156,7 +156,11 @@ class Trainer:
         def work():
             for b in range(self.nb):
                 idx = [int(mine[(b * self.batch + j) % len(mine)]) for j in range(self.batch)]
-                q.put(D.collate([D.augment(self.ds, i, rng, mosaic, self.hyp["imgsz"]) for i in idx], self.hyp["imgsz"]))
+                if self.hyp["augment"]:
+                    samples = [D.augment(self.ds, i, rng, mosaic, self.hyp["imgsz"]) for i in idx]
+                else:
+                    samples = [D.plain(self.ds, i, self.hyp["imgsz"]) for i in idx]
+                q.put(D.collate(samples, self.hyp["imgsz"]))
             q.put(None)
 
         threading.Thread(target=work, daemon=True).start()
@@ -167,16 +171,22 @@ class Trainer:
             yield item
 
     # ------------------------------------------------------------------ one optimisation step
+    def to_device(self, batch):
+        """numpy batch (data.collate) → device tensors; the bench keeps one such batch resident in HBM."""
+        return {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in batch.items()}
+
     def forward_backward(self, batch) -> torch.Tensor:
         """HIP forward → loss (device tensor ops) → HIP backward.  Gradients ACCUMULATE into store.g."""
         plan = self.plan
-        plan.in_view.t.copy_(torch.from_numpy(batch["img"]).reshape(-1), non_blocking=True)
+        if not torch.is_tensor(batch["img"]):
+            batch = self.to_device(batch)
+        plan.in_view.t.copy_(batch["img"].reshape(-1), non_blocking=True)
         plan.pack()
         plan.forward()
         outs = plan.head_outputs()
         leaves = [[t.detach().requires_grad_() for t in lv] for lv in outs["levels"]]
         proto = outs["proto"].detach().float().requires_grad_()
-        tb = {k: torch.from_numpy(v).to(self.device) for k, v in batch.items() if k != "img"}
+        tb = {k: v for k, v in batch.items() if k != "img"}
         loss, items = segmentation_loss([tuple(lv) for lv in leaves], proto, tb, self.nc)
         flat = [t for lv in leaves for t in lv] + [proto]
         grads = torch.autograd.grad(loss, flat)

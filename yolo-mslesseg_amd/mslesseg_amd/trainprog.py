@@ -631,6 +631,30 @@ class TrainPlan(graph.Visitor):
         so the caller zeroes store.g once per optimizer step."""
         self._run(self.backward_segments)
 
+    def time_segments(self, segments, reps: int = 3):
+        """HIP-event time of every op of the given segments (callables are timed as one item): [(label, kind, mean ms, op)]."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        items = []
+        for seg in segments:
+            if isinstance(seg, hiplib.Program):
+                items += [("op", seg.arr[i]) for i in range(seg.n)]
+            else:
+                items.append(("py", seg))
+        acc = [0.0] * len(items)
+        for _ in range(reps):
+            evs = [hiplib.Event() for _ in range(len(items) + 1)]
+            evs[0].record(s)
+            for i, (k, it) in enumerate(items):
+                if k == "op":
+                    hiplib.launch(it, s)
+                else:
+                    it()
+                evs[i + 1].record(s)
+            torch.cuda.synchronize(self.device)
+            for i in range(len(items)):
+                acc[i] += evs[i].elapsed_ms(evs[i + 1])
+        return [("py" if k == "py" else "op", (int(it.kind) if k == "op" else -1), acc[i] / reps, it) for i, (k, it) in enumerate(items)]
+
     def head_outputs(self):
         """→ dict of torch views: per level (box [N,H,W,64] f32, cls [N,H,W,nc] f32, coef [N,H,W,32] f32) and proto [N,mh,mw,32]."""
         return {"levels": [tuple(v.torch() for v in self.levels[i]) for i in sorted(self.levels)], "proto": self.proto_view.torch()}
