@@ -189,16 +189,22 @@ class Trainer:
         tb = {k: v for k, v in batch.items() if k != "img"}
         loss, items = segmentation_loss([tuple(lv) for lv in leaves], proto, tb, self.nc)
         flat = [t for lv in leaves for t in lv] + [proto]
-        grads = torch.autograd.grad(loss, flat)
+        grads = torch.autograd.grad(loss, flat, allow_unused=True)  # no positive anchor ⇒ the box branch gets no gradient
         hg = plan.head_grads()
         k = 0
         for li, lv in enumerate(hg["levels"]):
             for j, gv in enumerate(lv):
                 if j == 1:
                     plan.G(plan.levels[li][1]).t.zero_()  # padding channels of the narrow class head
-                gv.copy_(grads[k])
+                if grads[k] is None:
+                    gv.zero_()
+                else:
+                    gv.copy_(grads[k])
                 k += 1
-        hg["proto"].copy_(grads[k])
+        if grads[k] is None:
+            hg["proto"].zero_()
+        else:
+            hg["proto"].copy_(grads[k])
         plan.backward()
         return items
 
