@@ -319,3 +319,40 @@ def test_volume_ops_bit_exact(demo_volumes):
         inter, sg, sp = (int(v) for v in acc.cpu())
         assert (inter, sg, sp) == (int((gt * want).sum()), int(gt.sum()), int(want.sum()))
         assert abs(2.0 * inter / (sg + sp + 1e-8) - P.dsc_unrounded(gt, want)) < 1e-12
+
+
+WGRAD_CASES = [
+    # N, H, W, Cin, Cout, k, s, x_cs, x_co, z_cs, z_co
+    (2, 16, 40, 64, 64, 3, 1, 64, 0, 64, 0),      # LDS transposed-read kernel (bf16): ragged tiles
+    (1, 9, 33, 32, 16, 3, 1, 96, 32, 48, 16),     # partial channel blocks, concat slices
+    (2, 20, 20, 128, 64, 3, 1, 128, 0, 64, 0),    # two ci blocks
+    (1, 13, 21, 8, 16, 3, 1, 8, 0, 16, 0),        # narrow layers of C3k2 at P2
+    (2, 12, 17, 48, 64, 1, 1, 48, 0, 64, 0),      # 1x1
+    (1, 16, 24, 64, 128, 3, 2, 64, 0, 128, 0),    # stride 2 → fp32 kernel in both dtypes
+    (3, 7, 5, 16, 8, 3, 1, 16, 0, 8, 0),
+    (1, 40, 40, 64, 256, 1, 1, 256, 128, 256, 0), # qkv-like 1x1 from a concat slice
+]
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(case, dtype):
+    N, H, W, Cin, Cout, k, s, x_cs, x_co, z_cs, z_co = case
+    g = torch.Generator().manual_seed(hash(case) % (2**31))
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    xbuf = _rand_act((N, H, W, x_cs), dtype, g)
+    zbuf = _rand_act((N, Ho, Wo, z_cs), dtype, g)
+    x = xbuf[..., x_co : x_co + Cin].float().permute(0, 3, 1, 2)
+    dz = zbuf[..., z_co : z_co + Cout].float().permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dz, stride=s, padding=pad).permute(0, 2, 3, 1).reshape(Cout, -1)  # [Cout][(ky,kx,ci)]
+    xd, zd = xbuf.to(DEV), zbuf.to(DEV)
+    dw = torch.full((Cout, k * k * Cin), 0.5, device=DEV)  # accumulates on top of what is there
+    op = hiplib.make_op(hiplib.OP_CONV_WGRAD, dtype, p=(xd.data_ptr(), zd.data_ptr(), 0, 0, dw.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: k, 8: s, 9: pad, 10: x_cs, 11: x_co, 12: z_cs, 13: z_co})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    got = dw.cpu() - 0.5
+    tol = 1e-4 if dtype == MSL_F32 else 2e-3  # bf16 inputs are exact in both; only fp32 summation order differs
+    err = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+    assert err < tol, f"wgrad {case}: rel err {err:.2e}"

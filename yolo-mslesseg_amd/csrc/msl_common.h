@@ -109,6 +109,7 @@ int msl_launch_add_view(const msl_op& op, hipStream_t s);
 int msl_launch_upsample2x_bwd(const msl_op& op, hipStream_t s);
 int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s);
 int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s);
+int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s);
 int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s);
 int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s);
 int msl_launch_cast_pad(const msl_op& op, hipStream_t s);

@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
 
 static int reduce_grid(long M, int C) {
   const int PL = 256 / (C / 4);
+  // Every block ends with 2*C fp64 atomics onto the SAME addresses: same-address atomics serialise (~20-50 ns each), so the
+  // grid is kept near one block per CU (measured: 2048 blocks cost ~60 us per launch in atomics alone, x180 launches per step).
   long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -411,20 +413,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { cov[i] = cob * 64 + i * 16 + l15 < a.Cout; civ[i] = cib * 64 + i * 16 + l15 < a.Cin; }
 
-  for (long p0 = p_begin; p0 < p_end; p0 += 4) {
-    const long p = p0 + kq;
+  // this lane walks pixels p_begin+kq, +4, +8, ...: decode (n, oy, ox) once, then advance by 4 with carries
+  long p = p_begin + kq;
+  int n = (int)(p / HoWo);
+  int r0 = (int)(p - (long)n * HoWo);
+  int oy = r0 / a.Wo, ox = r0 - oy * a.Wo;
+  for (long p0 = p_begin; p0 < p_end; p0 += 4, p += 4) {
     const bool pv = p < p_end;
-    long xoff = 0;
-    bool xin = false;
-    if (pv) {
-      const int n = (int)(p / HoWo);
-      const int r = (int)(p - (long)n * HoWo);
-      const int oy = r / a.Wo, ox = r - oy * a.Wo;
-      const int iy = oy * a.stride - a.pad + ty, ix = ox * a.stride - a.pad + tx;
-      xin = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      xoff = (((long)n * a.H + iy) * a.W + ix) * a.x_cs + a.x_co + cib * 64 + l15;
-    }
+    const int iy = oy * a.stride - a.pad + ty, ix = ox * a.stride - a.pad + tx;
+    const bool xin = pv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const long xoff = (((long)n * a.H + iy) * a.W + ix) * a.x_cs + a.x_co + cib * 64 + l15;
     const long zoff = p * a.z_cs + a.z_co + cob * 64 + l15;
+    ox += 4;
+    while (ox >= a.Wo) { ox -= a.Wo; if (++oy == a.Ho) { oy = 0; ++n; } }
     float av[4], bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -453,6 +454,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 // p 0 x, 1 dz, 4 dW f32 [Cout][K] ; i 0 N,1 H,2 W,3 Cin,4 Ho,5 Wo,6 Cout,7 k,8 stride,9 pad,10 x_cs,11 x_co,12 z_cs,13 z_co,19 dz_is_f32
 int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
+  {  // bf16 tensors, stride 1, 3x3/p1 or 1x1/p0: LDS transposed-read kernel on the bf16 MFMA (conv_wgrad_tr.hip)
+    const int k = op.i[7];
+    const bool geom = op.i[8] == 1 && ((k == 3 && op.i[9] == 1) || (k == 1 && op.i[9] == 0)) && op.i[4] == op.i[1] && op.i[5] == op.i[2];
+    const bool al = op.i[3] % 8 == 0 && op.i[6] % 8 == 0 && op.i[10] % 8 == 0 && op.i[11] % 8 == 0 && op.i[12] % 8 == 0 && op.i[13] % 8 == 0;
+    if (op.dtype == MSL_BF16 && !op.i[19] && geom && al && op.i[20] == 0) return msl_launch_conv_wgrad_tr(op, s);
+  }
   WgradArgs a;
   a.x = (const char*)op.p[0]; a.dz = (const char*)op.p[1]; a.dw = (float*)op.p[4];
   a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6]; a.k = op.i[7]; a.stride = op.i[8]; a.pad = op.i[9];
