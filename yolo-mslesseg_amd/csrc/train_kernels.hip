@@ -74,7 +74,7 @@ static int reduce_grid(long M, int C) {
   const int PL = 256 / (C / 4);
   // Every block ends with 2*C fp64 atomics onto the SAME addresses: same-address atomics serialise (~20-50 ns each), so the
   // grid is kept near one block per CU (measured: 2048 blocks cost ~60 us per launch in atomics alone, x180 launches per step).
-  long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);
+  long blocks = (M + (long)PL * 64 - 1) / ((long)PL * 64);  // >= 64 pixels per thread before another block (and its atomics) pays off
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
