@@ -343,3 +343,35 @@ def test_volume_dice_fp32_vs_oracle_and_bf16_report(eng_f32, eng_bf16, oracle_mo
         d = P.dsc_unrounded(gt, vol)
         print(f"dtype={eng.dtype} dice={d:.6f} oracle={d_o:.6f} voxels differing={int((vol != vol_o).sum())}")
         assert abs(d - d_o) <= tol, (eng.dtype, d, d_o)
+
+
+def test_whole_volume_three_planes_consensus_and_dice_on_device(synth_state, oracle_model, demo_volumes, tmp_path):
+    """predict_volume / consensus / dice (device) against the oracle's per-slice loop + NumPy volume steps, fp32 engine."""
+    from oracle import prepost as P
+
+    from mslesseg_amd import params, volume as V
+    from ultralytics import YOLO
+
+    ck = tmp_path / "best.pt"
+    params.save_checkpoint(ck, synth_state, "n", 1, {0: "lesion"})
+    model = YOLO(ck, precision="fp32")
+    fl, gt = demo_volumes["P39_flair"], demo_volumes["P39_mask"]
+    idx = {"axial": list(range(40, 140, 25)), "coronal": list(range(60, 160, 25)), "sagital": list(range(50, 130, 20))}
+    vols_o = {}
+    for pl, ii in idx.items():
+        want = {i: P.generar_prediccion_2D(oracle_model, P.slice_to_png_array(P.take_slice(fl, pl, i))) for i in ii}
+        vols_o[pl] = P.reconstruir_volumen(want, gt.shape, pl)
+    cons_d, vols_d = V.predict_consensus({pl: model for pl in idx}, fl, umbral=2, indices=idx)
+    for pl in idx:
+        diff = int((vols_d[pl].cpu().numpy() != vols_o[pl]).sum())
+        assert diff <= 40, (pl, diff)  # sign ties of ~0 mask logits only
+    cons_o = P.combinar_volumenes(vols_o["axial"], vols_o["coronal"], vols_o["sagital"], 2)
+    assert int((cons_d.cpu().numpy() != cons_o).sum()) <= 40
+    d_dev, d_round = V.dice(torch.from_numpy(gt).to(cons_d.device), cons_d)
+    d_o = P.dsc_unrounded(gt, cons_o)
+    assert abs(d_dev - d_o) <= 1e-4 and d_round == round(d_dev, 3)
+    with pytest.raises(ValueError):
+        V.insert_slices(vols_d["axial"], torch.zeros(1, 218, 182, dtype=torch.uint8, device=cons_d.device), [0], "axial")
+    V.write_nifti(tmp_path / "P39_consenso.nii.gz", cons_d.cpu().numpy(), demo_volumes["P39_affine"])
+    back, aff = V.read_nifti(tmp_path / "P39_consenso.nii.gz")
+    assert np.array_equal(back, cons_d.cpu().numpy().astype(np.float64))

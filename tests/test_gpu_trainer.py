@@ -29,6 +29,7 @@ def test_train_synthetic_losses_decrease_and_files_exist(tmp_path, precision):
     tot = [sum(float(r[k]) for k in ("train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss")) for r in rows]
     assert all(np.isfinite(tot)) and tot[-1] < 0.75 * tot[0], tot
     assert float(rows[-1]["val/cls_loss"]) > 0 and float(rows[1]["lr/pg0"]) > 0
+    assert all(0.0 <= float(rows[-1][c]) <= 1.0 for c in rows[-1] if c.startswith("metrics/"))
     # reload what was written, at the path convention the reference uses, and predict with it
     m2 = YOLO(run / "weights" / "best.pt", precision=precision)
     assert m2.nc == 1 and m2.scale == "n"

@@ -1,0 +1,52 @@
+"""Validation metrics (box / mask mAP) known-answer tests on CPU."""
+import numpy as np
+import torch
+
+from mslesseg_amd import metrics as MT
+
+
+def _scene(n=6, P=400, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    boxes = torch.rand(n, 2, generator=g) * 300
+    boxes = torch.cat([boxes, boxes + 40 + torch.rand(n, 2, generator=g) * 60], 1)
+    masks = (torch.rand(n, P, generator=g) > 0.5).float()
+    return boxes, masks, torch.zeros(n)
+
+
+def test_perfect_predictions_score_one_and_nothing_scores_zero():
+    s = MT.SegStats()
+    for seed in range(4):
+        b, m, c = _scene(seed=seed)
+        s.add_image(b, torch.linspace(0.9, 0.5, len(b)), c, m, b, c, m)
+    r = s.result()
+    for k in ("metrics/mAP50(B)", "metrics/mAP50-95(B)", "metrics/mAP50(M)", "metrics/mAP50-95(M)", "metrics/precision(B)", "metrics/recall(M)"):
+        assert r[k] > 0.99, (k, r[k])
+    assert abs(r["fitness"] - 2.0) < 0.02
+    e = MT.SegStats()
+    b, m, c = _scene()
+    e.add_image(torch.zeros(0, 4), torch.zeros(0), torch.zeros(0), torch.zeros(0, 400), b, c, m)
+    assert e.result()["metrics/mAP50(B)"] == 0.0 and e.result()["fitness"] == 0.0
+
+
+def test_shifted_boxes_pass_map50_but_not_map95_and_false_positives_cut_precision():
+    s = MT.SegStats()
+    b, m, c = _scene(n=8, seed=3)
+    shifted = b + torch.tensor([6.0, 6.0, 6.0, 6.0])  # IoU ~0.6-0.75 with its own gt
+    fp = torch.tensor([[500.0, 500.0, 560.0, 560.0]]).repeat(8, 1) + torch.arange(8)[:, None] * 7.0
+    s.add_image(torch.cat([shifted, fp]), torch.cat([torch.full((8,), 0.9), torch.full((8,), 0.8)]), torch.zeros(16),
+                torch.cat([m, torch.zeros(8, 400)]), b, c, m)
+    r = s.result()
+    assert r["metrics/mAP50(B)"] > 0.95 and r["metrics/mAP50-95(B)"] < 0.6
+    assert r["metrics/mAP50(M)"] > 0.95 and r["metrics/mAP50-95(M)"] > 0.95  # masks are exact
+    s2 = MT.SegStats()
+    s2.add_image(torch.cat([fp, shifted]), torch.cat([torch.full((8,), 0.9), torch.full((8,), 0.8)]), torch.zeros(16),
+                 torch.cat([torch.zeros(8, 400), m]), b, c, m)
+    assert s2.result()["metrics/mAP50(B)"] < 0.62  # the false positives now outrank every true positive
+
+
+def test_matching_is_one_to_one():
+    gt = torch.tensor([[0.0, 0.0, 10.0, 10.0]])
+    pred = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 9.5]])
+    c = MT.match_predictions(torch.zeros(2), torch.zeros(1), MT.box_iou(gt, pred))
+    assert c[:, 0].sum() == 1 and c[0, 0]  # only the better duplicate counts
+    assert MT.match_predictions(torch.ones(2), torch.zeros(1), MT.box_iou(gt, pred)).sum() == 0  # wrong class never matches

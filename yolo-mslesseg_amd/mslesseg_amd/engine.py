@@ -382,12 +382,14 @@ class LetterBoxProgram:
 class InferEngine:
     """Weights + plan cache.  `dtype` MSL_BF16 (throughput) or MSL_F32 (exact-fp32 parity mode)."""
 
-    def __init__(self, state, scale: str, nc: int, dtype: int = MSL_BF16, device="cuda:0", use_lds3x3: bool = True):
+    def __init__(self, state, scale: str, nc: int, dtype: int = MSL_BF16, device="cuda:0", use_lds3x3: bool = True,
+                 conf: float = CONF_THRES, iou: float = IOU_THRES, max_det: int = MAX_DET):
         if not torch.cuda.is_available():
             raise hiplib.MslError("no GPU: the mslesseg_amd inference path runs only on the HIP kernels (no CPU fallback)")
         hiplib.lib()
         self.device = torch.device(device)
         self.scale, self.nc, self.dtype = scale, nc, dtype
+        self.conf, self.iou, self.max_det = conf, iou, max_det
         params.validate_state(state, scale, nc)
         self.weights = PackedWeights(state, scale, nc, dtype, self.device, use_lds3x3)
         self._plans: Dict[Tuple[int, int, int], Plan] = {}
@@ -396,7 +398,7 @@ class InferEngine:
     def plan(self, N: int, Hlb: int, Wlb: int) -> Plan:
         key = (N, Hlb, Wlb)
         if key not in self._plans:
-            self._plans[key] = Plan(self.weights, N, Hlb, Wlb)
+            self._plans[key] = Plan(self.weights, N, Hlb, Wlb, conf=self.conf, iou=self.iou, max_det=self.max_det)
         return self._plans[key]
 
     def letterbox(self, N, H0, W0, C) -> Tuple[LetterBoxProgram, Plan]:

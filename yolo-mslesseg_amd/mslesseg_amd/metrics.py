@@ -1,0 +1,139 @@
+"""Validation metrics of the training leg: box and mask precision / recall / mAP50 / mAP50-95 and the fitness that
+selects best.pt  [UPSTREAM ultralytics 8.3.70 utils/metrics.py ap_per_class / compute_ap / SegmentMetrics.fitness,
+models/yolo/segment/val.py SegmentationValidator].  These fill the eight `metrics/*` columns of results.csv
+[REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/results.csv:1].  Not on the throughput path: tensor plumbing only.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+IOUV = np.linspace(0.5, 0.95, 10)
+
+
+def box_iou(a: torch.Tensor, b: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """[n,4] x [m,4] xyxy → [n,m]."""
+    lt = torch.maximum(a[:, None, :2], b[None, :, :2])
+    rb = torch.minimum(a[:, None, 2:], b[None, :, 2:])
+    inter = (rb - lt).clamp_(0).prod(2)
+    aa, ab = (a[:, 2:] - a[:, :2]).prod(1), (b[:, 2:] - b[:, :2]).prod(1)
+    return inter / (aa[:, None] + ab[None] - inter + eps)
+
+
+def mask_iou(a: torch.Tensor, b: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """[n,P] x [m,P] binary float → [n,m]."""
+    inter = a @ b.T
+    union = a.sum(1)[:, None] + b.sum(1)[None] - inter
+    return inter / (union + eps)
+
+
+def match_predictions(pred_cls: torch.Tensor, true_cls: torch.Tensor, iou: torch.Tensor) -> np.ndarray:
+    """iou [n_gt, n_pred] → correct [n_pred, 10] bool: greedy one-to-one matching per IoU threshold, best IoU first."""
+    n_pred = pred_cls.shape[0]
+    correct = np.zeros((n_pred, len(IOUV)), dtype=bool)
+    if n_pred == 0 or true_cls.shape[0] == 0:
+        return correct
+    same = (true_cls[:, None] == pred_cls[None]).cpu().numpy()
+    iou = (iou.cpu().numpy()) * same
+    for i, thr in enumerate(IOUV):
+        g, p = np.nonzero(iou >= thr)
+        if g.size:
+            m = np.stack([g, p], 1)
+            if m.shape[0] > 1:
+                m = m[iou[g, p].argsort()[::-1]]
+                m = m[np.unique(m[:, 1], return_index=True)[1]]
+                m = m[np.unique(m[:, 0], return_index=True)[1]]
+            correct[m[:, 1], i] = True
+    return correct
+
+
+def _smooth(y: np.ndarray, f: float = 0.1) -> np.ndarray:
+    nf = round(len(y) * f * 2) // 2 + 1
+    p = np.ones(nf // 2)
+    yp = np.concatenate((p * y[0], y, p * y[-1]), 0)
+    return np.convolve(yp, np.ones(nf) / nf, mode="valid")
+
+
+def _compute_ap(recall: np.ndarray, precision: np.ndarray) -> float:
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    x = np.linspace(0, 1, 101)
+    y = np.interp(x, mrec, mpre)
+    return float(np.sum((y[1:] + y[:-1]) * 0.5 * np.diff(x)))  # trapezoid, 101-point interpolation (COCO)
+
+
+def ap_per_class(tp: np.ndarray, conf: np.ndarray, pred_cls: np.ndarray, target_cls: np.ndarray, eps: float = 1e-16) -> Tuple[float, float, float, float]:
+    """→ (precision, recall, mAP50, mAP50-95) averaged over the classes present in target_cls, P/R at the max-F1 confidence."""
+    if tp.shape[0] == 0 or target_cls.shape[0] == 0:
+        return 0.0, 0.0, 0.0, 0.0
+    order = np.argsort(-conf)
+    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
+    classes, nt = np.unique(target_cls, return_counts=True)
+    px = np.linspace(0, 1, 1000)
+    ap = np.zeros((len(classes), tp.shape[1]))
+    p_curve, r_curve = np.zeros((len(classes), 1000)), np.zeros((len(classes), 1000))
+    for ci, c in enumerate(classes):
+        i = pred_cls == c
+        n_l, n_p = nt[ci], int(i.sum())
+        if n_p == 0 or n_l == 0:
+            continue
+        fpc, tpc = (1 - tp[i]).cumsum(0), tp[i].cumsum(0)
+        recall = tpc / (n_l + eps)
+        precision = tpc / (tpc + fpc)
+        r_curve[ci] = np.interp(-px, -conf[i], recall[:, 0], left=0)
+        p_curve[ci] = np.interp(-px, -conf[i], precision[:, 0], left=1)
+        for j in range(tp.shape[1]):
+            ap[ci, j] = _compute_ap(recall[:, j], precision[:, j])
+    f1 = 2 * p_curve * r_curve / (p_curve + r_curve + eps)
+    k = int(_smooth(f1.mean(0), 0.1).argmax())
+    return float(p_curve[:, k].mean()), float(r_curve[:, k].mean()), float(ap[:, 0].mean()), float(ap.mean())
+
+
+def fitness(box: Tuple[float, float, float, float], mask: Tuple[float, float, float, float]) -> float:
+    """SegmentMetrics.fitness = Metric.fitness(box) + Metric.fitness(mask), each 0.1*mAP50 + 0.9*mAP50-95."""
+    return (0.1 * box[2] + 0.9 * box[3]) + (0.1 * mask[2] + 0.9 * mask[3])
+
+
+class SegStats:
+    """Accumulates per-image matches; `result()` → dict of the eight metric columns + fitness."""
+
+    def __init__(self):
+        self.tp_b: List[np.ndarray] = []
+        self.tp_m: List[np.ndarray] = []
+        self.conf: List[np.ndarray] = []
+        self.pcls: List[np.ndarray] = []
+        self.tcls: List[np.ndarray] = []
+
+    def add_image(self, pred_boxes, pred_conf, pred_cls, pred_masks, gt_boxes, gt_cls, gt_masks) -> None:
+        """pred_boxes [n,4] xyxy px, pred_masks [n,P] {0,1}; gt_boxes [m,4] xyxy px, gt_masks [m,P] {0,1} (same pixel grid)."""
+        n, m = pred_boxes.shape[0], gt_boxes.shape[0]
+        self.tcls.append(gt_cls.cpu().numpy().astype(np.int64))
+        if n == 0:
+            return
+        if m:
+            cb = match_predictions(pred_cls, gt_cls, box_iou(gt_boxes, pred_boxes))
+            cm = match_predictions(pred_cls, gt_cls, mask_iou(gt_masks, pred_masks))
+        else:
+            cb = cm = np.zeros((n, len(IOUV)), dtype=bool)
+        self.tp_b.append(cb)
+        self.tp_m.append(cm)
+        self.conf.append(pred_conf.cpu().numpy())
+        self.pcls.append(pred_cls.cpu().numpy().astype(np.int64))
+
+    def result(self) -> Dict[str, float]:
+        tcls = np.concatenate(self.tcls) if self.tcls else np.zeros(0, np.int64)
+        if self.conf:
+            tp_b, tp_m = np.concatenate(self.tp_b), np.concatenate(self.tp_m)
+            conf, pcls = np.concatenate(self.conf), np.concatenate(self.pcls)
+        else:
+            tp_b = tp_m = np.zeros((0, len(IOUV)), bool)
+            conf, pcls = np.zeros(0), np.zeros(0, np.int64)
+        b = ap_per_class(tp_b.astype(np.float64), conf, pcls, tcls)
+        m = ap_per_class(tp_m.astype(np.float64), conf, pcls, tcls)
+        out = {"metrics/precision(B)": b[0], "metrics/recall(B)": b[1], "metrics/mAP50(B)": b[2], "metrics/mAP50-95(B)": b[3],
+               "metrics/precision(M)": m[0], "metrics/recall(M)": m[1], "metrics/mAP50(M)": m[2], "metrics/mAP50-95(M)": m[3]}
+        out["fitness"] = fitness(b, m)
+        return out

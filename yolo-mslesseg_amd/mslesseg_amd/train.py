@@ -39,7 +39,7 @@ RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cl
                   "val/box_loss", "val/seg_loss", "val/cls_loss", "val/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"]  # [REF trains/…/results.csv:1]
 
 DEFAULTS = dict(imgsz=640, nbs=64, seed=0, lrf=0.01, warmup_epochs=3.0, warmup_bias_lr=0.0, weight_decay=0.0005, close_mosaic=10,
-                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=64, augment=True)
+                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=64, augment=True, val_max=None)
 
 
 def _fbits(x: float) -> int:
@@ -259,6 +259,48 @@ class Trainer:
         st.b.copy_(keep_b)  # validation must not move the running statistics
         return tot / max(cnt, 1)
 
+    @torch.no_grad()
+    def _val_metrics(self):
+        """Box/mask P, R, mAP50, mAP50-95 on the held-out fold with the EMA weights (eval-mode BN, conf 0.001, IoU 0.7, max_det 300)
+        [UPSTREAM SegmentationValidator]; masks are compared at proto resolution like upstream's default `process_mask`."""
+        from . import metrics as MT
+        from .engine import InferEngine
+
+        if self.val_ds is None or len(self.val_ds) == 0:
+            return None
+        S, n = self.hyp["imgsz"], len(self.val_ds)
+        limit = self.hyp.get("val_max") or n
+        sd = self.store.state_dict(p=self.ema_p, b=self.ema_b)
+        eng = InferEngine({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, self.store.scale, self.nc, self.dtype, str(self.device),
+                          conf=0.001, iou=0.7, max_det=300)
+        stats = MT.SegStats()
+        vb = min(self.batch, 16)
+        for b0 in range(0, min(n, limit), vb):
+            idx = list(range(b0, min(b0 + vb, n, limit)))
+            while len(idx) < vb:
+                idx.append(idx[-1])  # pad the last batch; padded entries are not scored
+            batch = D.collate([D.plain(self.val_ds, i, S) for i in idx], S)
+            plan = eng.predict_batch(torch.from_numpy(np.ascontiguousarray(batch["img"][..., ::-1])))  # engine input is BGR
+            cnt = plan.keep_cnt.cpu()
+            mh, mw = plan.proto.H, plan.proto.W
+            ys = torch.arange(mh, device=self.device, dtype=torch.float32)[None, :, None]
+            xs = torch.arange(mw, device=self.device, dtype=torch.float32)[None, None, :]
+            gtm = torch.from_numpy(batch["masks"]).to(self.device)
+            for j in range(len(set(range(b0, min(b0 + vb, n, limit))))):
+                k = int(cnt[j])
+                det = plan.det[j, :k]
+                bl = det[:, :4] * (mw / S)
+                inbox = (xs >= bl[:, 0, None, None]) & (xs < bl[:, 2, None, None]) & (ys >= bl[:, 1, None, None]) & (ys < bl[:, 3, None, None])
+                pm = ((plan.lowres[j, :k] > 0) & inbox).float().reshape(k, -1)
+                sel = batch["batch_idx"] == j
+                gb = torch.from_numpy(batch["bboxes"][sel]).to(self.device) * S
+                gxyxy = torch.cat((gb[:, :2] - gb[:, 2:] / 2, gb[:, :2] + gb[:, 2:] / 2), 1) if gb.numel() else torch.zeros(0, 4, device=self.device)
+                m = int(sel.sum())
+                gm = (gtm[j][None] == torch.arange(1, m + 1, device=self.device)[:, None, None]).float().reshape(m, -1)
+                stats.add_image(det[:, :4], det[:, 4], det[:, 5], pm, gxyxy, torch.from_numpy(batch["cls"][sel]).to(self.device), gm)
+        del eng
+        return stats.result()
+
     # ------------------------------------------------------------------ files
     def _save(self, epoch: int, fitness: float) -> None:
         sd = self.store.state_dict(p=self.ema_p, b=self.ema_b)
@@ -303,9 +345,11 @@ class Trainer:
                     break
             tl /= max(nb_seen, 1)
             vl = self._val_losses()
-            fitness = -float(vl.sum()) if vl.any() else -float(tl.sum())
+            mets = self._val_metrics() if self.rank == 0 else None
+            fitness = mets["fitness"] if mets else -float(tl.sum())
             if self.rank == 0:
-                row = [epoch + 1, round(time.time() - self.t0, 4)] + [round(float(x), 5) for x in tl] + [0.0] * 8 + [round(float(x), 5) for x in vl] + [lr] * 3
+                mcols = [round(float(mets[c]), 5) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
+                row = [epoch + 1, round(time.time() - self.t0, 4)] + [round(float(x), 5) for x in tl] + mcols + [round(float(x), 5) for x in vl] + [lr] * 3
                 with open(self.save_dir / "results.csv", "a", newline="") as f:
                     csv.writer(f).writerow(row)
                 self._save(epoch, fitness)

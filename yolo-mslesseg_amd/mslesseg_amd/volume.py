@@ -1,0 +1,161 @@
+"""Whole-volume path: slice extraction as the reference writes it, batched prediction, and the volume steps on device.
+
+  extract   [REF yolo_mslesseg/scripts/extraer_dataset.py:192, utils/Paciente.py:233-249]  corte.T, origin="lower", grey colormap
+  predict   [REF scripts/generar_predicciones.py:205-222]                                   one batch per plane instead of a per-slice loop
+  insert    [REF scripts/reconstruir_volumen.py:136-186]                                    binarise (>0) + validar_corte + slab assignment
+  consensus [REF scripts/generar_consenso.py:106-109]                                       ((a+c+s) >= umbral) → uint8
+  dice      [REF yolo_mslesseg/utils/utils.py:455-460]                                      2*sum(gt*p)/(sum gt + sum p + 1e-8), also rounded to 3 dp
+
+NIfTI-1 (.nii / .nii.gz) I/O with gzip + struct (nibabel is not required): float32 plane volumes and uint8 consensus with the
+GT affine, as `guardar_volumen` writes them [REF utils/utils.py:153-180].
+"""
+from __future__ import annotations
+
+import gzip
+import struct
+from pathlib import Path
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import hiplib
+from .hiplib import MSL_F32
+
+PLANE_AXIS = {"axial": 2, "coronal": 1, "sagital": 0}
+_GRAY_LUT = (np.linspace(0, 1, 256) * 255).astype(np.uint8)  # matplotlib cm.gray(bytes=True): truncation, 24 entries one below
+_NIFTI_DT = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16, 768: np.uint32}
+_NIFTI_CODE = {np.dtype(np.uint8): (2, 8), np.dtype(np.int16): (4, 16), np.dtype(np.float32): (16, 32), np.dtype(np.float64): (64, 64)}
+
+
+# ------------------------------------------------------------------------------------------------- NIfTI-1
+def read_nifti(path) -> Tuple[np.ndarray, np.ndarray]:
+    """→ (data float64 [x,y,z] like nib.load(p).get_fdata(), affine 4x4)."""
+    raw = (gzip.open if str(path).endswith(".gz") else open)(path, "rb").read()
+    end = "<" if struct.unpack_from("<i", raw, 0)[0] == 348 else ">"
+    dim = struct.unpack_from(end + "8h", raw, 40)
+    datatype = struct.unpack_from(end + "h", raw, 70)[0]
+    pixdim = struct.unpack_from(end + "8f", raw, 76)
+    vox_offset, slope, inter = struct.unpack_from(end + "3f", raw, 108)
+    sform_code = struct.unpack_from(end + "h", raw, 254)[0]
+    shape = tuple(int(d) for d in dim[1 : 1 + dim[0]])
+    arr = np.frombuffer(raw, dtype=np.dtype(_NIFTI_DT[datatype]).newbyteorder(end), count=int(np.prod(shape)), offset=int(vox_offset))
+    data = arr.reshape(shape, order="F").astype(np.float64)
+    if slope not in (0.0, 1.0) or inter != 0.0:
+        if slope != 0.0 and not np.isnan(slope):
+            data = data * slope + inter
+    affine = np.eye(4)
+    if sform_code > 0:
+        affine[:3] = np.array(struct.unpack_from(end + "12f", raw, 280), dtype=np.float64).reshape(3, 4)
+    else:
+        affine[0, 0], affine[1, 1], affine[2, 2] = pixdim[1:4]
+    return data, affine
+
+
+def write_nifti(path, vol: np.ndarray, affine: np.ndarray) -> None:
+    vol = np.asarray(vol)
+    if vol.dtype not in _NIFTI_CODE:
+        vol = vol.astype(np.float32)
+    code, bits = _NIFTI_CODE[vol.dtype]
+    hdr = bytearray(348)
+    struct.pack_into("<i", hdr, 0, 348)
+    struct.pack_into("<8h", hdr, 40, vol.ndim, *(list(vol.shape) + [1] * (7 - vol.ndim)))
+    struct.pack_into("<2h", hdr, 70, code, bits)
+    vox = [float(np.linalg.norm(affine[:3, i])) for i in range(3)]
+    struct.pack_into("<8f", hdr, 76, 1.0, *vox, 1.0, 1.0, 1.0, 1.0)
+    struct.pack_into("<3f", hdr, 108, 352.0, 1.0, 0.0)
+    struct.pack_into("<2h", hdr, 252, 0, 1)  # qform_code 0, sform_code 1
+    struct.pack_into("<12f", hdr, 280, *np.asarray(affine, dtype=np.float64)[:3].reshape(-1))
+    hdr[344:348] = b"n+1\x00"
+    payload = bytes(hdr) + b"\x00" * 4 + vol.tobytes(order="F")
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "wb", compresslevel=3) as f:
+            f.write(payload)
+    else:
+        Path(path).write_bytes(payload)
+
+
+# ------------------------------------------------------------------------------------------------- slices
+def take_slice(vol: np.ndarray, plano: str, i: int) -> np.ndarray:
+    if plano == "axial":
+        return vol[:, :, i]
+    if plano == "coronal":
+        return vol[:, i, :]
+    if plano == "sagital":
+        return vol[i, :, :]
+    raise ValueError(f"Plano no reconocido: {plano}")
+
+
+def slice_as_png_array(vol_slice: np.ndarray) -> np.ndarray:
+    """The uint8 [H,W,3] array cv2.imread returns for a slice saved by plt.imsave(corte.T, cmap="gray", origin="lower")."""
+    a = np.asarray(vol_slice, dtype=np.float64).T
+    vmin, vmax = a.min(), a.max()
+    norm = (a - vmin) / (vmax - vmin) if vmax > vmin else np.zeros_like(a)
+    g = _GRAY_LUT[np.clip((norm * 256).astype(np.int64), 0, 255)][::-1]
+    return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+
+
+def expected_slice_shape(shape, plano: str) -> Tuple[int, int]:
+    return {"axial": (shape[0], shape[1]), "coronal": (shape[0], shape[2]), "sagital": (shape[1], shape[2])}[plano]
+
+
+# ------------------------------------------------------------------------------------------------- device steps
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def insert_slices(vol: torch.Tensor, imgs: torch.Tensor, indices, plano: str) -> None:
+    """vol float32 [X,Y,Z] (device) ← predicted uint8 slices [S,a,b] at `indices` of `plano` (binarised > 0).
+    Index range and per-plane slice shape are validated like validar_corte [REF reconstruir_volumen.py:153-176]."""
+    X, Y, Z = vol.shape
+    axis = PLANE_AXIS[plano]
+    idx = [int(i) for i in indices]
+    if any(i < 0 or i >= vol.shape[axis] for i in idx):
+        raise ValueError(f"Índice fuera de rango para plano {plano}.")
+    if tuple(imgs.shape[1:]) != expected_slice_shape(vol.shape, plano):
+        raise ValueError(f"Dimensiones {tuple(imgs.shape[1:])} incorrectas para plano {plano}. Se esperaba {expected_slice_shape(vol.shape, plano)}.")
+    ix = torch.tensor(idx, dtype=torch.int32, device=vol.device)
+    imgs = imgs.contiguous()
+    hiplib.launch(hiplib.make_op(hiplib.OP_VOL_INSERT, MSL_F32, p=(imgs.data_ptr(), ix.data_ptr(), 0, 0, vol.data_ptr()),
+                                 i={0: len(idx), 1: X, 2: Y, 3: Z, 4: axis}), _stream(vol.device))
+
+
+def consensus(axial: torch.Tensor, coronal: torch.Tensor, sagital: torch.Tensor, umbral: int = 2) -> torch.Tensor:
+    n = axial.numel()
+    out = torch.empty(axial.shape, dtype=torch.uint8, device=axial.device)
+    hiplib.launch(hiplib.make_op(hiplib.OP_VOL_CONSENSUS, MSL_F32, p=(axial.data_ptr(), coronal.data_ptr(), sagital.data_ptr(), 0, out.data_ptr()),
+                                 i={0: n & 0x7FFFFFFF, 1: n >> 31, 2: int(umbral)}), _stream(axial.device))
+    return out
+
+
+def dice(gt: torch.Tensor, pred: torch.Tensor) -> Tuple[float, float]:
+    """→ (un-rounded DSC, DSC rounded to 3 dp as the reference reports it) from exact integer sums on device."""
+    g, p = (gt != 0).to(torch.uint8).contiguous(), (pred != 0).to(torch.uint8).contiguous()
+    acc = torch.zeros(3, dtype=torch.int64, device=g.device)
+    n = g.numel()
+    hiplib.launch(hiplib.make_op(hiplib.OP_VOL_DICE, MSL_F32, p=(g.data_ptr(), p.data_ptr(), 0, 0, acc.data_ptr()), i={0: n & 0x7FFFFFFF, 1: n >> 31}), _stream(g.device))
+    inter, sg, sp = (int(v) for v in acc.cpu())
+    d = (2.0 * inter) / (sg + sp + 1e-8)
+    return d, float(np.round(d, 3))
+
+
+def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Iterable[int]] = None, batch: int = 128) -> torch.Tensor:
+    """FLAIR volume → float32 {0,1} volume of `plano` predictions on device (slices never predicted stay 0).
+    Whole-volume batched replacement of generar_predicciones + reconstruir_volumen for one plane."""
+    eng = model._get_engine()
+    dev = eng.device
+    idx = list(range(flair.shape[PLANE_AXIS[plano]])) if indices is None else [int(i) for i in indices]
+    vol = torch.zeros(flair.shape, dtype=torch.float32, device=dev)
+    for b0 in range(0, len(idx), batch):
+        chunk = idx[b0 : b0 + batch]
+        imgs = np.stack([slice_as_png_array(take_slice(flair, plano, i)) for i in chunk])
+        out = eng.predict_slices(torch.from_numpy(imgs))  # uint8 [S, W, H] = the array the reference would save per slice
+        insert_slices(vol, out, chunk, plano)
+    return vol
+
+
+def predict_consensus(models: Dict[str, object], flair: np.ndarray, umbral: int = 2, indices: Optional[Dict[str, Iterable[int]]] = None):
+    """Three plane models → (consensus uint8 volume on device, per-plane float32 volumes)."""
+    vols = {pl: predict_volume(models[pl], flair, pl, None if indices is None else indices.get(pl)) for pl in ("axial", "coronal", "sagital")}
+    return consensus(vols["axial"], vols["coronal"], vols["sagital"], umbral), vols
