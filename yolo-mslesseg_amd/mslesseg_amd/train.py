@@ -280,7 +280,9 @@ class Trainer:
             while len(idx) < vb:
                 idx.append(idx[-1])  # pad the last batch; padded entries are not scored
             batch = D.collate([D.plain(self.val_ds, i, S) for i in idx], S)
-            plan = eng.predict_batch(torch.from_numpy(np.ascontiguousarray(batch["img"][..., ::-1])))  # engine input is BGR
+            plan = eng.plan(vb, S, S)  # validation slices are already letterboxed RGB at the training size: no LetterBox pass
+            plan.input.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
+            plan.run()
             cnt = plan.keep_cnt.cpu()
             mh, mw = plan.proto.H, plan.proto.W
             ys = torch.arange(mh, device=self.device, dtype=torch.float32)[None, :, None]
