@@ -231,5 +231,7 @@ def collate(samples: Sequence[Tuple[np.ndarray, list]], size: int = IMGSZ, mask_
             bidx.append(b)
             cls.append(c)
             boxes.append([(x1 + x2) / 2 / size, (y1 + y2) / 2 / size, (x2 - x1) / size, (y2 - y1) / size])
-    return {"img": imgs, "batch_idx": np.asarray(bidx, np.float32), "cls": np.asarray(cls, np.float32),
-            "bboxes": np.asarray(boxes, np.float32).reshape(-1, 4), "masks": masks}
+    bi = np.asarray(bidx, np.float32)
+    n_max = int(np.bincount(bi.astype(np.int64), minlength=B).max()) if len(bidx) else 0
+    return {"img": imgs, "batch_idx": bi, "cls": np.asarray(cls, np.float32),
+            "bboxes": np.asarray(boxes, np.float32).reshape(-1, 4), "masks": masks, "n_max": n_max}

@@ -86,11 +86,10 @@ def assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, nc: 
     mask_pos = count.float() * mask_in_gts * mask_gt
     # an anchor claimed by several gts goes to the one with the highest overlap
     fg = mask_pos.sum(-2)
-    if fg.max() > 1:
-        multi = (fg.unsqueeze(1) > 1).expand(-1, n_max, -1)
-        is_max = torch.zeros_like(mask_pos).scatter_(1, overlaps.argmax(1).unsqueeze(1), 1.0)
-        mask_pos = torch.where(multi, is_max, mask_pos)
-        fg = mask_pos.sum(-2)
+    multi = (fg.unsqueeze(1) > 1).expand(-1, n_max, -1)  # a no-op where no anchor is claimed twice (no host-side branch)
+    is_max = torch.zeros_like(mask_pos).scatter_(1, overlaps.argmax(1).unsqueeze(1), 1.0)
+    mask_pos = torch.where(multi, is_max, mask_pos)
+    fg = mask_pos.sum(-2)
     target_gt_idx = mask_pos.argmax(-2)
     # targets
     flat_idx = target_gt_idx + torch.arange(bs, device=dev)[:, None] * n_max
@@ -132,13 +131,17 @@ def segmentation_loss(levels: List[Tuple[torch.Tensor, torch.Tensor, torch.Tenso
     anchor_points, stride_tensor = make_anchors(shapes, dev)
     A = anchor_points.shape[0]
 
-    # ---- targets → [B, n_max, 5] (cls, xyxy in pixels)
+    # ---- targets → [B, n_max, 5] (cls, xyxy in pixels).  n_max comes from the host (data.collate) so that no shape below
+    # depends on a device value: the whole loss is static-shape, sync-free tensor code.
     bi = batch["batch_idx"].to(dev).long().view(-1)
     T = bi.numel()
-    counts = torch.bincount(bi, minlength=B) if T else torch.zeros(B, dtype=torch.long, device=dev)
-    n_max = int(counts.max()) if T else 0
+    n_max = batch.get("n_max")
+    if n_max is None:
+        n_max = int(torch.bincount(bi, minlength=B).max()) if T else 0
+    n_max = int(n_max)
     targets = torch.zeros(B, n_max, 5, device=dev)
     if T:
+        counts = torch.bincount(bi, minlength=B)
         order = torch.argsort(bi, stable=True)
         pos = torch.arange(T, device=dev) - torch.cumsum(counts, 0)[bi[order]] + counts[bi[order]]
         xywh = batch["bboxes"].to(dev).float()[order] * imgsz[[1, 0, 1, 0]]
@@ -155,43 +158,46 @@ def segmentation_loss(levels: List[Tuple[torch.Tensor, torch.Tensor, torch.Tenso
 
     target_bboxes, target_scores, fg_mask, target_gt_idx = assign(
         pred_scores.detach().sigmoid(), (pred_bboxes.detach() * stride_tensor), anchor_points * stride_tensor, gt_labels, gt_bboxes, mask_gt, nc)
-    tss = max(float(target_scores.sum()), 1.0)
+    tss = target_scores.sum().clamp(min=1.0)
+    fg = fg_mask.float()
+    zero = torch.zeros((), device=dev)
 
-    loss = torch.zeros(4, device=dev)  # box, seg, cls, dfl
-    loss[2] = F.binary_cross_entropy_with_logits(pred_scores, target_scores, reduction="none").sum() / tss
-    if fg_mask.any():
-        tb = target_bboxes / stride_tensor
-        weight = target_scores.sum(-1)[fg_mask].unsqueeze(-1)
-        iou = ciou(pred_bboxes[fg_mask], tb[fg_mask])
-        loss[0] = ((1.0 - iou) * weight).sum() / tss
-        # DFL
-        ltrb = torch.cat((anchor_points - tb[..., :2], tb[..., 2:] - anchor_points), -1).clamp_(0, REG_MAX - 1 - 0.01)
-        tgt = ltrb[fg_mask]
-        tl = tgt.long()
-        wl = (tl + 1) - tgt
-        pd = pred_distri[fg_mask].view(-1, REG_MAX)
-        dfl = (F.cross_entropy(pd, tl.view(-1), reduction="none").view(tl.shape) * wl
-               + F.cross_entropy(pd, (tl + 1).view(-1), reduction="none").view(tl.shape) * (1 - wl)).mean(-1, keepdim=True)
-        loss[3] = (dfl * weight).sum() / tss
-        # masks
+    l_cls = F.binary_cross_entropy_with_logits(pred_scores, target_scores, reduction="none").sum() / tss
+    # box + DFL, dense over all anchors with weight 0 off the foreground
+    tb = target_bboxes / stride_tensor
+    weight = target_scores.sum(-1) * fg  # [B,A]
+    iou = ciou(pred_bboxes, tb).squeeze(-1)
+    l_box = (torch.where(fg_mask, (1.0 - iou) * weight, zero)).sum() / tss
+    ltrb = torch.cat((anchor_points - tb[..., :2], tb[..., 2:] - anchor_points), -1).clamp_(0, REG_MAX - 1 - 0.01)
+    tl = ltrb.long()
+    wl = (tl + 1) - ltrb
+    logp = F.log_softmax(pred_distri.view(B, A, 4, REG_MAX), -1)
+    ce_lo = -logp.gather(-1, tl.unsqueeze(-1)).squeeze(-1)
+    ce_hi = -logp.gather(-1, (tl + 1).unsqueeze(-1)).squeeze(-1)
+    dfl = (ce_lo * wl + ce_hi * (1 - wl)).mean(-1)
+    l_dfl = (torch.where(fg_mask, dfl * weight, zero)).sum() / tss
+    # masks: the (at most topk * n_max) foreground anchors of every image, padded to a fixed count
+    l_seg = (protof * 0).sum() + (pred_masks * 0).sum()
+    if n_max > 0:
+        Fm = min(A, TAL_TOPK * n_max)
+        sel = torch.topk(fg, Fm, dim=1).indices  # foreground anchors first; the rest carry weight 0
+        sel_fg = fg.gather(1, sel)
+        coef = pred_masks.gather(1, sel.unsqueeze(-1).expand(-1, -1, 32))
+        pm = torch.bmm(coef, protof.reshape(B, 32, -1))  # [B,Fm,mh*mw]
         masks = batch["masks"].to(dev).float()
         if tuple(masks.shape[-2:]) != (mask_h, mask_w):
             masks = F.interpolate(masks[None], (mask_h, mask_w), mode="nearest")[0]
-        tbn = target_bboxes / imgsz[[1, 0, 1, 0]]
-        marea = (tbn[..., 2] - tbn[..., 0]) * (tbn[..., 3] - tbn[..., 1])
-        mxyxy = tbn * torch.tensor([mask_w, mask_h, mask_w, mask_h], device=dev)
-        seg = torch.zeros((), device=dev)
-        for i in range(B):
-            fgi = fg_mask[i]
-            if fgi.any():
-                gt_mask = (masks[i][None] == (target_gt_idx[i][fgi] + 1).view(-1, 1, 1)).float()
-                pm = torch.einsum("in,nhw->ihw", pred_masks[i][fgi], protof[i])
-                l = F.binary_cross_entropy_with_logits(pm, gt_mask, reduction="none")
-                seg = seg + (_crop(l, mxyxy[i][fgi]).mean(dim=(1, 2)) / marea[i][fgi]).sum()
-            else:
-                seg = seg + (protof * 0).sum() + (pred_masks * 0).sum()
-        loss[1] = seg / fg_mask.sum()
-    else:
-        loss[1] = (protof * 0).sum() + (pred_masks * 0).sum()
-    loss = loss * torch.tensor([GAIN_BOX, GAIN_BOX, GAIN_CLS, GAIN_DFL], device=dev)
+        tgi = target_gt_idx.gather(1, sel)
+        gt_mask = (masks.reshape(B, 1, -1) == (tgi + 1).unsqueeze(-1).float()).float()
+        bce = F.binary_cross_entropy_with_logits(pm, gt_mask, reduction="none").view(B, Fm, mask_h, mask_w)
+        tbn = target_bboxes.gather(1, sel.unsqueeze(-1).expand(-1, -1, 4)) / imgsz[[1, 0, 1, 0]]
+        area = (tbn[..., 2] - tbn[..., 0]) * (tbn[..., 3] - tbn[..., 1])
+        mx = tbn * torch.tensor([mask_w, mask_h, mask_w, mask_h], device=dev)
+        r = torch.arange(mask_w, device=dev, dtype=torch.float32)[None, None, None, :]
+        c = torch.arange(mask_h, device=dev, dtype=torch.float32)[None, None, :, None]
+        inside = (r >= mx[..., 0, None, None]) & (r < mx[..., 2, None, None]) & (c >= mx[..., 1, None, None]) & (c < mx[..., 3, None, None])
+        per = (bce * inside).mean(dim=(2, 3))
+        per = torch.where(sel_fg > 0, per / area.clamp(min=1e-12), zero)
+        l_seg = l_seg + per.sum() / fg.sum().clamp(min=1.0)
+    loss = torch.stack((l_box * GAIN_BOX, l_seg * GAIN_BOX, l_cls * GAIN_CLS, l_dfl * GAIN_DFL))
     return loss.sum() * B, loss.detach()

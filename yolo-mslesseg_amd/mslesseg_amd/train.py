@@ -173,7 +173,7 @@ class Trainer:
     # ------------------------------------------------------------------ one optimisation step
     def to_device(self, batch):
         """numpy batch (data.collate) → device tensors; the bench keeps one such batch resident in HBM."""
-        return {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in batch.items()}
+        return {k: (torch.from_numpy(v).to(self.device, non_blocking=True) if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
 
     def forward_backward(self, batch) -> torch.Tensor:
         """HIP forward → loss (device tensor ops) → HIP backward.  Gradients ACCUMULATE into store.g."""
@@ -251,7 +251,7 @@ class Trainer:
             self.plan.pack()
             self.plan.forward()
             outs = self.plan.head_outputs()
-            tb = {k: torch.from_numpy(v).to(self.device) for k, v in batch.items() if k != "img"}
+            tb = {k: (torch.from_numpy(v).to(self.device) if isinstance(v, np.ndarray) else v) for k, v in batch.items() if k != "img"}
             _, items = segmentation_loss(outs["levels"], outs["proto"], tb, self.nc)
             tot += items.cpu().numpy()
             cnt += 1
