@@ -118,10 +118,12 @@ class ProgramBuilder(graph.Visitor):
         self.levels = {}
         self.proto_view: Optional[View] = None
         self.in_view: Optional[View] = None
+        self._keep = []
 
     # -- helpers
     def _new(self, H, W, C, f32=False) -> View:
         t = torch.empty(self.N * H * W * C, dtype=torch.float32 if f32 else _dt(self.dtype), device=self.device)
+        self._keep.append(t)  # op descriptors hold raw device pointers: the builder owns every buffer for the plan's life
         return View(t, self.N, H, W, C, C, 0, f32)
 
     def _emit(self, name, op):
@@ -283,6 +285,7 @@ class Plan:
                             p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), off_dev.data_ptr(), out.data_ptr()),
                             i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb})
         hiplib.launch(op, s)
+        self._last_offsets = off_dev  # read asynchronously by the launch above
         res = []
         for n in range(self.N):
             c, o = int(cnt[n]), int(offsets[n])

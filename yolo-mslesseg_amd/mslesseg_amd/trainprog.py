@@ -248,6 +248,7 @@ class TrainPlan(graph.Visitor):
     # ------------------------------------------------------------------ helpers
     def _new(self, H, W, C, f32=False) -> View:
         t = torch.empty(self.N * H * W * C, dtype=torch.float32 if f32 else _dt(self.dtype), device=self.device)
+        self._keep.append(t)  # op descriptors hold raw device pointers: the plan owns every buffer for its whole life
         return View(t, self.N, H, W, C, C, 0, f32)
 
     def G(self, v: View) -> View:
@@ -407,6 +408,7 @@ class TrainPlan(graph.Visitor):
                                       i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32}))
             if dz_f32 and self.dtype != MSL_F32:  # the MFMA operand must be the compute dtype
                 dzc = self._new(Ho, Wo, dz.C)
+                self._keep.append(dzc.t)  # ops hold raw pointers: every buffer must outlive the programs
                 ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dzc.t.data_ptr(), dz.t.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
                 dz = dzc
