@@ -331,6 +331,8 @@ WGRAD_CASES = [
     (1, 16, 24, 64, 128, 3, 2, 64, 0, 128, 0),    # stride 2 → fp32 kernel in both dtypes
     (3, 7, 5, 16, 8, 3, 1, 16, 0, 8, 0),
     (1, 40, 40, 64, 256, 1, 1, 256, 128, 256, 0), # qkv-like 1x1 from a concat slice
+    (2, 21, 35, 32, 32, 3, 2, 32, 0, 32, 0),      # stride 2, odd sizes (parity-split halo in the bf16 kernel)
+    (1, 64, 96, 16, 32, 3, 2, 16, 0, 32, 0),      # model.1-like
 ]
 
 

@@ -22,16 +22,18 @@ struct WgTrArgs {
   const char* x;
   const char* dz;
   float* dw;
-  int N, H, W, Cin, Cout;  // stride 1: output size == input size
+  int N, H, W, Cin, Cout, Ho, Wo;
   int x_cs, x_co, z_cs, z_co, K;
   int tiles_x, tiles_y, tiles_per_block;
   long total_tiles;
 };
 
-template <int TAPS>
+template <int TAPS, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgTrArgs a) {
-  constexpr int TH = 8, TW = 32, PITCH = 144;                 // bytes per LDS slot: 64 bf16 + 16 B pad (9 x 16-byte chunks)
-  constexpr int ROWP = TAPS == 9 ? TW + 2 : TW, ROWS = TAPS == 9 ? TH + 2 : TH;
+  constexpr int TH = S == 1 ? 8 : 4, TW = 32, PITCH = 144;    // bytes per LDS slot: 64 bf16 + 16 B pad (9 x 16-byte chunks)
+  // x image rows: stride 1 → TW+2 halo columns; stride 2 → the 2*TW+1 halo columns split by parity ([33 even | 33 odd]) so
+  // that 8 consecutive OUTPUT pixels read 8 consecutive slots for every tap
+  constexpr int ROWP = TAPS == 9 ? (S == 1 ? TW + 2 : 66) : TW, ROWS = TAPS == 9 ? (S == 1 ? TH + 2 : 2 * TH + 1) : TH;
   constexpr int Z_SLOTS = TH * TW, X_SLOTS = ROWS * ROWP;
   constexpr int Z_PIECES = (Z_SLOTS * 9 + 63) / 64, X_PIECES = (X_SLOTS * 9 + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -63,15 +65,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgTrArgs a) {
     for (int pc = wave; pc < Z_PIECES; pc += 4) {
       const int cidx = pc * 64 + lane, slot = cidx / 9, ch = cidx - slot * 9;
       const int oy = oy0 + (slot >> 5), ox = ox0 + (slot & 31);
-      const bool ok = slot < Z_SLOTS && ch < 8 && oy < a.H && ox < a.W && cob * 64 + ch * 8 < a.Cout;
-      const char* src = ok ? a.dz + ((((long)n * a.H + oy) * a.W + ox) * a.z_cs + a.z_co + cob * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
+      const bool ok = slot < Z_SLOTS && ch < 8 && oy < a.Ho && ox < a.Wo && cob * 64 + ch * 8 < a.Cout;
+      const char* src = ok ? a.dz + ((((long)n * a.Ho + oy) * a.Wo + ox) * a.z_cs + a.z_co + cob * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_z + pc * 1024), 16, 0, 0);
     }
     // ---- stage x (halo) tile
     for (int pc = wave; pc < X_PIECES; pc += 4) {
       const int cidx = pc * 64 + lane, slot = cidx / 9, ch = cidx - slot * 9;
-      const int r = slot / ROWP, c = slot - r * ROWP;
-      const int iy = oy0 + r - (TAPS == 9 ? 1 : 0), ix = ox0 + c - (TAPS == 9 ? 1 : 0);
+      const int r = slot / ROWP;
+      int c = slot - r * ROWP;
+      if constexpr (S == 2) c = c < 33 ? 2 * c : 2 * (c - 33) + 1;  // parity-split image → halo column
+      const int iy = oy0 * S + r - (TAPS == 9 ? 1 : 0), ix = ox0 * S + c - (TAPS == 9 ? 1 : 0);
       const bool ok = slot < X_SLOTS && ch < 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cib * 64 + ch * 8 < a.Cin;
       const char* src = ok ? a.x + ((((long)n * a.H + iy) * a.W + ix) * a.x_cs + a.x_co + cib * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_x + pc * 1024), 16, 0, 0);
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgTrArgs a) {
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int ty = TAPS == 9 ? t / 3 : 0, tx = TAPS == 9 ? t % 3 : 0;
-        const int xslot = (row + ty) * ROWP + tx + 8 * g + q;
+        const int xslot = S == 1 ? (row + ty) * ROWP + tx + 8 * g + q : (2 * row + ty) * ROWP + (tx & 1) * 33 + (tx >> 1) + 8 * g + q;
         const unsigned char* xp = s_x + xslot * PITCH + (4 * pp) * 2;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -121,33 +125,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgTrArgs a) {
     }
 }
 
-template <int TAPS>
+template <int TAPS, int S>
 static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
-  constexpr int ROWP = TAPS == 9 ? 34 : 32, ROWS = TAPS == 9 ? 10 : 8;
-  constexpr int LDS = ((8 * 32 * 9 + 63) / 64 + (ROWS * ROWP * 9 + 63) / 64) * 1024;
+  constexpr int TH = S == 1 ? 8 : 4;
+  constexpr int ROWP = TAPS == 9 ? (S == 1 ? 34 : 66) : 32, ROWS = TAPS == 9 ? (S == 1 ? TH + 2 : 2 * TH + 1) : TH;
+  constexpr int LDS = ((TH * 32 * 9 + 63) / 64 + (ROWS * ROWP * 9 + 63) / 64) * 1024;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TAPS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS>), dim3((unsigned)gx, (unsigned)ny), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS, S>), dim3((unsigned)gx, (unsigned)ny), dim3(256), LDS, s, a);
   MSL_CHECK_LAUNCH("conv_wgrad_tr");
   return MSL_OK;
 }
 
-// Called from msl_launch_conv_wgrad for bf16 tensors, stride 1, k = 3 (pad 1) or k = 1 (pad 0).  Same op slots.
+// Called from msl_launch_conv_wgrad for bf16 tensors: k = 3 / pad 1 / stride 1|2, or k = 1 / pad 0 / stride 1.  Same op slots.
 int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   WgTrArgs a;
   a.x = (const char*)op.p[0]; a.dz = (const char*)op.p[1]; a.dw = (float*)op.p[4];
-  a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Cout = op.i[6];
-  const int k = op.i[7];
+  a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6];
+  const int k = op.i[7], stride = op.i[8], pad = op.i[9];
   a.x_cs = op.i[10]; a.x_co = op.i[11]; a.z_cs = op.i[12]; a.z_co = op.i[13];
   a.K = k * k * a.Cin;
   MSL_REQUIRE(a.x && a.dz && a.dw && a.N > 0 && a.H > 0 && a.W > 0, "conv_wgrad_tr: bad args");
-  MSL_REQUIRE(op.i[4] == a.H && op.i[5] == a.W && op.i[8] == 1 && ((k == 3 && op.i[9] == 1) || (k == 1 && op.i[9] == 0)), "conv_wgrad_tr: needs stride 1, k3p1 or k1p0");
+  MSL_REQUIRE((k == 3 && pad == 1 && (stride == 1 || stride == 2)) || (k == 1 && pad == 0 && stride == 1), "conv_wgrad_tr: needs k3p1 (stride 1|2) or k1p0 stride 1");
+  MSL_REQUIRE(a.Ho == (a.H + 2 * pad - k) / stride + 1 && a.Wo == (a.W + 2 * pad - k) / stride + 1, "conv_wgrad_tr: inconsistent output dims");
   MSL_REQUIRE(a.Cin % 8 == 0 && a.Cout % 8 == 0 && a.x_cs % 8 == 0 && a.x_co % 8 == 0 && a.z_cs % 8 == 0 && a.z_co % 8 == 0, "conv_wgrad_tr: channels/views must be multiples of 8");
-  a.tiles_x = (a.W + 31) / 32;
-  a.tiles_y = (a.H + 7) / 8;
+  const int TH = stride == 1 ? 8 : 4;
+  a.tiles_x = (a.Wo + 31) / 32;
+  a.tiles_y = (a.Ho + TH - 1) / TH;
   a.total_tiles = (long)a.N * a.tiles_y * a.tiles_x;
   const int ny = ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
   long want = (768 + ny - 1) / ny;  // ~3 workgroups per CU overall
@@ -156,6 +163,7 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   if (tpb < 1) tpb = 1;
   a.tiles_per_block = (int)tpb;
   const long gx = (a.total_tiles + tpb - 1) / tpb;
-  if (k == 3) return launch_tr<9>(a, ny, gx, s);
-  return launch_tr<1>(a, ny, gx, s);
+  if (k == 3 && stride == 1) return launch_tr<9, 1>(a, ny, gx, s);
+  if (k == 3) return launch_tr<9, 2>(a, ny, gx, s);
+  return launch_tr<1, 1>(a, ny, gx, s);
 }

@@ -236,6 +236,9 @@ class TrainPlan(graph.Visitor):
         self._fwd: List = [[]]
         self._bwd: List[List] = []  # per layer, list of ops / callables (emitted forward, replayed reversed)
         self._pack: List = []
+        self._arena: Dict[int, dict] = {}
+        self._bwd_acc = torch.zeros(1 << 17, dtype=torch.float64, device=self.device)  # all backward reduction accumulators
+        self._bwd_acc_n = 0
         self._keep: List[torch.Tensor] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.levels, self.proto_view, self.in_view = {}, None, None
@@ -267,15 +270,28 @@ class TrainPlan(graph.Visitor):
         self._keep.append(t)
         return t
 
+    def _acc_bwd(self, C) -> torch.Tensor:
+        """fp64 accumulator of a backward reduction: a slice of ONE buffer that backward() zeroes with a single memset."""
+        n = 2 * C
+        assert self._bwd_acc_n + n <= self._bwd_acc.numel()
+        t = self._bwd_acc[self._bwd_acc_n : self._bwd_acc_n + n]
+        self._bwd_acc_n += n
+        return t
+
     def _packed(self, idx: torch.Tensor, dtype: Optional[int] = None) -> torch.Tensor:
-        """Register a GATHER_CAST from the master buffer; returns the destination tensor."""
+        """Register a weight image to be gathered from the master buffer every step; returns its destination — a slice of one
+        pre-allocated arena per dtype, so that the whole pack is ONE GATHER_CAST launch per dtype instead of one per layer."""
         dt = self.dtype if dtype is None else dtype
-        idx_d = idx.to(self.device)
-        dst = torch.empty(idx.numel(), dtype=_dt(dt), device=self.device)
-        self._keep += [idx_d, dst]
+        if dt not in self._arena:
+            cap = 4 * self.store.n + (1 << 20) if dt == self.dtype else 1 << 16  # the fp32 side arena only holds ConvT bias images
+            self._arena[dt] = {"buf": torch.zeros(cap, dtype=_dt(dt), device=self.device), "idx": [], "n": 0}
+        ar = self._arena[dt]
         n = idx.numel()
-        self._pack.append(hiplib.make_op(hiplib.OP_GATHER_CAST, dt, p=(self.store.p.data_ptr(), idx_d.data_ptr(), 0, 0, dst.data_ptr()),
-                                         i={0: n & 0x7FFFFFFF, 1: n >> 31}))
+        pad = (-n) % 8  # keep every image 16-byte aligned inside the arena
+        assert ar["n"] + n + pad <= ar["buf"].numel(), "weight pack arena too small"
+        dst = ar["buf"][ar["n"] : ar["n"] + n]
+        ar["idx"].append(torch.cat([idx.reshape(-1).to(torch.int32), torch.full((pad,), -1, dtype=torch.int32)]))
+        ar["n"] += n + pad
         return dst
 
     def _conv_op(self, x: View, y: View, wt, bias_ptr, m, k, s, pad, act=0, res: Optional[View] = None, out_f32=False, store_mode=0, dgrad=0, cout=None):
@@ -313,13 +329,12 @@ class TrainPlan(graph.Visitor):
             first = self._init.first_write(gr)
             ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gr.t.data_ptr(), gy.t.data_ptr()),
                                       i={0: self.N, 1: y.H, 2: y.W, 3: C, 10: gr.cs, 11: gr.co, 12: gy.cs, 13: gy.co, 20: 1 if first else 0}))
-        acc = self._acc(C)
+        acc = self._acc_bwd(C)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0}
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=pcommon + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
                                   i={**dims, 14: z.cs, 15: z.co, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
-        ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, self.dump.data_ptr()), i={0: 2 * C, 1: 1}))  # reset acc for the next step
 
     # ------------------------------------------------------------------ Visitor
     def input(self):
@@ -397,12 +412,10 @@ class TrainPlan(graph.Visitor):
             else:  # plain conv + bias: dz = dy (the loss writes it, zeros in the padding channels)
                 gy = self.G(y)
                 gyw = View(gy.t, gy.N, gy.H, gy.W, cpad, gy.cs, gy.co, gy.f32)
-                acc = self._acc(cpad)
+                acc = self._acc_bwd(cpad)
                 ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gyw.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0}))
                 ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
-                if cpad != cout:
-                    ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, self.dump.data_ptr()), i={0: cpad, 1: 1}))
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
             ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
                                       i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32}))
@@ -445,7 +458,7 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             gy = self.G(y)
-            acc = self._acc(cout)
+            acc = self._acc_bwd(cout)
             ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gy.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co}))
             ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
@@ -611,6 +624,12 @@ class TrainPlan(graph.Visitor):
                     bwd_segments[-1].append(op)
         self.forward_segments = [hiplib.Program(s) if isinstance(s, list) and s else s for s in self._fwd if not (isinstance(s, list) and not s)]
         self.backward_segments = [hiplib.Program(s) if isinstance(s, list) and s else s for s in bwd_segments if not (isinstance(s, list) and not s)]
+        for dt, ar in self._arena.items():
+            idx_d = torch.cat(ar["idx"]).to(self.device)
+            self._keep += [idx_d, ar["buf"]]
+            n = idx_d.numel()
+            self._pack.append(hiplib.make_op(hiplib.OP_GATHER_CAST, dt, p=(self.store.p.data_ptr(), idx_d.data_ptr(), 0, 0, ar["buf"].data_ptr()),
+                                             i={0: n & 0x7FFFFFFF, 1: n >> 31}))
         self.pack_program = hiplib.Program(self._pack)
         self.A = sum(v[0].H * v[0].W for v in self.levels.values())
 
@@ -629,8 +648,9 @@ class TrainPlan(graph.Visitor):
         self._run(self.forward_segments)
 
     def backward(self):
-        """Head/proto gradient buffers must have been filled (see `head_grad_views`); weight gradients ACCUMULATE into store.g,
+        """Head/proto gradient buffers must have been filled (see `head_grads`); weight gradients ACCUMULATE into store.g,
         so the caller zeroes store.g once per optimizer step."""
+        self._bwd_acc[: self._bwd_acc_n].zero_()  # one memset for every backward reduction accumulator
         self._run(self.backward_segments)
 
     def time_segments(self, segments, reps: int = 3):
