@@ -228,7 +228,11 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             fl = conv_flops(it, True)
             wg_ms, wg_fl = wg_ms + ms, wg_fl + fl
             if best is None or ms > best[0]:
-                best = (ms, fl, "conv_wgrad_kernel (fp32 MFMA 16x16x4, pixel contraction)", "fp32", tag, it)
+                I = it.i  # same dispatch rule as msl_launch_conv_wgrad (train_kernels.hip): bf16 tensors + 3x3/p1 (s1|s2) or 1x1/p0/s1 + 8-aligned views
+                geom = (I[7] == 3 and I[9] == 1 and I[8] in (1, 2)) or (I[7] == 1 and I[9] == 0 and I[8] == 1)
+                tr_kernel = it.dtype == hiplib.MSL_BF16 and not I[19] and geom and all(I[j] % 8 == 0 for j in (3, 6, 10, 11, 12, 13)) and I[20] == 0
+                best = (ms, fl, "conv_wgrad_tr_kernel (bf16 MFMA 16x16x32, LDS transposed reads, pixel contraction)", "bf16", tag, it) if tr_kernel else \
+                       (ms, fl, "conv_wgrad_kernel (fp32 MFMA 16x16x4, pixel contraction)", "fp32", tag, it)
         elif kind == hiplib.OP_CONV:
             fl = conv_flops(it)
             cv_ms, cv_fl = cv_ms + ms, cv_fl + fl
@@ -242,7 +246,7 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "kernel": kname, "kernel_dtype": kdt, "launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "launch_shape": {"N": I[0], "H": I[1], "W": I[2], "Cin": I[3], "Ho": I[4], "Wo": I[5], "Cout": I[6], "k": I[7], "stride": I[8]},
-            "all_wgrad": {"tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2), "frac_of_fp32_mfma": round(wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK["fp32"], 4), "ms": round(wg_ms, 3)},
+            "all_wgrad": {"tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2), "frac": round(wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK[args.dtype], 4), "ms": round(wg_ms, 3)},
             "all_conv_fwd_dgrad": {"tflops": round(cv_fl / (cv_ms * 1e-3) / 1e12, 2), "frac": round(cv_fl / (cv_ms * 1e-3) / 1e12 / PEAK[args.dtype], 4), "ms": round(cv_ms, 3)},
             "program_ms": {"total_fwd_bwd_pack": round(total, 3),
                            **{f"{t}:{names.get(k, 'torch-attention')}": round(v, 3) for (t, k), v in sorted(by_kind.items(), key=lambda x: -x[1])[:14]}},

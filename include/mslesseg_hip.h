@@ -129,10 +129,10 @@ enum {
    * Train-mode Conv = CONV(raw, no bias/act) → BN_STATS → BN_FINALIZE → BN_ACT; its backward = BN_ACT_BWD_REDUCE →
    * BN_ACT_BWD_APPLY (dz, dgamma, dbeta) → CONV_WGRAD + CONV with i[22]=1 (dgrad: transposed-conv gather, weights packed
    * [Cin][(ky,kx,co)]).  ConvTranspose2d(2,2) backward = CONV k=2 s=2 p=0 (dgrad) and CONV_WGRAD with the operands swapped. */
-  MSL_OP_BN_STATS = 16,           /* acc f64[2C] += (sum z, sum z^2) per channel over N*H*W */
-  MSL_OP_BN_FINALIZE = 17,        /* stats f32[2C] = (mean, 1/sqrt(var+eps)); running stats update; acc = 0 */
+  MSL_OP_BN_STATS = 16,           /* acc f64[slots][2C] += (sum z, sum z^2) per channel over N*H*W; i[21] slots */
+  MSL_OP_BN_FINALIZE = 17,        /* stats f32[2C] = (mean, 1/sqrt(var+eps)) from the slot sums; running stats update; acc = 0 */
   MSL_OP_BN_ACT = 18,             /* y = act(gamma*zhat+beta) (+res) */
-  MSL_OP_BN_ACT_BWD_REDUCE = 19,  /* acc f64[2C] += (sum g, sum g*zhat), g = dy*act'(u) */
+  MSL_OP_BN_ACT_BWD_REDUCE = 19,  /* acc f64[slots][2C] += (sum g, sum g*zhat), g = dy*act'(u); i[21] slots */
   MSL_OP_BN_ACT_BWD_APPLY = 20,   /* dz = gamma*invstd*(g - s1/M - zhat*s2/M); dgamma = s2, dbeta = s1 */
   MSL_OP_COLSUM = 21,             /* acc f64[C] += column sums of a view (bias gradients) */
   MSL_OP_F64_DRAIN = 22,          /* dst f32[n] = src f64[n*stride]; src = 0 */

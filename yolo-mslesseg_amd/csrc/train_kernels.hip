@@ -10,13 +10,17 @@
 
 // =========================================================================================================
 // Per-channel reductions over the pixel axis of an NHWC view.  Block = 256 threads laid out as (C/4 channel
-// quads) x (pixel lanes); fp32 partials per thread, LDS tree over pixel lanes, one fp64 atomicAdd per channel
-// and block (fp64 so that E[z^2]-E[z]^2 and the long sums keep fp32-level accuracy at M ~ 3e6 pixels).
+// quads) x (pixel lanes); fp32 partials per thread (4 independent loads in flight), LDS tree over pixel lanes, one
+// fp64 atomicAdd per channel and block (fp64 so that E[z^2]-E[z]^2 and the long sums keep fp32-level accuracy at
+// M ~ 3e6 pixels).  Same-address fp64 atomics serialise in L2 (~30 ns each, measured), so the accumulator is
+// replicated over `slots` copies (block b adds into copy b % slots) and the consumer sums the copies: that lets
+// the grid grow to ~4 blocks per CU — enough loads in flight to stream at HBM rate — without an atomic tail.
 // =========================================================================================================
+#define MSL_MAX_SLOTS 16
 template <bool F32, int MODE>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ acc,
-                                                          long M, int C, int a_cs, int a_co, int b_cs, int b_co, int act, int a_f32) {
+                                                          long M, int C, int a_cs, int a_co, int b_cs, int b_co, int act, int a_f32, int slots) {
   __shared__ float red[2][256][4];
   const int C4 = C >> 2;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
@@ -27,31 +31,48 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
   }
-  if (pl < PL) {
-    for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
-      float va[4], vb[4];
-      if (MODE == 2 && a_f32) ld4<true>(a, p * a_cs + a_co + c, va); else ld4<F32>(a, p * a_cs + a_co + c, va);
-      if (MODE == 0) {
+  auto accumulate = [&](const float (&va)[4], const float (&vb)[4]) {
+    if (MODE == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[r] += va[r]; s2[r] = fmaf(va[r], va[r], s2[r]); }
-      } else if (MODE == 2) {
+      for (int r = 0; r < 4; ++r) { s1[r] += va[r]; s2[r] = fmaf(va[r], va[r], s2[r]); }
+    } else if (MODE == 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s1[r] += va[r];
-      } else {  // a = dy, b = z
-        ld4<F32>(b, p * b_cs + b_co + c, vb);
+      for (int r = 0; r < 4; ++r) s1[r] += va[r];
+    } else {  // a = dy, b = z
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float zh = (vb[r] - mu[r]) * is[r];
-          float g = va[r];
-          if (act) {
-            const float u = fmaf(ga[r], zh, be[r]);
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
-            g *= sg * (1.0f + u * (1.0f - sg));
-          }
-          s1[r] += g;
-          s2[r] = fmaf(g, zh, s2[r]);
+      for (int r = 0; r < 4; ++r) {
+        const float zh = (vb[r] - mu[r]) * is[r];
+        float g = va[r];
+        if (act) {
+          const float u = fmaf(ga[r], zh, be[r]);
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+          g *= sg * (1.0f + u * (1.0f - sg));
         }
+        s1[r] += g;
+        s2[r] = fmaf(g, zh, s2[r]);
       }
+    }
+  };
+  if (pl < PL) {
+    constexpr int U = 4;
+    const long step = (long)gridDim.x * PL;
+    long p = (long)blockIdx.x * PL + pl;
+    for (; p + (U - 1) * step < M; p += U * step) {
+      float va[U][4], vb[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long q = p + u * step;
+        if (MODE == 2 && a_f32) ld4<true>(a, q * a_cs + a_co + c, va[u]); else ld4<F32>(a, q * a_cs + a_co + c, va[u]);
+        if (MODE == 1) ld4<F32>(b, q * b_cs + b_co + c, vb[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(va[u], vb[u]);
+    }
+    for (; p < M; p += step) {
+      float va[4], vb[4] = {0, 0, 0, 0};
+      if (MODE == 2 && a_f32) ld4<true>(a, p * a_cs + a_co + c, va); else ld4<F32>(a, p * a_cs + a_co + c, va);
+      if (MODE == 1) ld4<F32>(b, p * b_cs + b_co + c, vb);
+      accumulate(va, vb);
     }
   }
 #pragma unroll
@@ -62,43 +83,51 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
     for (int j = 0; j < PL; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { t1[r] += red[0][j * C4 + threadIdx.x][r]; t2[r] += red[1][j * C4 + threadIdx.x][r]; }
+    double* dst = acc + (long)(blockIdx.x % slots) * (MODE == 2 ? C : 2 * C);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (MODE == 2) atomicAdd(acc + c + r, (double)t1[r]);
-      else { atomicAdd(acc + 2 * (c + r), (double)t1[r]); atomicAdd(acc + 2 * (c + r) + 1, (double)t2[r]); }
+      if (MODE == 2) atomicAdd(dst + c + r, (double)t1[r]);
+      else { atomicAdd(dst + 2 * (c + r), (double)t1[r]); atomicAdd(dst + 2 * (c + r) + 1, (double)t2[r]); }
     }
   }
 }
 
-static int reduce_grid(long M, int C) {
+static int reduce_grid(long M, int C, int slots) {
   const int PL = 256 / (C / 4);
-  // Every block ends with 2*C fp64 atomics onto the SAME addresses: same-address atomics serialise (~20-50 ns each), so the
-  // grid is kept near one block per CU (measured: 2048 blocks cost ~60 us per launch in atomics alone, x180 launches per step).
-  long blocks = (M + (long)PL * 64 - 1) / ((long)PL * 64);  // >= 64 pixels per thread before another block (and its atomics) pays off
-  if (blocks > 256) blocks = 256;
+  long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);  // >= 16 pixels per thread before another block (and its atomics) pays off
+  const long cap = slots > 1 ? 1024 : 256;                  // un-replicated accumulator: keep the same-address atomic chain short
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
+static int slots_of(const msl_op& op, int idx) { return op.i[idx] > 0 ? op.i[idx] : 1; }
 
-// BN_STATS: p 0 z, 1 acc f64[2C] ; i 0 N,1 H,2 W,3 C,10 cs,11 co
+// BN_STATS: p 0 z, 1 acc f64[slots][2C] ; i 0 N,1 H,2 W,3 C,10 cs,11 co,21 slots (0 = 1)
 int msl_launch_bn_stats(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
-  const int C = op.i[3], cs = op.i[10], co = op.i[11];
+  const int C = op.i[3], cs = op.i[10], co = op.i[11], slots = slots_of(op, 21);
   MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && cs % 4 == 0 && co % 4 == 0 && co + C <= cs, "bn_stats: bad args");
-  dim3 grid(reduce_grid(M, C));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0);
-  else hipLaunchKernelGGL((chan_reduce_kernel<false, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0);
+  MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "bn_stats: too many accumulator slots");
+  dim3 grid(reduce_grid(M, C, slots));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots);
+  else hipLaunchKernelGGL((chan_reduce_kernel<false, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots);
   MSL_CHECK_LAUNCH("bn_stats");
   return MSL_OK;
 }
 
-// BN_FINALIZE: mean / invstd from the sums, running-stat update, accumulator reset.
+// BN_FINALIZE: mean / invstd from the sums (all slots), running-stat update, accumulator reset.
 __global__ void bn_finalize_kernel(double* __restrict__ acc, float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar, int C,
-                                   double M, float eps, float mom) {
+                                   double M, float eps, float mom, int slots) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const double mean = acc[2 * c] / M;
-  double var = acc[2 * c + 1] / M - mean * mean;
+  double a1 = 0.0, a2 = 0.0;
+  for (int j = 0; j < slots; ++j) {
+    double* q = acc + (long)j * 2 * C + 2 * c;
+    a1 += q[0]; a2 += q[1];
+    q[0] = 0.0; q[1] = 0.0;
+  }
+  const double mean = a1 / M;
+  double var = a2 / M - mean * mean;
   if (var < 0) var = 0;
   stats[2 * c] = (float)mean;
   stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -106,16 +135,14 @@ __global__ void bn_finalize_kernel(double* __restrict__ acc, float* __restrict__
     rmean[c] = (1.f - mom) * rmean[c] + mom * (float)mean;
     rvar[c] = (1.f - mom) * rvar[c] + mom * (float)(var * (M > 1 ? M / (M - 1) : 1.0));
   }
-  acc[2 * c] = 0.0;
-  acc[2 * c + 1] = 0.0;
 }
 
-// BN_FINALIZE: p 0 acc, 1 stats f32[2C], 2 running_mean|NULL, 3 running_var ; i 0 N,1 H,2 W,3 C ; f 0 eps, 1 momentum
+// BN_FINALIZE: p 0 acc, 1 stats f32[2C], 2 running_mean|NULL, 3 running_var ; i 0 N,1 H,2 W,3 C,21 slots ; f 0 eps, 1 momentum
 int msl_launch_bn_finalize(const msl_op& op, hipStream_t s) {
   const double M = (double)op.i[0] * op.i[1] * op.i[2];
-  const int C = op.i[3];
-  MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && (!op.p[2] || op.p[3]), "bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[1], (float*)op.p[2], (float*)op.p[3], C, M, op.f[0], op.f[1]);
+  const int C = op.i[3], slots = slots_of(op, 21);
+  MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && (!op.p[2] || op.p[3]) && slots <= MSL_MAX_SLOTS, "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[1], (float*)op.p[2], (float*)op.p[3], C, M, op.f[0], op.f[1], slots);
   MSL_CHECK_LAUNCH("bn_finalize");
   return MSL_OK;
 }
@@ -162,14 +189,15 @@ int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
   return MSL_OK;
 }
 
-// BN_ACT_BWD_REDUCE: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc f64[2C] ; i 0 N,1 H,2 W,3 C,10 z_cs,11 z_co,12 dy_cs,13 dy_co,18 act
+// BN_ACT_BWD_REDUCE: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc f64[slots][2C] ; i 0 N,1 H,2 W,3 C,10 z_cs,11 z_co,12 dy_cs,13 dy_co,18 act,21 slots
 int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
-  const int C = op.i[3];
+  const int C = op.i[3], slots = slots_of(op, 21);
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_reduce: bad args");
   MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "bn_act_bwd_reduce: bad views");
-  dim3 grid(reduce_grid(M, C));
-#define BR(F) hipLaunchKernelGGL((chan_reduce_kernel<F, 1>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0)
+  MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "bn_act_bwd_reduce: too many accumulator slots");
+  dim3 grid(reduce_grid(M, C, slots));
+#define BR(F) hipLaunchKernelGGL((chan_reduce_kernel<F, 1>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0, slots)
   if (op.dtype == MSL_F32) BR(true); else BR(false);
 #undef BR
   MSL_CHECK_LAUNCH("bn_act_bwd_reduce");
@@ -177,51 +205,71 @@ int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s) {
 }
 
 // BN_ACT_BWD_APPLY: dz = gamma*invstd*(g - s1/M - zhat*s2/M), g = dy*act'(u).  Also writes dgamma = s2, dbeta = s1 (block 0).
+// Threads are laid out like the reduction (channel quad x pixel lane): the per-channel constants are folded once into
+// registers (dz = k1*g' - k0 - k2*z with g' = dy*act'), then each thread streams PPT pixels of its channel quad.
 template <bool F32>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ z, const float* __restrict__ stats,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
-                                                               int dz_cs, int dz_co, int act) {
+                                                               int dz_cs, int dz_co, int act, int slots, int PPT) {
   const int C4 = C >> 2;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == 0 && dgamma) {
-    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)acc[2 * c]; dgamma[c] = (float)acc[2 * c + 1]; }
-  }
-  if (t >= M * C4) return;
-  const int c = (int)(t % C4) * 4;
-  const long p = t / C4;
-  float g[4], v[4];
-  ld4<F32>(dy, p * dy_cs + dy_co + c, g);
-  ld4<F32>(z, p * z_cs + z_co + c, v);
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int c = cq * 4;
+  if (pl >= PL) return;
+  float mu[4], is[4], ga[4], be[4], k0[4], k2[4];
   const float invM = 1.0f / (float)M;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float is = stats[2 * (c + r) + 1], ga = gamma[c + r];
-    const float zh = (v[r] - stats[2 * (c + r)]) * is;
-    float gg = g[r];
-    if (act) {
-      const float u = fmaf(ga, zh, beta[c + r]);
-      const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
-      gg *= sg * (1.0f + u * (1.0f - sg));
-    }
-    const float s1 = (float)acc[2 * (c + r)], s2 = (float)acc[2 * (c + r) + 1];
-    v[r] = ga * is * (gg - s1 * invM - zh * s2 * invM);
+    double a1 = 0.0, a2 = 0.0;
+    for (int j = 0; j < slots; ++j) { a1 += acc[(long)j * 2 * C + 2 * (c + r)]; a2 += acc[(long)j * 2 * C + 2 * (c + r) + 1]; }
+    mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r];
+    k0[r] = (float)a1 * invM;
+    k2[r] = (float)a2 * invM;
+    if (blockIdx.x == 0 && pl == 0 && dgamma) { dbeta[c + r] = (float)a1; dgamma[c + r] = (float)a2; }
   }
-  st4<F32>(dz, p * dz_cs + dz_co + c, v);
+  const long p0 = ((long)blockIdx.x * PL + pl) * PPT;
+  for (int k = 0; k < PPT; k += 4) {
+    float g[4][4], v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long p = p0 + k + u;
+      if (k + u < PPT && p < M) { ld4<F32>(dy, p * dy_cs + dy_co + c, g[u]); ld4<F32>(z, p * z_cs + z_co + c, v[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long p = p0 + k + u;
+      if (k + u < PPT && p < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zh = (v[u][r] - mu[r]) * is[r];
+          float gg = g[u][r];
+          if (act) {
+            const float uu = fmaf(ga[r], zh, be[r]);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-uu));
+            gg *= sg * (1.0f + uu * (1.0f - sg));
+          }
+          v[u][r] = ga[r] * is[r] * (gg - k0[r] - zh * k2[r]);
+        }
+        st4<F32>(dz, p * dz_cs + dz_co + c, v[u]);
+      }
+    }
+  }
 }
 
 // BN_ACT_BWD_APPLY: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc, 6 dz, 7 dgamma (dbeta = dgamma + i[20]) ; i as REDUCE + 14 dz_cs,15 dz_co, 20 dbeta offset (elements)
 int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
-  const int C = op.i[3];
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0, "bn_act_bwd_apply: bad args");
-  MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14], "bn_act_bwd_apply: bad dz view");
-  const long total = M * (C / 4);
-  dim3 grid((unsigned)((total + 255) / 256));
+  const int C = op.i[3], slots = slots_of(op, 21);
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_apply: bad args");
+  MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14] && slots <= MSL_MAX_SLOTS, "bn_act_bwd_apply: bad dz view");
+  const int PL = 256 / (C / 4);
+  const int PPT = M >= (long)PL * 2048 * 8 ? 8 : 4;  // pixels per thread: amortises the per-channel constants, keeps >= 2048 blocks on large layers
+  const long per_block = (long)PL * PPT;
+  dim3 grid((unsigned)((M + per_block - 1) / per_block));
   float* dgamma = (float*)op.p[7];
   float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
-#define BB(F) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<F>, grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18])
+#define BB(F) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<F>, grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT)
   if (op.dtype == MSL_F32) BB(true); else BB(false);
 #undef BB
   MSL_CHECK_LAUNCH("bn_act_bwd_apply");
@@ -233,9 +281,9 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[4] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[11] + C <= op.i[10], "colsum: bad args");
-  dim3 grid(reduce_grid(M, C));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19]);
-  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19]);
+  dim3 grid(reduce_grid(M, C, 1));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
+  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
   MSL_CHECK_LAUNCH("colsum");
   return MSL_OK;
 }

@@ -25,6 +25,7 @@ from .engine import View, _dt
 from .hiplib import MSL_BF16, MSL_F32
 
 BN_EPS, BN_MOM = params.BN_EPS, params.BN_MOMENTUM
+ACC_SLOTS = 8  # replicas of every BatchNorm reduction accumulator (same-address fp64 atomics serialise; see train_kernels.hip)
 
 
 def _align4(n: int) -> int:
@@ -237,7 +238,7 @@ class TrainPlan(graph.Visitor):
         self._bwd: List[List] = []  # per layer, list of ops / callables (emitted forward, replayed reversed)
         self._pack: List = []
         self._arena: Dict[int, dict] = {}
-        self._bwd_acc = torch.zeros(1 << 17, dtype=torch.float64, device=self.device)  # all backward reduction accumulators
+        self._bwd_acc = torch.zeros(1 << 19, dtype=torch.float64, device=self.device)  # all backward reduction accumulators
         self._bwd_acc_n = 0
         self._keep: List[torch.Tensor] = []
         self.grads: Dict[int, torch.Tensor] = {}
@@ -266,13 +267,13 @@ class TrainPlan(graph.Visitor):
         self._fwd[-1].append(op)
 
     def _acc(self, C) -> torch.Tensor:
-        t = torch.zeros(2 * C, dtype=torch.float64, device=self.device)
+        t = torch.zeros(2 * C * ACC_SLOTS, dtype=torch.float64, device=self.device)
         self._keep.append(t)
         return t
 
-    def _acc_bwd(self, C) -> torch.Tensor:
+    def _acc_bwd(self, C, slots=1) -> torch.Tensor:
         """fp64 accumulator of a backward reduction: a slice of ONE buffer that backward() zeroes with a single memset."""
-        n = 2 * C
+        n = 2 * C * slots
         assert self._bwd_acc_n + n <= self._bwd_acc.numel()
         t = self._bwd_acc[self._bwd_acc_n : self._bwd_acc_n + n]
         self._bwd_acc_n += n
@@ -310,9 +311,9 @@ class TrainPlan(graph.Visitor):
         stats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
         self._keep.append(stats)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C}
-        self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co}))
+        self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co, 21: ACC_SLOTS}))
         self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var")),
-                               i=dims, f=(BN_EPS, BN_MOM)))
+                               i={**dims, 21: ACC_SLOTS}, f=(BN_EPS, BN_MOM)))
         i = {**dims, 10: z.cs, 11: z.co, 12: y.cs, 13: y.co, 18: 1 if act else 0}
         rp = 0
         if res is not None:
@@ -329,8 +330,8 @@ class TrainPlan(graph.Visitor):
             first = self._init.first_write(gr)
             ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gr.t.data_ptr(), gy.t.data_ptr()),
                                       i={0: self.N, 1: y.H, 2: y.W, 3: C, 10: gr.cs, 11: gr.co, 12: gy.cs, 13: gy.co, 20: 1 if first else 0}))
-        acc = self._acc_bwd(C)
-        dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0}
+        acc = self._acc_bwd(C, ACC_SLOTS)
+        dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS}
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=pcommon + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
