@@ -255,7 +255,13 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
         with open(args.op_table, "w") as f:
             f.write(f"# train: per-op HIP-event times, batch {tr.batch}, {args.size}x{args.size}, {args.dtype}; total {total:.3f} ms\n")
             for tag, what, kind, ms_, it in rows:
-                f.write(f"{tag:5s} {names.get(kind, 'torch-attention'):22s} {ms_:9.4f} ms\n")
+                shape = ""
+                if what == "op":
+                    I = it.i
+                    shape = f"  N{I[0]} {I[1]}x{I[2]} C{I[3]}" + (f" -> {I[4]}x{I[5]} C{I[6]} k{I[7]} s{I[8]}" if kind in (hiplib.OP_CONV, hiplib.OP_CONV_WGRAD, hiplib.OP_DW_WGRAD, hiplib.OP_DWCONV) else "")
+                    if kind in (hiplib.OP_CONV, hiplib.OP_CONV_WGRAD):
+                        shape += f"  {conv_flops(it, kind == hiplib.OP_CONV_WGRAD) / (ms_ * 1e-3) / 1e12:7.1f} TF/s" + ("  dgrad" if kind == hiplib.OP_CONV and I[22] else "")
+                f.write(f"{tag:5s} {names.get(kind, 'torch-attention'):22s} {ms_:9.4f} ms{shape}\n")
     return roof
 
 
@@ -297,6 +303,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-op replay (for a clean rocprofv3 trace of the timed steps only)")
     ap.add_argument("--no-infer", action="store_true", help="train mode: skip the short predict run reported under 'infer'")
     ap.add_argument("--op-table", default="", help="write the per-op timing table to this file")
     ap.add_argument("--target-kept", type=float, default=12.0,
@@ -326,7 +333,7 @@ def main():
                                         f"calibrated random weights, 1-6 random polygons per slice",
                             "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}: slices sharded, one flat-gradient all-reduce per step"})
         if rank == 0:
-            line["roofline"] = train_roofline(tr, dbatch, args, value / world)
+            line["roofline"] = None if args.no_roofline else train_roofline(tr, dbatch, args, value / world)
             line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_train(state, batch)
             if not args.no_infer and world == 1:
                 del tr, dbatch
@@ -360,7 +367,7 @@ def main():
                                         f"calibrated random weights, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
                             "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"slice-sharded x{world}, no collective"})
         if rank == 0:
-            line["roofline"] = predict_roofline(eng, imgs, out, args, value / world)
+            line["roofline"] = None if args.no_roofline else predict_roofline(eng, imgs, out, args, value / world)
             line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_predict(pstate, host[: min(B, 64)])
     if rank == 0:
         print(json.dumps(line), flush=True)

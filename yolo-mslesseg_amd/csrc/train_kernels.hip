@@ -213,33 +213,38 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
                                                                int dz_cs, int dz_co, int act, int slots, int PPT) {
+  __shared__ float ks[2048];  // (s1, s2) per channel, summed over the accumulator slots
   const int C4 = C >> 2;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int c = cq * 4;
+  for (int v = threadIdx.x; v < 2 * C; v += 256) {
+    double a = 0.0;
+    for (int j = 0; j < slots; ++j) a += acc[(long)j * 2 * C + v];
+    ks[v] = (float)a;
+    if (blockIdx.x == 0 && dgamma) { if (v & 1) dgamma[v >> 1] = (float)a; else dbeta[v >> 1] = (float)a; }
+  }
+  __syncthreads();
   if (pl >= PL) return;
   float mu[4], is[4], ga[4], be[4], k0[4], k2[4];
   const float invM = 1.0f / (float)M;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int j = 0; j < slots; ++j) { a1 += acc[(long)j * 2 * C + 2 * (c + r)]; a2 += acc[(long)j * 2 * C + 2 * (c + r) + 1]; }
     mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r];
-    k0[r] = (float)a1 * invM;
-    k2[r] = (float)a2 * invM;
-    if (blockIdx.x == 0 && pl == 0 && dgamma) { dbeta[c + r] = (float)a1; dgamma[c + r] = (float)a2; }
+    k0[r] = ks[2 * (c + r)] * invM;
+    k2[r] = ks[2 * (c + r) + 1] * invM;
   }
-  const long p0 = ((long)blockIdx.x * PL + pl) * PPT;
+  const long p0 = (long)blockIdx.x * PL * PPT + pl;  // pixel of (k,u) = p0 + (k+u)*PL: every load instruction covers PL consecutive pixels
   for (int k = 0; k < PPT; k += 4) {
     float g[4][4], v[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long p = p0 + k + u;
-      if (k + u < PPT && p < M) { ld4<F32>(dy, p * dy_cs + dy_co + c, g[u]); ld4<F32>(z, p * z_cs + z_co + c, v[u]); }
+      const long p = p0 + (long)(k + u) * PL;
+      if (p < M) { ld4<F32>(dy, p * dy_cs + dy_co + c, g[u]); ld4<F32>(z, p * z_cs + z_co + c, v[u]); }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long p = p0 + k + u;
-      if (k + u < PPT && p < M) {
+      const long p = p0 + (long)(k + u) * PL;
+      if (p < M) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float zh = (v[u][r] - mu[r]) * is[r];
@@ -264,7 +269,7 @@ int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_apply: bad args");
   MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14] && slots <= MSL_MAX_SLOTS, "bn_act_bwd_apply: bad dz view");
   const int PL = 256 / (C / 4);
-  const int PPT = M >= (long)PL * 2048 * 8 ? 8 : 4;  // pixels per thread: amortises the per-channel constants, keeps >= 2048 blocks on large layers
+  const int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;  // pixels per thread (multiple of 4): amortises the per-channel constants, keeps >= 2048 blocks on large layers
   const long per_block = (long)PL * PPT;
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
   float* dgamma = (float*)op.p[7];
@@ -378,39 +383,52 @@ int msl_launch_upsample2x_bwd(const msl_op& op, hipStream_t s) {
 template <bool F32>
 __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const void* __restrict__ ybuf, const void* __restrict__ gbuf, float* __restrict__ scratch,
                                                             int N, int H, int W, int C, int cs, int co, int g_cs, int g_co) {
+  const int C4 = C >> 2;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)N * H * W * C) return;
-  const int c = (int)(t % C);
-  const long p = t / C;
+  if (t >= (long)N * H * W * C4) return;
+  const int c = (int)(t % C4) * 4;
+  const long p = t / C4;
   const int ix = (int)(p % W);
   const long q = p / W;
   const int iy = (int)(q % H), n = (int)(q / H);
-  float best[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  int arg[3] = {0, 0, 0};
+  float best[3][4];
+  int arg[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { best[k][r] = -__builtin_inff(); arg[k][r] = 0; }
   for (int dy = -6; dy <= 6; ++dy) {
     const int yy = iy + dy;
     if ((unsigned)yy >= (unsigned)H) continue;
     for (int dx = -6; dx <= 6; ++dx) {
       const int xx = ix + dx;
       if ((unsigned)xx >= (unsigned)W) continue;
-      const float v = Elem<F32>::ld(ybuf, (((long)n * H + yy) * W + xx) * cs + co + c);
+      float v[4];
+      ld4<F32>(ybuf, (((long)n * H + yy) * W + xx) * cs + co + c, v);
       const int ad = max(abs(dy), abs(dx)), pos = yy * W + xx;
-      if (v > best[2]) { best[2] = v; arg[2] = pos; }
-      if (ad <= 4 && v > best[1]) { best[1] = v; arg[1] = pos; }
-      if (ad <= 2 && v > best[0]) { best[0] = v; arg[0] = pos; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (v[r] > best[2][r]) { best[2][r] = v[r]; arg[2][r] = pos; }
+        if (ad <= 4 && v[r] > best[1][r]) { best[1][r] = v[r]; arg[1][r] = pos; }
+        if (ad <= 2 && v[r] > best[0][r]) { best[0][r] = v[r]; arg[0][r] = pos; }
+      }
     }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float g = Elem<F32>::ld(gbuf, p * g_cs + g_co + (k + 1) * C + c);
-    if (g != 0.f) atomicAdd(scratch + ((long)n * H * W + arg[k]) * C + c, g);
+    float g[4];
+    ld4<F32>(gbuf, p * g_cs + g_co + (k + 1) * C + c, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (g[r] != 0.f) atomicAdd(scratch + ((long)n * H * W + arg[k][r]) * C + c + r, g[r]);
   }
 }
 // p 0 y buffer (forward concat buffer), 1 grad buffer, 4 scratch f32 [N,H,W,C] (zeroed by the caller) ; i 0 N,1 H,2 W,3 C,10 cs,11 co,12 g_cs,13 g_co
 int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && op.i[11] + 4 * C <= op.i[10] && op.i[13] + 4 * C <= op.i[12], "sppf_pool_bwd: bad args");
-  const long total = (long)N * H * W * C;
+  MSL_REQUIRE(C % 4 == 0 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0, "sppf_pool_bwd: channels / views must be 4-aligned");
+  const long total = (long)N * H * W * (C / 4);
   dim3 grid((unsigned)((total + 255) / 256));
   if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_bwd_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
   else hipLaunchKernelGGL(sppf_pool_bwd_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
@@ -534,49 +552,67 @@ int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
 }
 
 // DW_WGRAD: dW[tap][c] += sum_p dz[p][c] * x[p + tap][c]   (depthwise 3x3, stride 1, pad 1; optional input channel map as DWCONV)
+// Thread = (channel quad, pixel lane) like the channel reductions: 8-byte loads, 36 fp32 partials per thread, LDS tree over
+// the pixel lanes, then one atomic per (tap, channel) and block.
 template <bool F32>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const void* __restrict__ x, const void* __restrict__ dz, float* __restrict__ dw, int N, int H, int W,
                                                        int C, int x_cs, int x_co, int z_cs, int z_co, int gsz, int gstride, int goff) {
-  __shared__ float red[9][256];
-  const int CL = C < 256 ? C : 256;  // channels per block (C <= 256 or multiple of 256)
-  const int c = blockIdx.y * CL + threadIdx.x % CL, pl = threadIdx.x / CL, PL = 256 / CL;
+  __shared__ float red[36][256];
+  const int C4 = C >> 2;
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int c = cq * 4;
   const int cin = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
-  float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const long M = (long)N * H * W;
+  float s[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[t][r] = 0.f;
+  const unsigned M = (unsigned)N * H * W;
   if (pl < PL) {
-    for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
-      const int ix = (int)(p % W);
-      const long q = p / W;
-      const int iy = (int)(q % H), n = (int)(q / H);
-      const float g = Elem<F32>::ld(dz, p * z_cs + z_co + c);
+    for (unsigned p = blockIdx.x * PL + pl; p < M; p += gridDim.x * PL) {
+      const unsigned q = p / (unsigned)W;
+      const int ix = (int)(p - q * W);
+      const unsigned n = q / (unsigned)H;
+      const int iy = (int)(q - n * H);
+      float g[4];
+      ld4<F32>(dz, (long)p * z_cs + z_co + c, g);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = iy - 1 + t / 3, xx = ix - 1 + t % 3;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) s[t] = fmaf(g, Elem<F32>::ld(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin), s[t]);
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          float xv[4];
+          ld4<F32>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin, xv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][r] = fmaf(g[r], xv[r], s[t][r]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = s[t];
-  __syncthreads();
-  if (threadIdx.x < CL) {
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float v = 0.f;
-      for (int j = 0; j < PL; ++j) v += red[t][j * CL + threadIdx.x];
-      atomicAdd(dw + t * C + c, v);
-    }
+    for (int r = 0; r < 4; ++r) red[t * 4 + r][threadIdx.x] = s[t][r];
+  __syncthreads();
+  // 36*C4 sums of PL partials each, spread over the whole block
+  for (int v = threadIdx.x; v < 36 * C4; v += 256) {
+    const int k = v / C4, q = v - k * C4;
+    float acc = 0.f;
+    for (int j = 0; j < PL; ++j) acc += red[k][j * C4 + q];
+    atomicAdd(dw + (k >> 2) * C + q * 4 + (k & 3), acc);
   }
 }
 // p 0 x, 1 dz, 4 dW f32 [9][C] ; i 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 z_cs,13 z_co,22 gsz,23 gstride,24 goff
 int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "dw_wgrad: bad args (C must divide or be a multiple of 256)");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, "dw_wgrad: bad args (C must be a multiple of 4, <= 1024)");
+  MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && (op.i[22] == 0 || (op.i[22] % 4 == 0 && op.i[23] % 4 == 0 && op.i[24] % 4 == 0)),
+              "dw_wgrad: views / channel map must be 4-aligned");
   const long M = (long)N * H * W;
-  const int CL = C < 256 ? C : 256, PL = 256 / CL;
-  long bx = (M + (long)PL * 64 - 1) / ((long)PL * 64);
-  if (bx > 1024) bx = 1024;
-  dim3 grid((unsigned)bx, (unsigned)(C / CL));
+  MSL_REQUIRE(M < (1L << 31), "dw_wgrad: too many pixels");
+  const int PL = 256 / (C / 4);
+  long bx = (M + (long)PL * 32 - 1) / ((long)PL * 32);
+  if (bx > 512) bx = 512;
+  dim3 grid((unsigned)bx);
   if (op.dtype == MSL_F32) hipLaunchKernelGGL(dw_wgrad_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24]);
   else hipLaunchKernelGGL(dw_wgrad_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24]);
   MSL_CHECK_LAUNCH("dw_wgrad");
@@ -584,49 +620,55 @@ int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
 }
 
 // STEM_WGRAD: dW[(ky,kx,ci)][co] += sum_p (u8[pix(p,ky,kx)][ci] / 255) * dz[p][co]   (3x3 stride 2 pad 1 on the uint8 image)
+// Thread = (tap-channel t of 27 padded to 32, pixel lane of 8): one byte of the image and the COUT gradients of the pixel
+// (a 32/64-byte broadcast load shared by the 32 t-lanes) per step, COUT fp32 partials per thread; the raw byte is used as
+// the multiplicand and the 1/255 applied once per block partial.
 template <bool F32, int COUT>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restrict__ x, const void* __restrict__ dz, float* __restrict__ dw, int N, int H, int W,
                                                          int Ho, int Wo, int z_cs, int z_co) {
-  __shared__ float red[27 * COUT];
-  for (int i = threadIdx.x; i < 27 * COUT; i += 256) red[i] = 0.f;
-  __syncthreads();
-  const int co = threadIdx.x % COUT, pl = threadIdx.x / COUT;
-  constexpr int PL = 256 / COUT;
-  float s[27];
+  __shared__ float red[8][32][COUT + 1];
+  const int t = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int tt = t < 27 ? t : 26;
+  const int ky = tt / 9, kx = (tt / 3) % 3, ci = tt % 3;
+  float s[COUT];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) s[t] = 0.f;
-  const long M = (long)N * Ho * Wo;
-  for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
-    const int ox = (int)(p % Wo);
-    const long q = p / Wo;
-    const int oy = (int)(q % Ho), n = (int)(q / Ho);
-    const float g = Elem<F32>::ld(dz, p * z_cs + z_co + co);
-    const uint8_t* img = x + (long)n * H * W * 3;
+  for (int i = 0; i < COUT; ++i) s[i] = 0.f;
+  const unsigned M = (unsigned)N * Ho * Wo;
+  for (unsigned p = blockIdx.x * 8 + pl; p < M; p += gridDim.x * 8) {
+    const unsigned q = p / (unsigned)Wo;
+    const int ox = (int)(p - q * Wo);
+    const unsigned n = q / (unsigned)Ho;
+    const int oy = (int)(q - n * Ho);
+    const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+    float xv = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) xv = (float)x[(((long)n * H + iy) * W + ix) * 3 + ci];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * 2 - 1 + ky;
-      if ((unsigned)iy >= (unsigned)H) continue;
+    for (int c4 = 0; c4 < COUT; c4 += 4) {
+      float g[4];
+      ld4<F32>(dz, (long)p * z_cs + z_co + c4, g);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * 2 - 1 + kx;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const uint8_t* px = img + ((long)iy * W + ix) * 3;
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) s[(ky * 3 + kx) * 3 + ci] = fmaf((float)px[ci] / 255.0f, g, s[(ky * 3 + kx) * 3 + ci]);
-      }
+      for (int r = 0; r < 4; ++r) s[c4 + r] = fmaf(xv, g[r], s[c4 + r]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 27; ++t) atomicAdd(&red[t * COUT + co], s[t]);
+  for (int i = 0; i < COUT; ++i) red[pl][t][i] = s[i];
   __syncthreads();
-  for (int i = threadIdx.x; i < 27 * COUT; i += 256) atomicAdd(dw + i, red[i]);
+  for (int v = threadIdx.x; v < 27 * COUT; v += 256) {
+    const int tq = v / COUT, co = v - tq * COUT;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += red[j][tq][co];
+    atomicAdd(dw + v, acc * (1.0f / 255.0f));
+  }
 }
 // p 0 x u8 [N,H,W,3], 1 dz, 4 dW f32 [27][Cout] ; i 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout,12 z_cs,13 z_co
 int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], Ho = op.i[4], Wo = op.i[5], Cout = op.i[6];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && (Cout == 16 || Cout == 32) && op.i[13] + Cout <= op.i[12], "stem_wgrad: bad args");
+  MSL_REQUIRE(op.i[12] % 4 == 0 && op.i[13] % 4 == 0, "stem_wgrad: dz view must be 4-aligned");
   const long M = (long)N * Ho * Wo;
-  long bx = (M + 1023) / 1024;
+  MSL_REQUIRE(M < (1L << 31), "stem_wgrad: too many pixels");
+  long bx = (M + 255) / 256;  // >= 32 pixels per pixel lane
   if (bx > 2048) bx = 2048;
 #define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13])
   if (op.dtype == MSL_F32) { if (Cout == 16) SW(true, 16); else SW(true, 32); }
