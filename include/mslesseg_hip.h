@@ -145,7 +145,14 @@ enum {
   MSL_OP_CAST_PAD = 29,           /* fp32 [R][K] → op dtype [Rpad][Kpad] (optionally transposed) */
   MSL_OP_GATHER_CAST = 30,        /* dst[i] = idx[i]>=0 ? src[idx[i]] : 0, cast to op dtype: packs weight images from the flat master buffer */
   MSL_OP_ADAMW = 31,              /* fused AdamW step over a flat fp32 range */
-  MSL_OP_EMA = 32                 /* e = d*e + (1-d)*p over a flat fp32 range */
+  MSL_OP_EMA = 32,                /* e = d*e + (1-d)*p over a flat fp32 range */
+  MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
+                                     [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
+                                     p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),
+                                     H, W, box cs/co, cls cs/co, coef cs/co, first anchor, stride, cls-gradient channels to write),
+                                     1 gt f32 [B][n][5] (cls, xyxy px; zero rows = padding), 2 masks u8 [B][mh][mw] (1 + instance index),
+                                     3 prototypes view, 4 prototype gradient view, 5 workspace, 6 items f32[8] (box, seg, cls, dfl, tss, n_fg);
+                                     i 0 B,1 A,2 nc,3 n,4 mh,5 mw,6 nlev,7 no_grad,10-13 proto/gradient cs,co,14 image h,15 image w */
 };
 
 #define MSL_PRED_STRIDE 40 /* floats per anchor row: x,y,w,h | conf | cls | 32 coeffs | 2 pad */
@@ -176,6 +183,9 @@ int msl_event_create(void** ev_out);
 int msl_event_record(void* ev, void* stream);
 int msl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
 int msl_event_destroy(void* ev);
+
+/* Bytes of device workspace MSL_OP_SEG_LOSS needs for B slices, A anchors and at most n_max instances per slice (negative = error). */
+int64_t msl_seg_loss_workspace(int32_t B, int32_t A, int32_t n_max);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ def built_lib():
 # ------------------------------------------------------------------------------------------- C-ABI
 def test_library_exports_every_declared_symbol(built_lib):
     header = (ROOT / "include" / "mslesseg_hip.h").read_text()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(msl_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(msl_\w+)\s*\(", header, flags=re.M))
     assert declared == set(hiplib.EXPORTS), declared ^ set(hiplib.EXPORTS)
     lib = ctypes.CDLL(str(built_lib))
     for sym in declared:

@@ -75,7 +75,9 @@ def assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, nc: 
     overlaps = torch.where(mask, ov, torch.zeros_like(ov))
     align = bbox_scores.pow(TAL_ALPHA) * overlaps.pow(TAL_BETA)
     # top-k per gt
-    topk_metrics, topk_idx = torch.topk(align, TAL_TOPK, dim=-1, largest=True)
+    # torch.topk leaves the order among equal values unspecified (and zero-valued candidates do tie early in training); a stable
+    # descending sort pins it to "lowest anchor index first", the rule the HIP loss op implements
+    topk_idx = torch.sort(align, dim=-1, descending=True, stable=True).indices[..., :TAL_TOPK]
     topk_mask = mask_gt.expand(-1, -1, TAL_TOPK).bool()
     topk_idx = topk_idx.masked_fill(~topk_mask, 0)
     count = torch.zeros(bs, n_max, A, dtype=torch.int8, device=dev)
@@ -153,7 +155,7 @@ def segmentation_loss(levels: List[Tuple[torch.Tensor, torch.Tensor, torch.Tenso
 
     # ---- decode predicted boxes (grid units)
     proj = torch.arange(REG_MAX, device=dev, dtype=torch.float32)
-    dist = pred_distri.view(B, A, 4, REG_MAX).softmax(3).matmul(proj)
+    dist = (pred_distri.view(B, A, 4, REG_MAX).softmax(3) * proj).sum(3)  # expectation over the bins (a plain weighted sum: no GEMV launch)
     pred_bboxes = torch.cat((anchor_points - dist[..., :2], anchor_points + dist[..., 2:]), -1)
 
     target_bboxes, target_scores, fg_mask, target_gt_idx = assign(

@@ -32,6 +32,7 @@ from . import data as D
 from . import hiplib, params
 from .hiplib import MSL_BF16, MSL_F32
 from .loss import segmentation_loss
+from .segloss import SegLossOp, pack_targets
 from .trainprog import ParamStore, TrainPlan
 
 RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss", "metrics/precision(B)", "metrics/recall(B)",
@@ -131,6 +132,10 @@ class Trainer:
         self.dtype = yolo.dtype
         S = self.hyp["imgsz"]
         self.plan = TrainPlan(self.store, self.batch, S, S, self.dtype)
+        lv = [self.plan.levels[i] for i in sorted(self.plan.levels)]
+        self.loss_op = SegLossOp(lv, [tuple(self.plan.G(v) for v in l) for l in lv], self.plan.proto_view, self.plan.G(self.plan.proto_view), self.nc, S, S,
+                                 self.dtype, self.device)
+        self.torch_loss = False  # True: the autograd tensor-op loss of loss.py (the fp32 reference of the HIP loss op) — tests only
         # ---- optimizer ('auto' rule) and schedule
         per_rank = math.ceil(len(self.ds) / self.world)
         self.nb = max(math.ceil(per_rank / self.batch), 1)
@@ -173,16 +178,24 @@ class Trainer:
     # ------------------------------------------------------------------ one optimisation step
     def to_device(self, batch):
         """numpy batch (data.collate) → device tensors; the bench keeps one such batch resident in HBM."""
-        return {k: (torch.from_numpy(v).to(self.device, non_blocking=True) if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+        out = {k: (torch.from_numpy(v).to(self.device, non_blocking=True) if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+        S = self.hyp["imgsz"]
+        gt, _ = pack_targets(batch["batch_idx"], batch["cls"], batch["bboxes"], len(batch["masks"]), S, S)
+        out["gt"] = torch.from_numpy(gt).to(self.device, non_blocking=True)
+        return out
 
     def forward_backward(self, batch) -> torch.Tensor:
-        """HIP forward → loss (device tensor ops) → HIP backward.  Gradients ACCUMULATE into store.g."""
+        """HIP forward → HIP loss op (value + gradient of the head outputs) → HIP backward.  Gradients ACCUMULATE into store.g."""
         plan = self.plan
         if not torch.is_tensor(batch["img"]):
             batch = self.to_device(batch)
         plan.in_view.t.copy_(batch["img"].reshape(-1), non_blocking=True)
         plan.pack()
         plan.forward()
+        if not self.torch_loss:
+            items = self.loss_op(batch["gt"], batch["masks"])[:4].clone()  # writes d(loss)/d(head outputs) into the plan's gradient views
+            plan.backward()
+            return items
         outs = plan.head_outputs()
         leaves = [[t.detach().requires_grad_() for t in lv] for lv in outs["levels"]]
         proto = outs["proto"].detach().float().requires_grad_()
@@ -250,10 +263,8 @@ class Trainer:
             self.plan.in_view.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
             self.plan.pack()
             self.plan.forward()
-            outs = self.plan.head_outputs()
-            tb = {k: (torch.from_numpy(v).to(self.device) if isinstance(v, np.ndarray) else v) for k, v in batch.items() if k != "img"}
-            _, items = segmentation_loss(outs["levels"], outs["proto"], tb, self.nc)
-            tot += items.cpu().numpy()
+            db = self.to_device({k: v for k, v in batch.items() if k != "img"})
+            tot += self.loss_op(db["gt"], db["masks"], no_grad=True)[:4].cpu().numpy()
             cnt += 1
         st.p.copy_(keep_p)
         st.b.copy_(keep_b)  # validation must not move the running statistics
