@@ -139,7 +139,9 @@ enum {
   MSL_OP_ADD_VIEW = 23,           /* dst view (+)= src view (residual / concat gradient fan-in) */
   MSL_OP_UPSAMPLE2X_BWD = 24,     /* dx += 2x2 sums of dy */
   MSL_OP_SPPF_POOL_BWD = 25,      /* arg-max routing of the three pooled gradients into a fp32 scratch */
-  MSL_OP_CONV_WGRAD = 26,         /* dW f32[Cout][(ky,kx,ci)] += sum_p dz[p][co]*x[pix(p,ky,kx)][ci]  (fp32 MFMA, pixel contraction) */
+  MSL_OP_CONV_WGRAD = 26,         /* dW f32[Cout][(ky,kx,ci)] += sum_p dz[p][co]*x[pix(p,ky,kx)][ci]: pixel contraction on the bf16 MFMA via LDS
+                                     transposed reads (bf16 tensors; 3x3/p1 s1|s2, 2x2/p0/s2, 1x1), else on the fp32 MFMA.  Optional p 5 = scratch
+                                     for per-workgroup partial sums (i 21 = its capacity in floats): stores + a reduction instead of atomics */
   MSL_OP_DW_WGRAD = 27,           /* depthwise 3x3 weight gradient */
   MSL_OP_STEM_WGRAD = 28,         /* stem weight gradient from the uint8 image */
   MSL_OP_CAST_PAD = 29,           /* fp32 [R][K] → op dtype [Rpad][Kpad] (optionally transposed) */

@@ -333,6 +333,22 @@ WGRAD_CASES = [
     (1, 40, 40, 64, 256, 1, 1, 256, 128, 256, 0), # qkv-like 1x1 from a concat slice
     (2, 21, 35, 32, 32, 3, 2, 32, 0, 32, 0),      # stride 2, odd sizes (parity-split halo in the bf16 kernel)
     (1, 64, 96, 16, 32, 3, 2, 16, 0, 32, 0),      # model.1-like
+    # every LDS-slot width pair (chunks of 8 channels: <=16 / <=32 / <=64) and wave layout of the double-buffered kernel
+    (1, 20, 20, 64, 32, 3, 1, 64, 0, 32, 0),
+    (1, 20, 20, 32, 64, 3, 1, 32, 0, 64, 0),
+    (2, 10, 37, 32, 32, 3, 1, 32, 0, 32, 0),
+    (1, 12, 12, 16, 64, 3, 1, 16, 0, 64, 0),
+    (1, 12, 12, 64, 16, 3, 1, 64, 0, 16, 0),
+    (1, 30, 30, 32, 32, 1, 1, 32, 0, 32, 0),
+    (1, 25, 25, 16, 32, 1, 1, 16, 0, 32, 0),
+    (1, 25, 25, 64, 24, 1, 1, 64, 0, 24, 0),
+    (1, 22, 22, 64, 32, 3, 2, 64, 0, 32, 0),
+    (1, 22, 22, 128, 256, 3, 2, 128, 0, 256, 0),  # several ci / co blocks
+    (8, 96, 96, 64, 64, 3, 1, 64, 0, 64, 0),      # runs of 3 tiles per workgroup: the pipelined (double-buffered) loop
+    (8, 96, 96, 32, 16, 3, 2, 32, 0, 16, 0),
+    (6, 80, 80, 96, 128, 1, 1, 96, 0, 128, 0),
+    (2, 24, 40, 64, 64, 2, 2, 64, 0, 64, 0),      # 2x2 stride 2 pad 0: the ConvTranspose2d weight gradient with swapped operands
+    (4, 96, 96, 32, 16, 2, 2, 32, 0, 16, 0),
 ]
 
 
@@ -341,7 +357,7 @@ WGRAD_CASES = [
 def test_conv_wgrad(case, dtype):
     N, H, W, Cin, Cout, k, s, x_cs, x_co, z_cs, z_co = case
     g = torch.Generator().manual_seed(hash(case) % (2**31))
-    pad = k // 2
+    pad = k // 2 if k != 2 else 0
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     xbuf = _rand_act((N, H, W, x_cs), dtype, g)
     zbuf = _rand_act((N, Ho, Wo, z_cs), dtype, g)
@@ -358,3 +374,12 @@ def test_conv_wgrad(case, dtype):
     tol = 1e-4 if dtype == MSL_F32 else 2e-3  # bf16 inputs are exact in both; only fp32 summation order differs
     err = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
     assert err < tol, f"wgrad {case}: rel err {err:.2e}"
+    # same op with a scratch buffer: per-workgroup partial matrices + reduction instead of atomics (the path the training plan uses)
+    scratch = torch.full((300 * Cout * k * k * Cin,), float("nan"), device=DEV)
+    dw2 = torch.full((Cout, k * k * Cin), 0.5, device=DEV)
+    op2 = hiplib.make_op(hiplib.OP_CONV_WGRAD, dtype, p=(xd.data_ptr(), zd.data_ptr(), 0, 0, dw2.data_ptr(), scratch.data_ptr()),
+                         i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: k, 8: s, 9: pad, 10: x_cs, 11: x_co, 12: z_cs, 13: z_co, 21: scratch.numel()})
+    hiplib.launch(op2, _stream())
+    torch.cuda.synchronize()
+    err2 = float((dw2.cpu() - 0.5 - ref).abs().max() / (ref.abs().max() + 1e-12))
+    assert err2 < tol, f"wgrad (scratch) {case}: rel err {err2:.2e}"

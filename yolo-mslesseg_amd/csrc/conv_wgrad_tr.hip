@@ -3,19 +3,24 @@
 //   dW[co][(ky,kx,ci)] += sum_p dz[p][co] * x[pix(p,ky,kx)][ci]
 //
 // NHWC keeps CHANNELS contiguous, but this contraction runs over PIXELS, so neither operand is K-contiguous in memory.
-// A workgroup stages an 8x32-pixel tile of dz (64 output channels) and the matching x halo tile (64 input channels) in LDS
-// once — with coalesced 16-byte LDS-DMA copies along the channel axis — and every wave then pulls its MFMA fragments
-// with ds_read_b64_tr_b16: a 4-row x 16-column block read column-major, i.e. 4 consecutive PIXELS of one channel per lane.
-// Two such reads give the 8 k-values of v_mfma_f32_16x16x32_bf16.  All 9 taps reuse the one staged halo (they are shifted
-// windows of it), so staging traffic per MFMA drops 9x against a per-tap formulation, and the arithmetic runs at the bf16
-// MFMA rate instead of the fp32 one.  A wave owns one 16-channel co tile x four 16-channel ci tiles x all taps
-// (144 accumulator registers); workgroups loop over several pixel tiles before flushing with fp32 atomics.
+// A workgroup (8 waves) walks a run of 4x32-pixel output tiles (2x32 for stride 2).  Each tile of dz and the matching x halo
+// tile are copied to LDS with coalesced 16-byte LDS-DMA transfers along the channel axis, DOUBLE-BUFFERED: the DMA of
+// tile i+1 is in flight while tile i is multiplied.  Waves pull MFMA fragments with ds_read_b64_tr_b16 (a 4-pixel x 16-channel
+// block read column-major: 4 consecutive PIXELS of one channel per lane; two reads = the 8 k-values of
+// v_mfma_f32_16x16x32_bf16).  Fragment reuse is what keeps the LDS pipe below the MFMA pipe:
+//   * a wave owns up to 2 co-tiles x 2 ci-tiles (16 channels each) x all taps — every A/B fragment feeds 2 MFMAs;
+//   * the 3x3 taps are shifted windows of ONE staged halo, and a wave iterates over HALO rows: the x fragments of halo row h
+//     serve the output rows h, h-1, h-2 (taps ky = 0, 1, 2), whose dz fragments stay in registers.
+// 64x64 channels, 3x3: 16 fragment reads per 36 MFMAs (the previous kernel: 74 per 36).  Narrow layers shrink the LDS slot
+// (ZC / XC 16-byte chunks per pixel) and spread the 8 waves over tile rows instead of channel tiles.  Accumulators
+// (<= 144 VGPRs) live across the whole tile run and are flushed once with fp32 atomics.
 //
 // Replaces torch.nn.Conv2d's weight gradient inside ultralytics' trainer [UPSTREAM], reached from model.train()
-// [REF yolo_mslesseg/scripts/train.py:358-366].  fp32 tensors and strided convs keep the fp32 kernel in train_kernels.hip.
+// [REF yolo_mslesseg/scripts/train.py:358-366].  fp32 tensors and other geometries keep the fp32 kernel in train_kernels.hip.
 #include "msl_common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 __device__ __attribute__((aligned(16))) unsigned wg_zero_page[4];  // source of padding for LDS-DMA gathers (per translation unit: no RDC)
 
 struct WgTrArgs {
@@ -25,122 +30,296 @@ struct WgTrArgs {
   int N, H, W, Cin, Cout, Ho, Wo;
   int x_cs, x_co, z_cs, z_co, K;
   int tiles_x, tiles_y, tiles_per_block;
-  long total_tiles;
+  long total_tiles, M;
+  float* scratch;  // [gridDim.x][Cout][K] per-workgroup partial sums (NULL: flush with atomics)
 };
 
-template <int TAPS, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgTrArgs a) {
-  constexpr int TH = S == 1 ? 8 : 4, TW = 32, PITCH = 144;    // bytes per LDS slot: 64 bf16 + 16 B pad (9 x 16-byte chunks)
-  // x image rows: stride 1 → TW+2 halo columns; stride 2 → the 2*TW+1 halo columns split by parity ([33 even | 33 odd]) so
-  // that 8 consecutive OUTPUT pixels read 8 consecutive slots for every tap
-  constexpr int ROWP = TAPS == 9 ? (S == 1 ? TW + 2 : 66) : TW, ROWS = TAPS == 9 ? (S == 1 ? TH + 2 : 2 * TH + 1) : TH;
-  constexpr int Z_SLOTS = TH * TW, X_SLOTS = ROWS * ROWP;
-  constexpr int Z_PIECES = (Z_SLOTS * 9 + 63) / 64, X_PIECES = (X_SLOTS * 9 + 63) / 64;
+// bytes per LDS slot for C 16-byte channel chunks: data + padding such that the 4 slots x 32 bytes one transposed read touches
+// per 16 lanes fall into distinct banks
+__host__ __device__ constexpr int wg_pitch(int chunks) { return chunks == 4 ? 96 : chunks * 16 + 16; }
+
+template <int TAPS, int S, int ZC, int XC>
+struct WgCfg {
+  static constexpr int KD = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1), PAD = TAPS == 9 ? 1 : 0;  // 3x3/p1 (s1|s2), 2x2/p0/s2, 1x1/p0/s1
+  static constexpr int TH = S == 2 ? 2 : 4, TW = 32;
+  static constexpr int PZ = wg_pitch(ZC), PX = wg_pitch(XC), CPZ = PZ / 16, CPX = PX / 16;
+  static constexpr int HALF = KD == 3 ? 33 : 32;  // stride 2: halo columns stored parity-split [HALF even | HALF odd]
+  static constexpr int ROWP = S == 1 ? TW + KD - 1 : 2 * HALF;
+  static constexpr int ROWS = S == 1 ? TH + KD - 1 : 2 * TH + KD - 2;
+  static constexpr int Z_SLOTS = TH * TW, X_SLOTS = ROWS * ROWP;
+  static constexpr int Z_PIECES = (Z_SLOTS * CPZ + 63) / 64, X_PIECES = (X_SLOTS * CPX + 63) / 64;
+  static constexpr int BUF = (Z_PIECES + X_PIECES) * 1024;
+  static constexpr int COT = (ZC + 1) / 2, CIT = (XC + 1) / 2;  // 16-channel tiles of the block
+  static constexpr int TCO0 = COT >= 2 ? 2 : 1, TCI0 = CIT >= 2 ? 2 : 1;
+  static constexpr int TCO = ((COT / TCO0) * (CIT / TCI0) * TH >= 8) ? TCO0 : 1;  // give up register blocking before idling waves
+  static constexpr int TCI = ((COT / TCO) * (CIT / TCI0) * TH >= 8) ? TCI0 : 1;
+  static constexpr int WCO = COT / TCO, WCI = CIT / TCI;
+  static constexpr int WR = (8 / (WCO * WCI)) < TH ? (8 / (WCO * WCI)) : TH;  // waves along tile rows
+  static constexpr int RPW = TH / WR;                                            // output rows per wave
+  static constexpr int ACTIVE = WCO * WCI * WR;
+};
+
+template <int TAPS, int S, int ZC, int XC>
+__global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
+  typedef WgCfg<TAPS, S, ZC, XC> C;
+  constexpr int TH = C::TH, TW = C::TW, PZ = C::PZ, PX = C::PX, ROWP = C::ROWP, TCO = C::TCO, TCI = C::TCI, RPW = C::RPW, KD = C::KD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_z = smem;
-  unsigned char* s_x = smem + Z_PIECES * 1024;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
   const int coB = (a.Cout + 63) / 64;
   const int cob = blockIdx.y % coB, cib = blockIdx.y / coB;
-  const int co_tiles = min(4, (a.Cout - cob * 64 + 15) / 16), ci_tiles = min(4, (a.Cin - cib * 64 + 15) / 16);
-  const bool wave_active = wave < co_tiles;  // wave-uniform
+  const int wr = wave % C::WR, wci = (wave / C::WR) % C::WCI, wco = wave / (C::WR * C::WCI);
+  const bool wave_active = wave < C::ACTIVE;  // wave-uniform
 
-  f32x4 acc[TAPS][4];
+  f32x4 acc[TAPS][TCO][TCI];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < TCI; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const long tile0 = (long)blockIdx.x * a.tiles_per_block;
-  for (int it = 0; it < a.tiles_per_block; ++it) {
-    const long tile = tile0 + it;
-    if (tile >= a.total_tiles) break;  // block-uniform
-    const int txi = (int)(tile % a.tiles_x);
-    const long tq = tile / a.tiles_x;
-    const int tyi = (int)(tq % a.tiles_y), n = (int)(tq / a.tiles_y);
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    __syncthreads();
-    // ---- stage dz tile: slot = row*32 + col, 9 chunks of 16 B per slot (chunk 8 = padding)
-    for (int pc = wave; pc < Z_PIECES; pc += 4) {
-      const int cidx = pc * 64 + lane, slot = cidx / 9, ch = cidx - slot * 9;
-      const int oy = oy0 + (slot >> 5), ox = ox0 + (slot & 31);
-      const bool ok = slot < Z_SLOTS && ch < 8 && oy < a.Ho && ox < a.Wo && cob * 64 + ch * 8 < a.Cout;
-      const char* src = ok ? a.dz + ((((long)n * a.Ho + oy) * a.Wo + ox) * a.z_cs + a.z_co + cob * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
+  auto stage = [&](long tile, unsigned char* buf) __attribute__((always_inline)) {
+    unsigned char* s_z = buf;
+    unsigned char* s_x = buf + C::Z_PIECES * 1024;
+    int n, oy0, ox0;
+    long p0 = 0;
+    if constexpr (TAPS == 1) {
+      p0 = tile * (TH * TW);  // 1x1: the pixels are a flat list, a "row" is just 32 consecutive ones
+      n = 0; oy0 = 0; ox0 = 0;
+    } else {
+      const int txi = (int)(tile % a.tiles_x);
+      const long tq = tile / a.tiles_x;
+      const int tyi = (int)(tq % a.tiles_y);
+      n = (int)(tq / a.tiles_y);
+      oy0 = tyi * TH; ox0 = txi * TW;
+    }
+    for (int pc = wave; pc < C::Z_PIECES; pc += 8) {
+      const int cidx = pc * 64 + lane, slot = cidx / C::CPZ, ch = cidx - slot * C::CPZ;
+      bool ok = slot < C::Z_SLOTS && ch < ZC && cob * 64 + ch * 8 < a.Cout;
+      long pix;
+      if constexpr (TAPS == 1) {
+        pix = p0 + slot;
+        ok = ok && pix < a.M;
+      } else {
+        const int oy = oy0 + (slot >> 5), ox = ox0 + (slot & 31);
+        ok = ok && oy < a.Ho && ox < a.Wo;
+        pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+      }
+      const char* src = ok ? a.dz + (pix * a.z_cs + a.z_co + cob * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_z + pc * 1024), 16, 0, 0);
     }
-    // ---- stage x (halo) tile
-    for (int pc = wave; pc < X_PIECES; pc += 4) {
-      const int cidx = pc * 64 + lane, slot = cidx / 9, ch = cidx - slot * 9;
-      const int r = slot / ROWP;
-      int c = slot - r * ROWP;
-      if constexpr (S == 2) c = c < 33 ? 2 * c : 2 * (c - 33) + 1;  // parity-split image → halo column
-      const int iy = oy0 * S + r - (TAPS == 9 ? 1 : 0), ix = ox0 * S + c - (TAPS == 9 ? 1 : 0);
-      const bool ok = slot < X_SLOTS && ch < 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cib * 64 + ch * 8 < a.Cin;
-      const char* src = ok ? a.x + ((((long)n * a.H + iy) * a.W + ix) * a.x_cs + a.x_co + cib * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
+    for (int pc = wave; pc < C::X_PIECES; pc += 8) {
+      const int cidx = pc * 64 + lane, slot = cidx / C::CPX, ch = cidx - slot * C::CPX;
+      bool ok = slot < C::X_SLOTS && ch < XC && cib * 64 + ch * 8 < a.Cin;
+      long pix;
+      if constexpr (TAPS == 1) {
+        pix = p0 + slot;
+        ok = ok && pix < a.M;
+      } else {
+        const int r = slot / ROWP;
+        int c = slot - r * ROWP;
+        if constexpr (S == 2) c = c < C::HALF ? 2 * c : 2 * (c - C::HALF) + 1;  // parity-split image → halo column
+        const int iy = oy0 * S + r - C::PAD, ix = ox0 * S + c - C::PAD;
+        ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        pix = ((long)n * a.H + iy) * a.W + ix;
+      }
+      const char* src = ok ? a.x + (pix * a.x_cs + a.x_co + cib * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_x + pc * 1024), 16, 0, 0);
     }
+  };
+
+  auto rd = [&](const unsigned char* p, int pitch) __attribute__((always_inline)) -> s16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * pitch));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  auto compute = [&](const unsigned char* buf) __attribute__((always_inline)) {
+    const unsigned char* s_z = buf;
+    const unsigned char* s_x = buf + C::Z_PIECES * 1024;
+    const int r0 = wr * RPW;
+    // dz fragments of this wave's output rows: lane group g owns pixels 8g..8g+7 of the 32-pixel row
+    s16x8 afr[RPW][TCO];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+        afr[r][i] = rd(s_z + ((r0 + r) * TW + 8 * g + q) * PZ + ((wco * TCO + i) * 16 + 4 * pp) * 2, PZ);
+    if constexpr (TAPS == 1) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        s16x8 bfr[TCI];
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) bfr[j] = rd(s_x + ((r0 + r) * TW + 8 * g + q) * PX + ((wci * TCI + j) * 16 + 4 * pp) * 2, PX);
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+          for (int j = 0; j < TCI; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[r][i]), __builtin_bit_cast(bf16x8, bfr[j]), acc[0][i][j], 0, 0, 0);
+      }
+    } else {
+      constexpr int HR = S == 1 ? RPW + KD - 1 : 2 * RPW + KD - 2;  // halo rows this wave touches
+#pragma unroll
+      for (int h = 0; h < HR; ++h) {
+        const int hrow = (S == 1 ? r0 : 2 * r0) + h;
+        s16x8 bfr[KD][TCI];
+#pragma unroll
+        for (int tx = 0; tx < KD; ++tx) {
+          const int xslot = S == 1 ? hrow * ROWP + tx + 8 * g + q : hrow * ROWP + (tx & 1) * C::HALF + (tx >> 1) + 8 * g + q;
+#pragma unroll
+          for (int j = 0; j < TCI; ++j) bfr[tx][j] = rd(s_x + xslot * PX + ((wci * TCI + j) * 16 + 4 * pp) * 2, PX);
+        }
+#pragma unroll
+        for (int ty = 0; ty < KD; ++ty) {
+          const int d = h - ty;  // halo row = S * output row + ky
+          if (d < 0 || d % S != 0 || d / S >= RPW) continue;
+          const int r = d / S;
+#pragma unroll
+          for (int tx = 0; tx < KD; ++tx)
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+              for (int j = 0; j < TCI; ++j)
+                acc[ty * KD + tx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[r][i]), __builtin_bit_cast(bf16x8, bfr[tx][j]),
+                                                                                   acc[ty * KD + tx][i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  const long tile0 = (long)blockIdx.x * a.tiles_per_block;
+  long tile_end = tile0 + a.tiles_per_block;
+  if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+  if (tile0 < tile_end) {
+    stage(tile0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!wave_active) continue;  // wave-uniform: EXEC stays full for the transposed reads below
-    // ---- K loop: one tile row (32 pixels) per step; lane group g owns pixels 8g..8g+7 of the row
-#pragma unroll 1
-    for (int row = 0; row < TH; ++row) {
-      const int zslot = row * TW + 8 * g + q;
-      const unsigned char* zp = s_z + zslot * PITCH + (wave * 16 + 4 * pp) * 2;
-      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)zp);
-      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(zp + 4 * PITCH));
-      typedef __attribute__((ext_vector_type(8))) short s16x8;
-      const s16x8 afrag = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    int cur = 0;
+    for (long tile = tile0; tile < tile_end; ++tile) {  // block-uniform trip count
+      if (tile + 1 < tile_end) stage(tile + 1, smem + (cur ^ 1) * C::BUF);
+      if (wave_active) compute(smem + cur * C::BUF);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // ---- waves that split the tile rows hold partial sums of the same outputs: fold them into wave row 0 through LDS
+  if constexpr (C::WR > 1) {
+    constexpr int TG = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);  // taps per round (bounds the LDS footprint: <= 49 KB)
+    constexpr int PER = TG * TCO * TCI * 4;                    // floats per lane and round
+    float* red = (float*)smem;
+    const int slot = (((wr - 1) * C::WCO + wco) * C::WCI + wci) * PER;
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int ty = TAPS == 9 ? t / 3 : 0, tx = TAPS == 9 ? t % 3 : 0;
-        const int xslot = S == 1 ? (row + ty) * ROWP + tx + 8 * g + q : (2 * row + ty) * ROWP + (tx & 1) * 33 + (tx >> 1) + 8 * g + q;
-        const unsigned char* xp = s_x + xslot * PITCH + (4 * pp) * 2;
+    for (int t0 = 0; t0 < TAPS; t0 += TG) {
+      __syncthreads();  // tile buffers / previous round are free
+      if (wave_active && wr > 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c < ci_tiles) {  // block-uniform
-            s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xp + c * 32));
-            s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xp + c * 32 + 4 * PITCH));
-            const s16x8 bfrag = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfrag), acc[t][c], 0, 0, 0);
-          }
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TCI; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) red[(slot + ((t * TCO + i) * TCI + j) * 4 + r) * 64 + lane] = acc[t0 + t][i][j][r];
+      }
+      __syncthreads();
+      if (wave_active && wr == 0) {
+#pragma unroll
+        for (int w = 1; w < C::WR; ++w) {
+          const int so = (((w - 1) * C::WCO + wco) * C::WCI + wci) * PER;
+#pragma unroll
+          for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+              for (int j = 0; j < TCI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t0 + t][i][j][r] += red[(so + ((t * TCO + i) * TCI + j) * 4 + r) * 64 + lane];
         }
       }
     }
   }
-  if (!wave_active) return;
-  // ---- flush: D[row = co][col = ci], col = lane&15, row = 4*(lane>>4)+reg
+  if (!wave_active || wr != 0) return;
+  // ---- flush: D[row = co][col = ci], col = lane&15, row = 4*(lane>>4)+reg.  With a scratch buffer every workgroup stores its
+  // partial matrix (no contention; wgrad_reduce_kernel sums them), otherwise fp32 atomics straight into dW.
+  float* dst = a.scratch ? a.scratch + (long)blockIdx.x * a.Cout * a.K : a.dw;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int ci = cib * 64 + c * 16 + li;
-      if (c >= ci_tiles || ci >= a.Cin) continue;
+    for (int i = 0; i < TCO; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = cob * 64 + wave * 16 + g * 4 + r;
-        if (co < a.Cout) atomicAdd(a.dw + (long)co * a.K + t * a.Cin + ci, acc[t][c][r]);
+      for (int j = 0; j < TCI; ++j) {
+        const int ci = cib * 64 + (wci * TCI + j) * 16 + li;
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = cob * 64 + (wco * TCO + i) * 16 + g * 4 + r;
+          if (co < a.Cout) {
+            if (a.scratch) dst[(long)co * a.K + t * a.Cin + ci] = acc[t][i][j][r];
+            else atomicAdd(dst + (long)co * a.K + t * a.Cin + ci, acc[t][i][j][r]);
+          }
+        }
       }
-    }
 }
 
-template <int TAPS, int S>
+// dW[i] += sum over the workgroup partials scratch[b][i]; blockIdx.y splits the partials into runs of 32 (few atomics per output)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dw, long size, int nb) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= size) return;
+  const int b0 = blockIdx.y * 32, b1 = min(nb, b0 + 32);
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i + 3 < size) {
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) {
+      const float4 v = *(const float4*)(scratch + (long)b * size + i);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    atomicAdd(dw + i, s4.x); atomicAdd(dw + i + 1, s4.y); atomicAdd(dw + i + 2, s4.z); atomicAdd(dw + i + 3, s4.w);
+  } else {
+    for (long k = i; k < size; ++k) {
+      float v = 0.f;
+      for (int b = b0; b < b1; ++b) v += scratch[(long)b * size + k];
+      atomicAdd(dw + k, v);
+    }
+  }
+}
+
+template <int TAPS, int S, int ZC, int XC>
 static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
-  constexpr int TH = S == 1 ? 8 : 4;
-  constexpr int ROWP = TAPS == 9 ? (S == 1 ? 34 : 66) : 32, ROWS = TAPS == 9 ? (S == 1 ? TH + 2 : 2 * TH + 1) : TH;
-  constexpr int LDS = ((TH * 32 * 9 + 63) / 64 + (ROWS * ROWP * 9 + 63) / 64) * 1024;
+  typedef WgCfg<TAPS, S, ZC, XC> C;
+  constexpr int RED = (C::WR - 1) * C::WCO * C::WCI * (TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1)) * C::TCO * C::TCI * 4 * 256;  // cross-wave fold
+  constexpr int LDS = 2 * C::BUF > RED ? 2 * C::BUF : RED;
+  static_assert(LDS <= 160 * 1024, "tile does not fit in LDS twice");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TAPS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TAPS, S, ZC, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS, S>), dim3((unsigned)gx, (unsigned)ny), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS, S, ZC, XC>), dim3((unsigned)gx, (unsigned)ny), dim3(512), LDS, s, a);
+  if (a.scratch) {
+    const long size = (long)a.Cout * a.K;  // multiple of 4: Cin is a multiple of 8
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((size / 4 + 255) / 256), (unsigned)((gx + 31) / 32)), dim3(256), 0, s, a.scratch, a.dw, size, (int)gx);
+  }
   MSL_CHECK_LAUNCH("conv_wgrad_tr");
   return MSL_OK;
 }
 
-// Called from msl_launch_conv_wgrad for bf16 tensors: k = 3 / pad 1 / stride 1|2, or k = 1 / pad 0 / stride 1.  Same op slots.
+template <int TAPS, int S>
+static int launch_tr_c(const WgTrArgs& a, int zc, int xc, int ny, long gx, hipStream_t s) {
+#define WG_CASE(Z, X) if (zc == Z && xc == X) return launch_tr<TAPS, S, Z, X>(a, ny, gx, s)
+  WG_CASE(2, 2); WG_CASE(2, 4); WG_CASE(2, 8);
+  WG_CASE(4, 2); WG_CASE(4, 4); WG_CASE(4, 8);
+  WG_CASE(8, 2); WG_CASE(8, 4); WG_CASE(8, 8);
+#undef WG_CASE
+  msl_set_error("conv_wgrad_tr: no kernel for chunk counts %d / %d", zc, xc);
+  return MSL_EINVAL;
+}
+
+static int wg_chunks(int c) { return c > 32 ? 8 : (c > 16 ? 4 : 2); }  // 16-byte chunks staged per pixel for a block's channel range
+
+// Called from msl_launch_conv_wgrad for bf16 tensors: k = 3 / pad 1 / stride 1|2, k = 2 / pad 0 / stride 2, or k = 1 / pad 0 / stride 1.
+// Same op slots, plus p 5 = scratch for the per-workgroup partial sums (optional) and i 21 = its capacity in floats.
 int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   WgTrArgs a;
   a.x = (const char*)op.p[0]; a.dz = (const char*)op.p[1]; a.dw = (float*)op.p[4];
@@ -149,21 +328,32 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   a.x_cs = op.i[10]; a.x_co = op.i[11]; a.z_cs = op.i[12]; a.z_co = op.i[13];
   a.K = k * k * a.Cin;
   MSL_REQUIRE(a.x && a.dz && a.dw && a.N > 0 && a.H > 0 && a.W > 0, "conv_wgrad_tr: bad args");
-  MSL_REQUIRE((k == 3 && pad == 1 && (stride == 1 || stride == 2)) || (k == 1 && pad == 0 && stride == 1), "conv_wgrad_tr: needs k3p1 (stride 1|2) or k1p0 stride 1");
+  MSL_REQUIRE((k == 3 && pad == 1 && (stride == 1 || stride == 2)) || (k == 2 && pad == 0 && stride == 2) || (k == 1 && pad == 0 && stride == 1),
+              "conv_wgrad_tr: needs k3p1 (stride 1|2), k2p0 stride 2 or k1p0 stride 1");
   MSL_REQUIRE(a.Ho == (a.H + 2 * pad - k) / stride + 1 && a.Wo == (a.W + 2 * pad - k) / stride + 1, "conv_wgrad_tr: inconsistent output dims");
   MSL_REQUIRE(a.Cin % 8 == 0 && a.Cout % 8 == 0 && a.x_cs % 8 == 0 && a.x_co % 8 == 0 && a.z_cs % 8 == 0 && a.z_co % 8 == 0, "conv_wgrad_tr: channels/views must be multiples of 8");
-  const int TH = stride == 1 ? 8 : 4;
-  a.tiles_x = (a.Wo + 31) / 32;
-  a.tiles_y = (a.Ho + TH - 1) / TH;
-  a.total_tiles = (long)a.N * a.tiles_y * a.tiles_x;
+  a.M = (long)a.N * a.Ho * a.Wo;
+  const int TH = stride == 2 ? 2 : 4;
+  if (k == 1) {
+    a.tiles_x = 1; a.tiles_y = 1;
+    a.total_tiles = (a.M + TH * 32 - 1) / (TH * 32);
+  } else {
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.tiles_y = (a.Ho + TH - 1) / TH;
+    a.total_tiles = (long)a.N * a.tiles_y * a.tiles_x;
+  }
   const int ny = ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
-  long want = (768 + ny - 1) / ny;  // ~3 workgroups per CU overall
+  long want = (256 + ny - 1) / ny;  // one 8-wave workgroup per CU: each holds two staged tiles in LDS
   if (want < 1) want = 1;
   long tpb = (a.total_tiles + want - 1) / want;
   if (tpb < 1) tpb = 1;
   a.tiles_per_block = (int)tpb;
   const long gx = (a.total_tiles + tpb - 1) / tpb;
-  if (k == 3 && stride == 1) return launch_tr<9, 1>(a, ny, gx, s);
-  if (k == 3) return launch_tr<9, 2>(a, ny, gx, s);
-  return launch_tr<1, 1>(a, ny, gx, s);
+  a.scratch = (float*)op.p[5];
+  if (a.scratch) MSL_REQUIRE(gx * a.Cout * a.K <= (long)op.i[21] && ((uintptr_t)a.scratch & 15) == 0, "conv_wgrad_tr: scratch too small (%ld floats needed) or misaligned", gx * a.Cout * a.K);
+  const int zc = wg_chunks(a.Cout), xc = wg_chunks(a.Cin);
+  if (k == 3 && stride == 1) return launch_tr_c<9, 1>(a, zc, xc, ny, gx, s);
+  if (k == 3) return launch_tr_c<9, 2>(a, zc, xc, ny, gx, s);
+  if (k == 2) return launch_tr_c<4, 2>(a, zc, xc, ny, gx, s);
+  return launch_tr_c<1, 1>(a, zc, xc, ny, gx, s);
 }

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
   {  // bf16 tensors, stride 1, 3x3/p1 or 1x1/p0: LDS transposed-read kernel on the bf16 MFMA (conv_wgrad_tr.hip)
     const int k = op.i[7];
-    const bool geom = (k == 3 && op.i[9] == 1 && (op.i[8] == 1 || op.i[8] == 2)) || (k == 1 && op.i[9] == 0 && op.i[8] == 1);
+    const bool geom = (k == 3 && op.i[9] == 1 && (op.i[8] == 1 || op.i[8] == 2)) || (k == 2 && op.i[9] == 0 && op.i[8] == 2) || (k == 1 && op.i[9] == 0 && op.i[8] == 1);
     const bool al = op.i[3] % 8 == 0 && op.i[6] % 8 == 0 && op.i[10] % 8 == 0 && op.i[11] % 8 == 0 && op.i[12] % 8 == 0 && op.i[13] % 8 == 0;
     if (op.dtype == MSL_BF16 && !op.i[19] && geom && al && op.i[20] == 0) return msl_launch_conv_wgrad_tr(op, s);
   }

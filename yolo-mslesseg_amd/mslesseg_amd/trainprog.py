@@ -25,6 +25,7 @@ from .engine import View, _dt
 from .hiplib import MSL_BF16, MSL_F32
 
 BN_EPS, BN_MOM = params.BN_EPS, params.BN_MOMENTUM
+WG_SCRATCH_FLOATS = 12 << 20  # >= (256 + ny) workgroups x 64x64x9 partial outputs each (conv_wgrad_tr.hip)
 ACC_SLOTS = 8  # replicas of every BatchNorm reduction accumulator (same-address fp64 atomics serialise; see train_kernels.hip)
 
 
@@ -240,6 +241,7 @@ class TrainPlan(graph.Visitor):
         self._arena: Dict[int, dict] = {}
         self._bwd_acc = torch.zeros(1 << 19, dtype=torch.float64, device=self.device)  # all backward reduction accumulators
         self._bwd_acc_n = 0
+        self._wg_scratch = torch.empty(WG_SCRATCH_FLOATS, dtype=torch.float32, device=self.device)  # per-workgroup dW partials (one wgrad runs at a time)
         self._keep: List[torch.Tensor] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.levels, self.proto_view, self.in_view = {}, None, None
@@ -418,8 +420,8 @@ class TrainPlan(graph.Visitor):
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0}))
                 ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
-                                      i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32}))
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+                                      i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}))
             if dz_f32 and self.dtype != MSL_F32:  # the MFMA operand must be the compute dtype
                 dzc = self._new(Ho, Wo, dz.C)
                 self._keep.append(dzc.t)  # ops hold raw pointers: every buffer must outlive the programs
@@ -464,8 +466,8 @@ class TrainPlan(graph.Visitor):
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co}))
             ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
             # dW[ci][(dy,dx,co)] = sum_p x[p][ci] * dy[(2y+dy,2x+dx)][co]: CONV_WGRAD with the operands swapped
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
-                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co}))
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co, 21: WG_SCRATCH_FLOATS}))
             gx = self.G(x)
             first = self._init.first_write(gx)
             ops.append(self._conv_op(gy, gx, wd, self.zeros.data_ptr(), dm, 2, 2, 0, res=None if first else gx, cout=cin))
