@@ -349,6 +349,8 @@ WGRAD_CASES = [
     (6, 80, 80, 96, 128, 1, 1, 96, 0, 128, 0),
     (2, 24, 40, 64, 64, 2, 2, 64, 0, 64, 0),      # 2x2 stride 2 pad 0: the ConvTranspose2d weight gradient with swapped operands
     (4, 96, 96, 32, 16, 2, 2, 32, 0, 16, 0),
+    (2, 40, 40, 64, 1, 1, 1, 64, 0, 8, 0),        # the nc=1 class head: one output channel in an 8-wide gradient buffer
+    (2, 20, 20, 64, 3, 1, 1, 64, 0, 8, 0),
 ]
 
 

@@ -285,6 +285,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Shared by every weight-gradient kernel that writes per-workgroup partials: dst[i] += sum_b scratch[b][i].
+int msl_reduce_partials(const float* scratch, float* dst, long size, int nb, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((size + 3) / 4 + 255) / 256), (unsigned)((nb + 31) / 32)), dim3(256), 0, s, scratch, dst, size, nb);
+  return MSL_OK;
+}
+
 template <int TAPS, int S, int ZC, int XC>
 static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
   typedef WgCfg<TAPS, S, ZC, XC> C;
@@ -297,10 +303,7 @@ static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
     attr = true;
   }
   hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS, S, ZC, XC>), dim3((unsigned)gx, (unsigned)ny), dim3(512), LDS, s, a);
-  if (a.scratch) {
-    const long size = (long)a.Cout * a.K;  // multiple of 4: Cin is a multiple of 8
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((size / 4 + 255) / 256), (unsigned)((gx + 31) / 32)), dim3(256), 0, s, a.scratch, a.dw, size, (int)gx);
-  }
+  if (a.scratch) msl_reduce_partials(a.scratch, a.dw, (long)a.Cout * a.K, (int)gx, s);
   MSL_CHECK_LAUNCH("conv_wgrad_tr");
   return MSL_OK;
 }
@@ -331,7 +334,8 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE((k == 3 && pad == 1 && (stride == 1 || stride == 2)) || (k == 2 && pad == 0 && stride == 2) || (k == 1 && pad == 0 && stride == 1),
               "conv_wgrad_tr: needs k3p1 (stride 1|2), k2p0 stride 2 or k1p0 stride 1");
   MSL_REQUIRE(a.Ho == (a.H + 2 * pad - k) / stride + 1 && a.Wo == (a.W + 2 * pad - k) / stride + 1, "conv_wgrad_tr: inconsistent output dims");
-  MSL_REQUIRE(a.Cin % 8 == 0 && a.Cout % 8 == 0 && a.x_cs % 8 == 0 && a.x_co % 8 == 0 && a.z_cs % 8 == 0 && a.z_co % 8 == 0, "conv_wgrad_tr: channels/views must be multiples of 8");
+  MSL_REQUIRE(a.Cin % 8 == 0 && a.x_cs % 8 == 0 && a.x_co % 8 == 0 && a.z_cs % 8 == 0 && a.z_co % 8 == 0 && a.z_co + (a.Cout + 7) / 8 * 8 <= a.z_cs,
+              "conv_wgrad_tr: Cin and the views must be multiples of 8 (dz is read in whole 8-channel chunks inside its pixel stride)");
   a.M = (long)a.N * a.Ho * a.Wo;
   const int TH = stride == 2 ? 2 : 4;
   if (k == 1) {

@@ -523,7 +523,8 @@ int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
   {  // bf16 tensors, stride 1, 3x3/p1 or 1x1/p0: LDS transposed-read kernel on the bf16 MFMA (conv_wgrad_tr.hip)
     const int k = op.i[7];
     const bool geom = (k == 3 && op.i[9] == 1 && (op.i[8] == 1 || op.i[8] == 2)) || (k == 2 && op.i[9] == 0 && op.i[8] == 2) || (k == 1 && op.i[9] == 0 && op.i[8] == 1);
-    const bool al = op.i[3] % 8 == 0 && op.i[6] % 8 == 0 && op.i[10] % 8 == 0 && op.i[11] % 8 == 0 && op.i[12] % 8 == 0 && op.i[13] % 8 == 0;
+    const bool al = op.i[3] % 8 == 0 && op.i[10] % 8 == 0 && op.i[11] % 8 == 0 && op.i[12] % 8 == 0 && op.i[13] % 8 == 0 &&
+                    op.i[13] + (op.i[6] + 7) / 8 * 8 <= op.i[12];  // a narrow dz view is read in whole 8-channel chunks: they must lie inside the pixel stride
     if (op.dtype == MSL_BF16 && !op.i[19] && geom && al && op.i[20] == 0) return msl_launch_conv_wgrad_tr(op, s);
   }
   WgradArgs a;
@@ -556,7 +557,7 @@ int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
 // the pixel lanes, then one atomic per (tap, channel) and block.
 template <bool F32>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const void* __restrict__ x, const void* __restrict__ dz, float* __restrict__ dw, int N, int H, int W,
-                                                       int C, int x_cs, int x_co, int z_cs, int z_co, int gsz, int gstride, int goff) {
+                                                       int C, int x_cs, int x_co, int z_cs, int z_co, int gsz, int gstride, int goff, float* __restrict__ scratch) {
   __shared__ float red[36][256];
   const int C4 = C >> 2;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
@@ -598,10 +599,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const void* __restrict__ 
     const int k = v / C4, q = v - k * C4;
     float acc = 0.f;
     for (int j = 0; j < PL; ++j) acc += red[k][j * C4 + q];
-    atomicAdd(dw + (k >> 2) * C + q * 4 + (k & 3), acc);
+    const int o = (k >> 2) * C + q * 4 + (k & 3);
+    if (scratch) scratch[(long)blockIdx.x * 9 * C + o] = acc;  // per-workgroup partial (msl_reduce_partials sums them): no contended atomics
+    else atomicAdd(dw + o, acc);
   }
 }
-// p 0 x, 1 dz, 4 dW f32 [9][C] ; i 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 z_cs,13 z_co,22 gsz,23 gstride,24 goff
+// p 0 x, 1 dz, 4 dW f32 [9][C], 5 scratch for per-workgroup partials (optional; i 21 = capacity in floats) ; i 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 z_cs,13 z_co,22 gsz,23 gstride,24 goff
 int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, "dw_wgrad: bad args (C must be a multiple of 4, <= 1024)");
@@ -613,8 +616,11 @@ int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
   long bx = (M + (long)PL * 32 - 1) / ((long)PL * 32);
   if (bx > 512) bx = 512;
   dim3 grid((unsigned)bx);
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL(dw_wgrad_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24]);
-  else hipLaunchKernelGGL(dw_wgrad_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24]);
+  float* scratch = (float*)op.p[5];
+  if (scratch) MSL_REQUIRE(bx * 9 * C <= (long)op.i[21], "dw_wgrad: scratch too small");
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(dw_wgrad_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24], scratch);
+  else hipLaunchKernelGGL(dw_wgrad_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24], scratch);
+  if (scratch) msl_reduce_partials(scratch, (float*)op.p[4], 9L * C, (int)bx, s);
   MSL_CHECK_LAUNCH("dw_wgrad");
   return MSL_OK;
 }
@@ -625,7 +631,7 @@ int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
 // the multiplicand and the 1/255 applied once per block partial.
 template <bool F32, int COUT>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restrict__ x, const void* __restrict__ dz, float* __restrict__ dw, int N, int H, int W,
-                                                         int Ho, int Wo, int z_cs, int z_co) {
+                                                         int Ho, int Wo, int z_cs, int z_co, float* __restrict__ scratch) {
   __shared__ float red[8][32][COUT + 1];
   const int t = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int tt = t < 27 ? t : 26;
@@ -658,10 +664,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc += red[j][tq][co];
-    atomicAdd(dw + v, acc * (1.0f / 255.0f));
+    if (scratch) scratch[(long)blockIdx.x * 27 * COUT + v] = acc * (1.0f / 255.0f);
+    else atomicAdd(dw + v, acc * (1.0f / 255.0f));
   }
 }
-// p 0 x u8 [N,H,W,3], 1 dz, 4 dW f32 [27][Cout] ; i 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout,12 z_cs,13 z_co
+// p 0 x u8 [N,H,W,3], 1 dz, 4 dW f32 [27][Cout], 5 scratch (optional; i 21 = capacity in floats) ; i 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout,12 z_cs,13 z_co
 int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], Ho = op.i[4], Wo = op.i[5], Cout = op.i[6];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && (Cout == 16 || Cout == 32) && op.i[13] + Cout <= op.i[12], "stem_wgrad: bad args");
@@ -670,10 +677,13 @@ int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(M < (1L << 31), "stem_wgrad: too many pixels");
   long bx = (M + 255) / 256;  // >= 32 pixels per pixel lane
   if (bx > 2048) bx = 2048;
-#define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13])
+  float* scratch = (float*)op.p[5];
+  if (scratch) MSL_REQUIRE(bx * 27 * Cout <= (long)op.i[21], "stem_wgrad: scratch too small");
+#define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13], scratch)
   if (op.dtype == MSL_F32) { if (Cout == 16) SW(true, 16); else SW(true, 32); }
   else { if (Cout == 16) SW(false, 16); else SW(false, 32); }
 #undef SW
+  if (scratch) msl_reduce_partials(scratch, (float*)op.p[4], 27L * Cout, (int)bx, s);
   MSL_CHECK_LAUNCH("stem_wgrad");
   return MSL_OK;
 }

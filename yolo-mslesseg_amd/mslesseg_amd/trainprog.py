@@ -357,8 +357,8 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             self._bn_backward(ops, name, z, y, cout, True, stats, None)
-            ops.append(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
-                                      i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co}))
+            ops.append(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+                                      i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS}))
             return ops
 
         self._bw_builders.append(bw)
@@ -420,14 +420,14 @@ class TrainPlan(graph.Visitor):
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0}))
                 ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
-                                      i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}))
-            if dz_f32 and self.dtype != MSL_F32:  # the MFMA operand must be the compute dtype
+            if dz_f32 and self.dtype != MSL_F32:  # the MFMA operands must be the compute dtype (as autocast feeds these convs upstream)
                 dzc = self._new(Ho, Wo, dz.C)
                 self._keep.append(dzc.t)  # ops hold raw pointers: every buffer must outlive the programs
                 ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dzc.t.data_ptr(), dz.t.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
-                dz = dzc
+                dz, dz_f32 = dzc, 0
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+                                      i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}))
             gx = self.G(x)
             first = self._init.first_write(gx)
             gres = None if first else gx
@@ -491,8 +491,8 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             self._bn_backward(ops, name, z, y, C, act, stats, res, res_inplace=inplace)
-            ops.append(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g)),
-                                      i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, **gm}))
+            ops.append(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+                                      i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS, **gm}))
             gx = self.G(x)
             if gmap is None:
                 first = self._init.first_write(gx)
