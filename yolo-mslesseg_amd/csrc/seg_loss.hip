@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void sl_main_kernel(SlArgs s) {
 // ---------------------------------------------------------------------------------------------- 7 mask
 // Block = one 16x16 tile of prototype pixels of one slice; thread = pixel (32 prototype values in registers).
 template <bool F32>
-__global__ __launch_bounds__(256) void sl_mask_kernel(SlArgs s) {
+__global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two tiles per CU (no spills at <= 256 VGPRs)
   constexpr int CH = 16;  // foreground anchors staged per pass
   __shared__ float s_cf[CH][32];
   __shared__ float s_box[CH][4];
@@ -420,6 +420,8 @@ __global__ __launch_bounds__(256) void sl_mask_kernel(SlArgs s) {
   __shared__ float s_gc[CH][32];
   __shared__ int s_hit[CH];
   __shared__ float* s_gptr[CH];
+  __shared__ const float* s_cptr[CH];
+  __shared__ int s_use[CH];
   __shared__ double s_red[4];
   const int b = blockIdx.y;
   const int tiles_x = (s.mw + 15) / 16;
@@ -447,31 +449,36 @@ __global__ __launch_bounds__(256) void sl_mask_kernel(SlArgs s) {
   for (int c0 = 0; c0 < nf; c0 += CH) {
     const int nc_ = min(CH, nf - c0);
     __syncthreads();
-    // ---- stage the chunk: coefficients, crop box (prototype pixels), weight 1 / (mh*mw*area)
-    for (int i = threadIdx.x; i < nc_ * 32; i += 256) {
-      const int e = i >> 5, k = i & 31;
+    // ---- stage the chunk: crop box (prototype pixels), weight 1 / (mh*mw*area) and pointers first; the coefficient rows are
+    // gathered only for anchors whose crop box meets this tile, and tiles that meet none skip the chunk altogether
+    int hit = 0;
+    if (threadIdx.x < nc_) {
+      const int e = threadIdx.x;
       const int2 ent = s.flist[(long)b * cap + c0 + e];
       const SlLoc lc = sl_locate(s.tab, s.nlev, ent.x);
       const long long* tb = s.tab + lc.l * SL_TAB;
       const long ap = ((long)b * lc.H + lc.y) * lc.W + lc.x;
-      s_cf[e][k] = ((const float*)tb[2])[ap * tb[12] + tb[13] + k];
-      s_gc[e][k] = 0.f;
-      if (k == 0) {
-        const float* g = s.gt + ((long)b * s.n + ent.y) * 5;
-        const float n0 = g[1] / s.imgw, n1 = g[2] / s.imgh, n2 = g[3] / s.imgw, n3 = g[4] / s.imgh;
-        s_box[e][0] = n0 * (float)s.mw; s_box[e][1] = n1 * (float)s.mh; s_box[e][2] = n2 * (float)s.mw; s_box[e][3] = n3 * (float)s.mh;
-        const float area = (n2 - n0) * (n3 - n1);
-        s_w[e] = inv_px / fmaxf(area, 1e-12f);
-        s_j[e] = ent.y;
-        s_hit[e] = 0;
-        s_gptr[e] = (float*)tb[5] + ap * tb[12] + tb[13];
-      }
+      const float* g = s.gt + ((long)b * s.n + ent.y) * 5;
+      const float n0 = g[1] / s.imgw, n1 = g[2] / s.imgh, n2 = g[3] / s.imgw, n3 = g[4] / s.imgh;
+      const float x1 = n0 * (float)s.mw, y1 = n1 * (float)s.mh, x2 = n2 * (float)s.mw, y2 = n3 * (float)s.mh;
+      s_box[e][0] = x1; s_box[e][1] = y1; s_box[e][2] = x2; s_box[e][3] = y2;
+      s_w[e] = inv_px / fmaxf((n2 - n0) * (n3 - n1), 1e-12f);
+      s_j[e] = ent.y;
+      s_hit[e] = 0;
+      s_gptr[e] = (float*)tb[5] + ap * tb[12] + tb[13];
+      s_cptr[e] = (const float*)tb[2] + ap * tb[12] + tb[13];
+      hit = (float)(tx0 + 15) >= x1 && (float)tx0 < x2 && (float)(ty0 + 15) >= y1 && (float)ty0 < y2;
+      s_use[e] = hit;
+    }
+    if (!__syncthreads_or(hit)) continue;  // block-uniform
+    for (int i = threadIdx.x; i < nc_ * 32; i += 256) {
+      const int e = i >> 5, k = i & 31;
+      if (s_use[e]) { s_cf[e][k] = s_cptr[e][k]; s_gc[e][k] = 0.f; }
     }
     __syncthreads();
     for (int e = 0; e < nc_; ++e) {
+      if (!s_use[e]) continue;  // tile vs crop box (block-uniform)
       const float x1 = s_box[e][0], y1 = s_box[e][1], x2 = s_box[e][2], y2 = s_box[e][3];
-      // tile vs crop box (block-uniform)
-      if (!((float)(tx0 + 15) >= x1 && (float)tx0 < x2 && (float)(ty0 + 15) >= y1 && (float)ty0 < y2)) continue;
       const bool in = live && fx >= x1 && fx < x2 && fy >= y1 && fy < y2;
       if (__ballot(in) == 0ull) continue;  // wave-uniform
       float dpm = 0.f;
@@ -485,15 +492,24 @@ __global__ __launch_bounds__(256) void sl_mask_kernel(SlArgs s) {
         dpm = (sl_sigmoid(pm) - gtv) * w * S;
       }
       if (s.no_grad) continue;
-      float v[32];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { gp[k] = fmaf(dpm, s_cf[e][k], gp[k]); v[k] = dpm * pr[k]; }
-      // transpose-reduce 32 values over the 64 lanes: 31 + 1 shuffles, lane 2k ends with value index of its bits
-#pragma unroll
-      for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
-        const bool up = (lane & bit) != 0;
+      for (int k = 0; k < 32; ++k) gp[k] = fmaf(dpm, s_cf[e][k], gp[k]);
+      // d(loss)/d(coef[k]) = sum over pixels of dpm * proto[k]: transpose-reduce the 32 values over the 64 lanes
+      // (31 + 1 shuffles; the products are formed inside the first exchange so only 16 live values remain)
+      float v[16];
+      {
+        const bool up = (lane & 32) != 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+          const float lo = dpm * pr[i], hi = dpm * pr[i + 16];
+          v[i] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 32);
+        }
+      }
+#pragma unroll
+      for (int half = 8, bit = 16; half >= 1; half >>= 1, bit >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
           if (i < half) {
             const float send = up ? v[i] : v[i + half];
             const float keep = up ? v[i + half] : v[i];

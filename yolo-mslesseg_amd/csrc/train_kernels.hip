@@ -613,11 +613,16 @@ int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
   const long M = (long)N * H * W;
   MSL_REQUIRE(M < (1L << 31), "dw_wgrad: too many pixels");
   const int PL = 256 / (C / 4);
-  long bx = (M + (long)PL * 32 - 1) / ((long)PL * 32);
-  if (bx > 512) bx = 512;
-  dim3 grid((unsigned)bx);
   float* scratch = (float*)op.p[5];
-  if (scratch) MSL_REQUIRE(bx * 9 * C <= (long)op.i[21], "dw_wgrad: scratch too small");
+  // each thread walks its pixels one dependent load round-trip at a time: with a scratch buffer (no contended atomics) the
+  // work is spread over many short workgroups instead of few long ones
+  const int ppt = scratch ? 4 : 32;
+  long bx = (M + (long)PL * ppt - 1) / ((long)PL * ppt);
+  const long cap = scratch ? 8192 : 512;
+  if (bx > cap) bx = cap;
+  if (scratch && bx * 9 * C > (long)op.i[21]) bx = (long)op.i[21] / (9L * C);
+  MSL_REQUIRE(bx >= 1, "dw_wgrad: scratch too small");
+  dim3 grid((unsigned)bx);
   if (op.dtype == MSL_F32) hipLaunchKernelGGL(dw_wgrad_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24], scratch);
   else hipLaunchKernelGGL(dw_wgrad_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24], scratch);
   if (scratch) msl_reduce_partials(scratch, (float*)op.p[4], 9L * C, (int)bx, s);
@@ -640,21 +645,37 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
 #pragma unroll
   for (int i = 0; i < COUT; ++i) s[i] = 0.f;
   const unsigned M = (unsigned)N * Ho * Wo;
-  for (unsigned p = blockIdx.x * 8 + pl; p < M; p += gridDim.x * 8) {
-    const unsigned q = p / (unsigned)Wo;
-    const int ox = (int)(p - q * Wo);
-    const unsigned n = q / (unsigned)Ho;
-    const int oy = (int)(q - n * Ho);
-    const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-    float xv = 0.f;
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) xv = (float)x[(((long)n * H + iy) * W + ix) * 3 + ci];
+  constexpr int U = 4;  // pixels in flight per thread: the loop is a chain of load round-trips otherwise
+  const unsigned step = gridDim.x * 8;
+  for (unsigned p0 = blockIdx.x * 8 + pl; p0 < M; p0 += U * step) {
+    float xv[U], g[U][COUT];
 #pragma unroll
-    for (int c4 = 0; c4 < COUT; c4 += 4) {
-      float g[4];
-      ld4<F32>(dz, (long)p * z_cs + z_co + c4, g);
+    for (int u = 0; u < U; ++u) {
+      const unsigned p = p0 + u * step;
+      xv[u] = 0.f;
+      if (p < M) {
+        const unsigned q = p / (unsigned)Wo;
+        const int ox = (int)(p - q * Wo);
+        const unsigned n = q / (unsigned)Ho;
+        const int oy = (int)(q - n * Ho);
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) xv[u] = (float)x[(((long)n * H + iy) * W + ix) * 3 + ci];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[c4 + r] = fmaf(xv, g[r], s[c4 + r]);
+        for (int c4 = 0; c4 < COUT; c4 += 4) {
+          float t4[4];
+          ld4<F32>(dz, (long)p * z_cs + z_co + c4, t4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g[u][c4 + r] = t4[r];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) g[u][c] = 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) s[c] = fmaf(xv[u], g[u][c], s[c]);
   }
 #pragma unroll
   for (int i = 0; i < COUT; ++i) red[pl][t][i] = s[i];
@@ -675,10 +696,12 @@ int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.i[12] % 4 == 0 && op.i[13] % 4 == 0, "stem_wgrad: dz view must be 4-aligned");
   const long M = (long)N * Ho * Wo;
   MSL_REQUIRE(M < (1L << 31), "stem_wgrad: too many pixels");
-  long bx = (M + 255) / 256;  // >= 32 pixels per pixel lane
-  if (bx > 2048) bx = 2048;
   float* scratch = (float*)op.p[5];
-  if (scratch) MSL_REQUIRE(bx * 27 * Cout <= (long)op.i[21], "stem_wgrad: scratch too small");
+  long bx = scratch ? (M + 127) / 128 : (M + 255) / 256;  // 16 / 32 pixels per pixel lane; partials in scratch make short workgroups cheap
+  const long cap = scratch ? 16384 : 2048;
+  if (bx > cap) bx = cap;
+  if (scratch && bx * 27 * Cout > (long)op.i[21]) bx = (long)op.i[21] / (27L * Cout);
+  MSL_REQUIRE(bx >= 1, "stem_wgrad: scratch too small");
 #define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13], scratch)
   if (op.dtype == MSL_F32) { if (Cout == 16) SW(true, 16); else SW(true, 32); }
   else { if (Cout == 16) SW(false, 16); else SW(false, 32); }
