@@ -380,58 +380,103 @@ int msl_launch_upsample2x_bwd(const msl_op& op, hipStream_t s) {
 // SPPF_POOL_BWD: dy of the 5x5/9x9/13x13 pools (views at co+C, co+2C, co+3C of the grad buffer) is routed to the arg-max
 // position of each window in the forward view (first maximum in row-major scan order) and accumulated into a fp32 scratch
 // [N,H,W,C], which ADD_VIEW then folds into the grad view at co.  (Chained 5x5 pools route to an equal-valued element.)
+// Workgroup = one slice x 4 channels: the plane sits in LDS, the window arg-max is separable (per row the leftmost maximum
+// of [x-r, x+r], then the topmost row of [y-r, y+r] — the same element a row-major scan of the square finds first), and the
+// routed gradients are summed in LDS: 13 + 39 LDS reads per pixel instead of 169 global ones, no global atomics.
 template <bool F32>
 __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const void* __restrict__ ybuf, const void* __restrict__ gbuf, float* __restrict__ scratch,
                                                             int N, int H, int W, int C, int cs, int co, int g_cs, int g_co) {
-  const int C4 = C >> 2;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)N * H * W * C4) return;
-  const int c = (int)(t % C4) * 4;
-  const long p = t / C4;
-  const int ix = (int)(p % W);
-  const long q = p / W;
-  const int iy = (int)(q % H), n = (int)(q / H);
-  float best[3][4];
-  int arg[3][4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_[];
+  const int HW = H * W;
+  float4* val = (float4*)sm_;                     // [HW]
+  float4* rmax = val + HW;                        // [3][HW] row-pass maxima
+  float4* gsum = rmax + 3 * HW;                   // [HW] routed gradient
+  unsigned short* rarg = (unsigned short*)(gsum + HW);  // [3][HW][4] row-pass arg x
+  const int n = blockIdx.x / (C >> 2), c = (blockIdx.x % (C >> 2)) * 4;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float v[4];
+    ld4<F32>(ybuf, ((long)n * HW + p) * cs + co + c, v);
+    val[p] = make_float4(v[0], v[1], v[2], v[3]);
+    gsum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  // ---- row pass: nested windows r = 2, 4, 6 in one scan
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / W, x = p - y * W;
+    float best[3][4];
+    int arg[3][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { best[k][r] = -__builtin_inff(); arg[k][r] = 0; }
-  for (int dy = -6; dy <= 6; ++dy) {
-    const int yy = iy + dy;
-    if ((unsigned)yy >= (unsigned)H) continue;
+      for (int r = 0; r < 4; ++r) { best[k][r] = -__builtin_inff(); arg[k][r] = x; }
     for (int dx = -6; dx <= 6; ++dx) {
-      const int xx = ix + dx;
+      const int xx = x + dx;
       if ((unsigned)xx >= (unsigned)W) continue;
-      float v[4];
-      ld4<F32>(ybuf, (((long)n * H + yy) * W + xx) * cs + co + c, v);
-      const int ad = max(abs(dy), abs(dx)), pos = yy * W + xx;
+      const float4 f = val[y * W + xx];
+      const float v[4] = {f.x, f.y, f.z, f.w};
+      const int ad = abs(dx);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (v[r] > best[2][r]) { best[2][r] = v[r]; arg[2][r] = pos; }
-        if (ad <= 4 && v[r] > best[1][r]) { best[1][r] = v[r]; arg[1][r] = pos; }
-        if (ad <= 2 && v[r] > best[0][r]) { best[0][r] = v[r]; arg[0][r] = pos; }
+        if (v[r] > best[2][r]) { best[2][r] = v[r]; arg[2][r] = xx; }
+        if (ad <= 4 && v[r] > best[1][r]) { best[1][r] = v[r]; arg[1][r] = xx; }
+        if (ad <= 2 && v[r] > best[0][r]) { best[0][r] = v[r]; arg[0][r] = xx; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rmax[k * HW + p] = make_float4(best[k][0], best[k][1], best[k][2], best[k][3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rarg[(k * HW + p) * 4 + r] = (unsigned short)arg[k][r];
+    }
+  }
+  __syncthreads();
+  // ---- column pass + routing
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / W, x = p - y * W;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int rad = 2 * (k + 1);
+      float g[4];
+      ld4<F32>(gbuf, ((long)n * HW + p) * g_cs + g_co + (k + 1) * C + c, g);
+      float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+      int ay[4] = {y, y, y, y};
+      for (int dy = -rad; dy <= rad; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        const float4 f = rmax[k * HW + yy * W + x];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (v[r] > best[r]) { best[r] = v[r]; ay[r] = yy; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (g[r] != 0.f) {
+          const int ax = rarg[(k * HW + ay[r] * W + x) * 4 + r];
+          atomicAdd((float*)(gsum + ay[r] * W + ax) + r, g[r]);
+        }
       }
     }
   }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float g[4];
-    ld4<F32>(gbuf, p * g_cs + g_co + (k + 1) * C + c, g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (g[r] != 0.f) atomicAdd(scratch + ((long)n * H * W + arg[k][r]) * C + c + r, g[r]);
-  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += 256) *(float4*)(scratch + ((long)n * HW + p) * C + c) = gsum[p];
 }
-// p 0 y buffer (forward concat buffer), 1 grad buffer, 4 scratch f32 [N,H,W,C] (zeroed by the caller) ; i 0 N,1 H,2 W,3 C,10 cs,11 co,12 g_cs,13 g_co
+// p 0 y buffer (forward concat buffer), 1 grad buffer, 4 scratch f32 [N,H,W,C] (fully written) ; i 0 N,1 H,2 W,3 C,10 cs,11 co,12 g_cs,13 g_co
 int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[4] && N > 0 && H > 0 && W > 0 && C > 0 && op.i[11] + 4 * C <= op.i[10] && op.i[13] + 4 * C <= op.i[12], "sppf_pool_bwd: bad args");
   MSL_REQUIRE(C % 4 == 0 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0, "sppf_pool_bwd: channels / views must be 4-aligned");
-  const long total = (long)N * H * W * (C / 4);
-  dim3 grid((unsigned)((total + 255) / 256));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_bwd_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
-  else hipLaunchKernelGGL(sppf_pool_bwd_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  const size_t lds = (size_t)H * W * (16 * 5 + 3 * 8);
+  MSL_REQUIRE(lds <= 150 * 1024 && W < 65536, "sppf_pool_bwd: plane too large for LDS (H*W <= 1476)");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  dim3 grid((unsigned)(N * (C / 4)));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_bwd_kernel<true>, grid, dim3(256), lds, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  else hipLaunchKernelGGL(sppf_pool_bwd_kernel<false>, grid, dim3(256), lds, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
   MSL_CHECK_LAUNCH("sppf_pool_bwd");
   return MSL_OK;
 }
@@ -644,38 +689,40 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
   float s[COUT];
 #pragma unroll
   for (int i = 0; i < COUT; ++i) s[i] = 0.f;
-  const unsigned M = (unsigned)N * Ho * Wo;
-  constexpr int U = 4;  // pixels in flight per thread: the loop is a chain of load round-trips otherwise
-  const unsigned step = gridDim.x * 8;
-  for (unsigned p0 = blockIdx.x * 8 + pl; p0 < M; p0 += U * step) {
-    float xv[U], g[U][COUT];
+  // workgroup = output rows (n, oy) — no per-pixel index division; the 8 pixel lanes stride along the row, U pixels in flight
+  constexpr int U = 4;
+  const int rows = N * Ho;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / Ho, oy = row - n * Ho;
+    const int iy = oy * 2 - 1 + ky;
+    const bool rowok = (unsigned)iy < (unsigned)H;
+    const uint8_t* xrow = x + ((long)n * H + (rowok ? iy : 0)) * W * 3 + ci;
+    const long zrow = (long)row * Wo;
+    for (int ox0 = pl; ox0 < Wo; ox0 += 8 * U) {
+      float xv[U], g[U][COUT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned p = p0 + u * step;
-      xv[u] = 0.f;
-      if (p < M) {
-        const unsigned q = p / (unsigned)Wo;
-        const int ox = (int)(p - q * Wo);
-        const unsigned n = q / (unsigned)Ho;
-        const int oy = (int)(q - n * Ho);
-        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) xv[u] = (float)x[(((long)n * H + iy) * W + ix) * 3 + ci];
+      for (int u = 0; u < U; ++u) {
+        const int ox = ox0 + 8 * u;
+        const int ix = ox * 2 - 1 + kx;
+        xv[u] = (rowok && ox < Wo && (unsigned)ix < (unsigned)W) ? (float)xrow[ix * 3] : 0.f;
+        if (ox < Wo) {
 #pragma unroll
-        for (int c4 = 0; c4 < COUT; c4 += 4) {
-          float t4[4];
-          ld4<F32>(dz, (long)p * z_cs + z_co + c4, t4);
+          for (int c4 = 0; c4 < COUT; c4 += 4) {
+            float t4[4];
+            ld4<F32>(dz, (zrow + ox) * z_cs + z_co + c4, t4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) g[u][c4 + r] = t4[r];
+            for (int r = 0; r < 4; ++r) g[u][c4 + r] = t4[r];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) g[u][c] = 0.f;
         }
-      } else {
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) g[u][c] = 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) s[c] = fmaf(xv[u], g[u][c], s[c]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int c = 0; c < COUT; ++c) s[c] = fmaf(xv[u], g[u][c], s[c]);
   }
 #pragma unroll
   for (int i = 0; i < COUT; ++i) red[pl][t][i] = s[i];
@@ -697,8 +744,8 @@ int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   const long M = (long)N * Ho * Wo;
   MSL_REQUIRE(M < (1L << 31), "stem_wgrad: too many pixels");
   float* scratch = (float*)op.p[5];
-  long bx = scratch ? (M + 127) / 128 : (M + 255) / 256;  // 16 / 32 pixels per pixel lane; partials in scratch make short workgroups cheap
-  const long cap = scratch ? 16384 : 2048;
+  long bx = (long)N * Ho;  // one output row per workgroup (partials in scratch make short workgroups cheap), else a row-strided grid
+  const long cap = scratch ? 32768 : 2048;
   if (bx > cap) bx = cap;
   if (scratch && bx * 27 * Cout > (long)op.i[21]) bx = (long)op.i[21] / (27L * Cout);
   MSL_REQUIRE(bx >= 1, "stem_wgrad: scratch too small");

@@ -553,8 +553,7 @@ class TrainPlan(graph.Visitor):
             g = self.G(buf)
             y0 = View(g.t, g.N, g.H, g.W, c, g.cs, g.co, False)
             assert self._init.is_done(y0)
-            return [
-                (lambda: scratch.zero_()),
+            return [  # the kernel writes every element of `scratch`
                 hiplib.make_op(hiplib.OP_SPPF_POOL_BWD, self.dtype, p=(buf.t.data_ptr(), g.t.data_ptr(), 0, 0, scratch.data_ptr()),
                                i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co, 12: g.cs, 13: g.co}),
                 hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(g.t.data_ptr(), scratch.data_ptr()),
