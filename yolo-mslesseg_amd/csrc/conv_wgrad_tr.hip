@@ -263,31 +263,46 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       }
 }
 
-// dW[i] += sum over the workgroup partials scratch[b][i]; blockIdx.y splits the partials into runs of 32 (few atomics per output)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dw, long size, int nb) {
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= size) return;
-  const int b0 = blockIdx.y * 32, b1 = min(nb, b0 + 32);
+// dW[i] += sum over the workgroup partials scratch[b][i].  Block = 64 float4 columns x 4 row lanes; blockIdx.y owns a run of
+// `rows` partials (>= 32, and few enough runs that the closing atomics do not contend); row lanes are folded through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dw, long size, int nb, int rows) {
+  __shared__ float4 red[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + col) * 4;
+  const int b0 = blockIdx.y * rows, b1 = min(nb, b0 + rows);
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i + 3 < size) {
-#pragma unroll 8
-    for (int b = b0; b < b1; ++b) {
+  if (i + 3 < size && (size & 3) == 0) {  // rows stay 16-byte aligned only when size is a multiple of 4
+#pragma unroll 4
+    for (int b = b0 + rl; b < b1; b += 4) {
       const float4 v = *(const float4*)(scratch + (long)b * size + i);
       s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
     }
-    atomicAdd(dw + i, s4.x); atomicAdd(dw + i + 1, s4.y); atomicAdd(dw + i + 2, s4.z); atomicAdd(dw + i + 3, s4.w);
-  } else {
-    for (long k = i; k < size; ++k) {
-      float v = 0.f;
-      for (int b = b0; b < b1; ++b) v += scratch[(long)b * size + k];
-      atomicAdd(dw + k, v);
+  } else if (i < size) {
+    for (int b = b0 + rl; b < b1; b += 4) {
+      const float* q = scratch + (long)b * size;
+      s4.x += q[i];
+      if (i + 1 < size) s4.y += q[i + 1];
+      if (i + 2 < size) s4.z += q[i + 2];
+      if (i + 3 < size) s4.w += q[i + 3];
     }
+  }
+  red[rl][col] = s4;
+  __syncthreads();
+  if (rl == 0 && i < size) {
+    const float4 a = red[0][col], b_ = red[1][col], c = red[2][col], d = red[3][col];
+    atomicAdd(dw + i, (a.x + b_.x) + (c.x + d.x));
+    if (i + 1 < size) atomicAdd(dw + i + 1, (a.y + b_.y) + (c.y + d.y));
+    if (i + 2 < size) atomicAdd(dw + i + 2, (a.z + b_.z) + (c.z + d.z));
+    if (i + 3 < size) atomicAdd(dw + i + 3, (a.w + b_.w) + (c.w + d.w));
   }
 }
 
 // Shared by every weight-gradient kernel that writes per-workgroup partials: dst[i] += sum_b scratch[b][i].
 int msl_reduce_partials(const float* scratch, float* dst, long size, int nb, hipStream_t s) {
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((size + 3) / 4 + 255) / 256), (unsigned)((nb + 31) / 32)), dim3(256), 0, s, scratch, dst, size, nb);
+  int rows = (nb + 63) / 64;  // <= 64 runs → <= 64 atomics per output
+  if (rows < 32) rows = 32;
+  rows = (rows + 3) / 4 * 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((size + 3) / 4 + 63) / 64), (unsigned)((nb + rows - 1) / rows)), dim3(256), 0, s, scratch, dst, size, nb, rows);
   return MSL_OK;
 }
 

@@ -745,7 +745,7 @@ int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(M < (1L << 31), "stem_wgrad: too many pixels");
   float* scratch = (float*)op.p[5];
   long bx = (long)N * Ho;  // one output row per workgroup (partials in scratch make short workgroups cheap), else a row-strided grid
-  const long cap = scratch ? 32768 : 2048;
+  const long cap = scratch ? 8192 : 2048;
   if (bx > cap) bx = cap;
   if (scratch && bx * 27 * Cout > (long)op.i[21]) bx = (long)op.i[21] / (27L * Cout);
   MSL_REQUIRE(bx >= 1, "stem_wgrad: scratch too small");
