@@ -385,3 +385,45 @@ def test_conv_wgrad(case, dtype):
     torch.cuda.synchronize()
     err2 = float((dw2.cpu() - 0.5 - ref).abs().max() / (ref.abs().max() + 1e-12))
     assert err2 < tol, f"wgrad (scratch) {case}: rel err {err2:.2e}"
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("shape", [(2, 64, 96, 16, False), (3, 50, 70, 16, True), (1, 96, 64, 32, True)])
+def test_stem_wgrad(shape, dtype):
+    """dW[(ky,kx,ci)][co] of the 3x3/s2/p1 stem on the uint8 image (VALU kernel in fp32, MFMA kernel in bf16; atomics or scratch partials)."""
+    N, H, W, Cout, use_scratch = shape
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+    zbuf = _rand_act((N, Ho, Wo, Cout), dtype, g)
+    x = img.float().permute(0, 3, 1, 2) / 255
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, 3, 3, 3), zbuf.float().permute(0, 3, 1, 2), stride=2, padding=1)  # [co][ci][ky][kx]
+    ref = ref.permute(2, 3, 1, 0).reshape(27, Cout)
+    dw = torch.full((27, Cout), 0.25, device=DEV)
+    scratch = torch.full((8192 * 27 * Cout,), float("nan"), device=DEV) if use_scratch else None
+    xd, zd = img.to(DEV), zbuf.to(DEV)
+    op = hiplib.make_op(hiplib.OP_STEM_WGRAD, dtype, p=(xd.data_ptr(), zd.data_ptr(), 0, 0, dw.data_ptr(), scratch.data_ptr() if use_scratch else 0),
+                        i={0: N, 1: H, 2: W, 4: Ho, 5: Wo, 6: Cout, 12: Cout, 13: 0, 21: scratch.numel() if use_scratch else 0})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    err = float((dw.cpu() - 0.25 - ref).abs().max() / ref.abs().max())
+    assert err < (1e-4 if dtype == MSL_F32 else 2e-3), err
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("shape", [(2, 20, 20, 64, False), (2, 17, 23, 128, True), (1, 40, 40, 256, True)])
+def test_dw_wgrad(shape, dtype):
+    N, H, W, C, use_scratch = shape
+    g = torch.Generator().manual_seed(C + H)
+    xbuf, zbuf = _rand_act((N, H, W, C), dtype, g), _rand_act((N, H, W, C), dtype, g)
+    ref = torch.nn.grad.conv2d_weight(xbuf.float().permute(0, 3, 1, 2), (C, 1, 3, 3), zbuf.float().permute(0, 3, 1, 2), padding=1, groups=C)  # [C][1][3][3]
+    ref = ref.reshape(C, 9).t()
+    dw = torch.full((9, C), 0.25, device=DEV)
+    scratch = torch.full((8192 * 9 * C,), float("nan"), device=DEV) if use_scratch else None
+    xd, zd = xbuf.to(DEV), zbuf.to(DEV)
+    op = hiplib.make_op(hiplib.OP_DW_WGRAD, dtype, p=(xd.data_ptr(), zd.data_ptr(), 0, 0, dw.data_ptr(), scratch.data_ptr() if use_scratch else 0),
+                        i={0: N, 1: H, 2: W, 3: C, 10: C, 11: 0, 12: C, 13: 0, 21: scratch.numel() if use_scratch else 0})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    err = float((dw.cpu() - 0.25 - ref).abs().max() / ref.abs().max())
+    assert err < (1e-4 if dtype == MSL_F32 else 2e-3), err

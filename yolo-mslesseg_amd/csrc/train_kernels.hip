@@ -736,6 +736,85 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const uint8_t* __restri
     else atomicAdd(dw + v, acc * (1.0f / 255.0f));
   }
 }
+// bf16 tensors: the same contraction on the MFMA.  dW[tap][co] = sum_p X[p][tap] * dZ[p][co] is a GEMM with M = 27 taps (two
+// 16-row tiles), N = COUT and K = pixels.  A wave takes 32 consecutive output pixels of one row per step: lane (li, g) gathers
+// the 8 k-values (pixels 8g..8g+7) of tap li / li+16 as image bytes (exact in bf16) and of output channel li from dz, then
+// 2 x COUT/16 v_mfma_f32_16x16x32_bf16.  ~20x fewer instructions per pixel than the VALU kernel above; the 1/255 is applied
+// once to the per-workgroup partial.
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const uint8_t* __restrict__ x, const unsigned short* __restrict__ dz, float* __restrict__ dw, int N, int H,
+                                                              int W, int Ho, int Wo, int z_cs, int z_co, float* __restrict__ scratch) {
+  constexpr int NT = COUT / 16;
+  __shared__ float red[4][2][NT][4][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  int ky[2], kx[2], ci[2];
+  bool tv[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = tt * 16 + li;
+    tv[tt] = t < 27;
+    const int tc = tv[tt] ? t : 0;
+    ky[tt] = tc / 9; kx[tt] = (tc / 3) % 3; ci[tt] = tc % 3;
+  }
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[tt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int segs = (Wo + 31) / 32;
+  const long total = (long)N * Ho * segs;
+  for (long seg = (long)blockIdx.x * 4 + wave; seg < total; seg += (long)gridDim.x * 4) {  // wave-uniform
+    const int row = (int)(seg / segs), ox0 = (int)(seg - (long)row * segs) * 32 + 8 * g;
+    const int n = row / Ho, oy = row - n * Ho;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 a[2], b[NT];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int iy = oy * 2 - 1 + ky[tt];
+      const bool rowok = tv[tt] && (unsigned)iy < (unsigned)H;
+      const uint8_t* xr = x + ((long)n * H + (rowok ? iy : 0)) * W * 3 + ci[tt];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ix = (ox0 + j) * 2 - 1 + kx[tt];
+        const float v = (rowok && ox0 + j < Wo && (unsigned)ix < (unsigned)W) ? (float)xr[ix * 3] : 0.f;
+        a[tt][j] = (short)f32_to_bf16_bits(v);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[c][j] = (ox0 + j < Wo) ? (short)dz[((long)row * Wo + ox0 + j) * z_cs + z_co + c * 16 + li] : (short)0;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tt]), __builtin_bit_cast(bf16x8, b[c]), acc[tt][c], 0, 0, 0);
+  }
+  // fold the 4 waves, then D[row = tap 4g+r (+16 tt)][col = co li]
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][tt][c][r][lane] = acc[tt][c][r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = tt * 16 + 4 * g + r;
+          if (t >= 27) continue;
+          const float v = (red[0][tt][c][r][lane] + red[1][tt][c][r][lane] + red[2][tt][c][r][lane] + red[3][tt][c][r][lane]) * (1.0f / 255.0f);
+          const int o = t * COUT + c * 16 + li;
+          if (scratch) scratch[(long)blockIdx.x * 27 * COUT + o] = v;
+          else atomicAdd(dw + o, v);
+        }
+  }
+}
+
 // p 0 x u8 [N,H,W,3], 1 dz, 4 dW f32 [27][Cout], 5 scratch (optional; i 21 = capacity in floats) ; i 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout,12 z_cs,13 z_co
 int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], Ho = op.i[4], Wo = op.i[5], Cout = op.i[6];
@@ -751,7 +830,14 @@ int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(bx >= 1, "stem_wgrad: scratch too small");
 #define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13], scratch)
   if (op.dtype == MSL_F32) { if (Cout == 16) SW(true, 16); else SW(true, 32); }
-  else { if (Cout == 16) SW(false, 16); else SW(false, 32); }
+  else {
+    bx = (M / 32 + 4 * 16 - 1) / (4 * 16);  // >= 16 segments of 32 pixels per wave
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+#define SM(CO) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], (const unsigned short*)op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13], scratch)
+    if (Cout == 16) SM(16); else SM(32);
+#undef SM
+  }
 #undef SW
   if (scratch) msl_reduce_partials(scratch, (float*)op.p[4], 27L * Cout, (int)bx, s);
   MSL_CHECK_LAUNCH("stem_wgrad");
