@@ -78,6 +78,42 @@ __device__ __forceinline__ void st4(void* p, long i, const float (&v)[4]) {
   }
 }
 
+// load / store V (4 or 8) consecutive elements (i multiple of V) as floats: 8 bf16 = one 16-byte access
+template <bool F32, int V>
+__device__ __forceinline__ void ldv(const void* p, long i, float (&v)[V]) {
+  static_assert(V == 4 || V == 8, "V");
+  if constexpr (V == 4) {
+    ld4<F32>(p, i, v);
+  } else if constexpr (F32) {
+    const float4 a = *(const float4*)((const float*)p + i), b = *(const float4*)((const float*)p + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const uint4 t = *(const uint4*)((const unsigned short*)p + i);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+}
+template <bool F32, int V>
+__device__ __forceinline__ void stv(void* p, long i, const float (&v)[V]) {
+  static_assert(V == 4 || V == 8, "V");
+  if constexpr (V == 4) {
+    st4<F32>(p, i, v);
+  } else if constexpr (F32) {
+    *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 t;
+    t.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+    t.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+    t.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
+    t.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+    *(uint4*)((unsigned short*)p + i) = t;
+  }
+}
+
+
 // SiLU = x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each): 5 VALU instead of the ~15 of an IEEE division.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 

@@ -17,30 +17,32 @@
 // the grid grow to ~4 blocks per CU — enough loads in flight to stream at HBM rate — without an atomic tail.
 // =========================================================================================================
 #define MSL_MAX_SLOTS 16
-template <bool F32, int MODE>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
+// V = channels per thread: 8 (one 16-byte access of bf16) when the channel count and the views allow it, else 4
+template <bool F32, int MODE, int V>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ acc,
                                                           long M, int C, int a_cs, int a_co, int b_cs, int b_co, int act, int a_f32, int slots) {
-  __shared__ float red[2][256][4];
-  const int C4 = C >> 2;
-  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
-  const int c = cq * 4;
-  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+  __shared__ float red[2][256][V];
+  const int CV = C / V;
+  const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
+  const int c = cq * V;
+  float s1[V], s2[V], mu[V], is[V], ga[V], be[V];
+#pragma unroll
+  for (int r = 0; r < V; ++r) { s1[r] = 0.f; s2[r] = 0.f; mu[r] = 0.f; is[r] = 1.f; ga[r] = 1.f; be[r] = 0.f; }
   if (MODE == 1 && pl < PL) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
+    for (int r = 0; r < V; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
   }
-  auto accumulate = [&](const float (&va)[4], const float (&vb)[4]) {
+  auto accumulate = [&](const float (&va)[V], const float (&vb)[V]) {
     if (MODE == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[r] += va[r]; s2[r] = fmaf(va[r], va[r], s2[r]); }
+      for (int r = 0; r < V; ++r) { s1[r] += va[r]; s2[r] = fmaf(va[r], va[r], s2[r]); }
     } else if (MODE == 2) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s1[r] += va[r];
+      for (int r = 0; r < V; ++r) s1[r] += va[r];
     } else {  // a = dy, b = z
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < V; ++r) {
         const float zh = (vb[r] - mu[r]) * is[r];
         float g = va[r];
         if (act) {
@@ -54,46 +56,50 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
     }
   };
   if (pl < PL) {
-    constexpr int U = 4;
+    constexpr int U = V == 8 ? 2 : 4;
     const long step = (long)gridDim.x * PL;
     long p = (long)blockIdx.x * PL + pl;
     for (; p + (U - 1) * step < M; p += U * step) {
-      float va[U][4], vb[U][4];
+      float va[U][V], vb[U][V];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long q = p + u * step;
-        if (MODE == 2 && a_f32) ld4<true>(a, q * a_cs + a_co + c, va[u]); else ld4<F32>(a, q * a_cs + a_co + c, va[u]);
-        if (MODE == 1) ld4<F32>(b, q * b_cs + b_co + c, vb[u]);
+        if (MODE == 2 && a_f32) ldv<true, V>(a, q * a_cs + a_co + c, va[u]); else ldv<F32, V>(a, q * a_cs + a_co + c, va[u]);
+        if (MODE == 1) ldv<F32, V>(b, q * b_cs + b_co + c, vb[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) accumulate(va[u], vb[u]);
     }
     for (; p < M; p += step) {
-      float va[4], vb[4] = {0, 0, 0, 0};
-      if (MODE == 2 && a_f32) ld4<true>(a, p * a_cs + a_co + c, va); else ld4<F32>(a, p * a_cs + a_co + c, va);
-      if (MODE == 1) ld4<F32>(b, p * b_cs + b_co + c, vb);
+      float va[V], vb[V];
+#pragma unroll
+      for (int r = 0; r < V; ++r) vb[r] = 0.f;
+      if (MODE == 2 && a_f32) ldv<true, V>(a, p * a_cs + a_co + c, va); else ldv<F32, V>(a, p * a_cs + a_co + c, va);
+      if (MODE == 1) ldv<F32, V>(b, p * b_cs + b_co + c, vb);
       accumulate(va, vb);
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
+  for (int r = 0; r < V; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
   __syncthreads();
-  if (threadIdx.x < C4) {
-    float t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+  if (threadIdx.x < CV) {
+    float t1[V], t2[V];
+#pragma unroll
+    for (int r = 0; r < V; ++r) { t1[r] = 0.f; t2[r] = 0.f; }
     for (int j = 0; j < PL; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { t1[r] += red[0][j * C4 + threadIdx.x][r]; t2[r] += red[1][j * C4 + threadIdx.x][r]; }
+      for (int r = 0; r < V; ++r) { t1[r] += red[0][j * CV + threadIdx.x][r]; t2[r] += red[1][j * CV + threadIdx.x][r]; }
     double* dst = acc + (long)(blockIdx.x % slots) * (MODE == 2 ? C : 2 * C);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < V; ++r) {
       if (MODE == 2) atomicAdd(dst + c + r, (double)t1[r]);
       else { atomicAdd(dst + 2 * (c + r), (double)t1[r]); atomicAdd(dst + 2 * (c + r) + 1, (double)t2[r]); }
     }
   }
 }
 
-static int reduce_grid(long M, int C, int slots) {
-  const int PL = 256 / (C / 4);
+static int reduce_grid(long M, int C, int slots, int V) {
+  const int PL = 256 / (C / V);
   long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);  // >= 16 pixels per thread before another block (and its atomics) pays off
   const long cap = slots > 1 ? 1024 : 256;                  // un-replicated accumulator: keep the same-address atomic chain short
   if (blocks > cap) blocks = cap;
@@ -101,6 +107,8 @@ static int reduce_grid(long M, int C, int slots) {
   return (int)blocks;
 }
 static int slots_of(const msl_op& op, int idx) { return op.i[idx] > 0 ? op.i[idx] : 1; }
+// 8 channels per thread when every offset / stride involved is a multiple of 8
+static bool vec8(int C, int a, int b, int c = 0, int d = 0, int e = 0, int f = 0) { return C % 8 == 0 && C / 8 <= 256 && ((a | b | c | d | e | f) & 7) == 0; }
 
 // BN_STATS: p 0 z, 1 acc f64[slots][2C] ; i 0 N,1 H,2 W,3 C,10 cs,11 co,21 slots (0 = 1)
 int msl_launch_bn_stats(const msl_op& op, hipStream_t s) {
@@ -108,9 +116,11 @@ int msl_launch_bn_stats(const msl_op& op, hipStream_t s) {
   const int C = op.i[3], cs = op.i[10], co = op.i[11], slots = slots_of(op, 21);
   MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && cs % 4 == 0 && co % 4 == 0 && co + C <= cs, "bn_stats: bad args");
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "bn_stats: too many accumulator slots");
-  dim3 grid(reduce_grid(M, C, slots));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots);
-  else hipLaunchKernelGGL((chan_reduce_kernel<false, 0>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots);
+  const bool v8 = vec8(C, cs, co);
+  dim3 grid(reduce_grid(M, C, slots, v8 ? 8 : 4));
+#define BS(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 0, V>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots)
+  if (op.dtype == MSL_F32) { if (v8) BS(true, 8); else BS(true, 4); } else { if (v8) BS(false, 8); else BS(false, 4); }
+#undef BS
   MSL_CHECK_LAUNCH("bn_stats");
   return MSL_OK;
 }
@@ -147,43 +157,61 @@ int msl_launch_bn_finalize(const msl_op& op, hipStream_t s) {
   return MSL_OK;
 }
 
-// BN_ACT forward: y = act(gamma * (z - mean) * invstd + beta) (+ res)
-template <bool F32>
+// BN_ACT forward: y = act(gamma * (z - mean) * invstd + beta) (+ res).  Thread = (channel group, pixel lane): the per-channel
+// constants sit in registers and the thread streams PPT pixels.
+template <bool F32, int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y, long M, int C,
-                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act) {
-  const int C4 = C >> 2;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= M * C4) return;
-  const int c = (int)(t % C4) * 4;
-  const long p = t / C4;
-  float v[4];
-  ld4<F32>(z, p * z_cs + z_co + c, v);
+                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT) {
+  const int CV = C / V;
+  const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
+  const int c = cq * V;
+  if (pl >= PL) return;
+  float mu[V], is[V], ga[V], be[V];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float u = fmaf(gamma[c + r], (v[r] - stats[2 * (c + r)]) * stats[2 * (c + r) + 1], beta[c + r]);
-    v[r] = act ? silu_f(u) : u;
-  }
-  if (res) {
-    float rv[4];
-    ld4<F32>(res, p * r_cs + r_co + c, rv);
+  for (int r = 0; r < V; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
+  const long p0 = (long)blockIdx.x * PL * PPT + pl;
+  constexpr int U = V == 8 ? 2 : 4;
+  for (int k = 0; k < PPT; k += U) {
+    float v[U][V], rv[U][V];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + (long)(k + u) * PL;
+      if (p < M) {
+        ldv<F32, V>(z, p * z_cs + z_co + c, v[u]);
+        if (res) ldv<F32, V>(res, p * r_cs + r_co + c, rv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + (long)(k + u) * PL;
+      if (p < M) {
+#pragma unroll
+        for (int r = 0; r < V; ++r) {
+          const float t = fmaf(ga[r], (v[u][r] - mu[r]) * is[r], be[r]);  // same expression as the backward's zhat: no cancellation against the mean
+          v[u][r] = act ? silu_f(t) : t;
+          if (res) v[u][r] += rv[u][r];
+        }
+        stv<F32, V>(y, p * y_cs + y_co + c, v[u]);
+      }
+    }
   }
-  st4<F32>(y, p * y_cs + y_co + c, v);
 }
 
 // BN_ACT: p 0 z, 1 stats, 2 gamma, 3 res|NULL, 4 y, 5 beta ; i 0 N,1 H,2 W,3 C,10 z_cs,11 z_co,12 y_cs,13 y_co,14 r_cs,15 r_co,18 act
 int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3];
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4] && op.p[5] && M > 0 && C > 0 && C % 4 == 0, "bn_act: bad args");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4] && op.p[5] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act: bad args");
   MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "bn_act: bad views");
   if (op.p[3]) MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14], "bn_act: bad residual view");
-  const long total = M * (C / 4);
-  dim3 grid((unsigned)((total + 255) / 256));
-#define BA(F) hipLaunchKernelGGL(bn_act_kernel<F>, grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18])
-  if (op.dtype == MSL_F32) BA(true); else BA(false);
+  const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13], op.p[3] ? op.i[14] : 0, op.p[3] ? op.i[15] : 0);
+  const int PL = 256 / (C / (v8 ? 8 : 4));
+  const int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;
+  const long per_block = (long)PL * PPT;
+  dim3 grid((unsigned)((M + per_block - 1) / per_block));
+#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT)
+  if (op.dtype == MSL_F32) { if (v8) BA(true, 8); else BA(true, 4); } else { if (v8) BA(false, 8); else BA(false, 4); }
 #undef BA
   MSL_CHECK_LAUNCH("bn_act");
   return MSL_OK;
@@ -196,27 +224,28 @@ int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_reduce: bad args");
   MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "bn_act_bwd_reduce: bad views");
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "bn_act_bwd_reduce: too many accumulator slots");
-  dim3 grid(reduce_grid(M, C, slots));
-#define BR(F) hipLaunchKernelGGL((chan_reduce_kernel<F, 1>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0, slots)
-  if (op.dtype == MSL_F32) BR(true); else BR(false);
+  const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13]);
+  dim3 grid(reduce_grid(M, C, slots, v8 ? 8 : 4));
+#define BR(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 1, V>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0, slots)
+  if (op.dtype == MSL_F32) { if (v8) BR(true, 8); else BR(true, 4); } else { if (v8) BR(false, 8); else BR(false, 4); }
 #undef BR
   MSL_CHECK_LAUNCH("bn_act_bwd_reduce");
   return MSL_OK;
 }
 
 // BN_ACT_BWD_APPLY: dz = gamma*invstd*(g - s1/M - zhat*s2/M), g = dy*act'(u).  Also writes dgamma = s2, dbeta = s1 (block 0).
-// Threads are laid out like the reduction (channel quad x pixel lane): the per-channel constants are folded once into
-// registers (dz = k1*g' - k0 - k2*z with g' = dy*act'), then each thread streams PPT pixels of its channel quad.
-template <bool F32>
+// Threads are laid out like the reduction (channel group x pixel lane): the per-channel constants are folded once into
+// registers, then each thread streams PPT pixels of its channel group.
+template <bool F32, int V>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ z, const float* __restrict__ stats,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
                                                                int dz_cs, int dz_co, int act, int slots, int PPT) {
   __shared__ float ks[2048];  // (s1, s2) per channel, summed over the accumulator slots
-  const int C4 = C >> 2;
-  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
-  const int c = cq * 4;
+  const int CV = C / V;
+  const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
+  const int c = cq * V;
   for (int v = threadIdx.x; v < 2 * C; v += 256) {
     double a = 0.0;
     for (int j = 0; j < slots; ++j) a += acc[(long)j * 2 * C + v];
@@ -225,28 +254,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
   }
   __syncthreads();
   if (pl >= PL) return;
-  float mu[4], is[4], ga[4], be[4], k0[4], k2[4];
+  float mu[V], is[V], ga[V], be[V], k0[V], k2[V];
   const float invM = 1.0f / (float)M;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < V; ++r) {
     mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r];
     k0[r] = ks[2 * (c + r)] * invM;
     k2[r] = ks[2 * (c + r) + 1] * invM;
   }
   const long p0 = (long)blockIdx.x * PL * PPT + pl;  // pixel of (k,u) = p0 + (k+u)*PL: every load instruction covers PL consecutive pixels
-  for (int k = 0; k < PPT; k += 4) {
-    float g[4][4], v[4][4];
+  constexpr int U = V == 8 ? 2 : 4;
+  for (int k = 0; k < PPT; k += U) {
+    float g[U][V], v[U][V];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long p = p0 + (long)(k + u) * PL;
-      if (p < M) { ld4<F32>(dy, p * dy_cs + dy_co + c, g[u]); ld4<F32>(z, p * z_cs + z_co + c, v[u]); }
+      if (p < M) { ldv<F32, V>(dy, p * dy_cs + dy_co + c, g[u]); ldv<F32, V>(z, p * z_cs + z_co + c, v[u]); }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long p = p0 + (long)(k + u) * PL;
       if (p < M) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < V; ++r) {
           const float zh = (v[u][r] - mu[r]) * is[r];
           float gg = g[u][r];
           if (act) {
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
           }
           v[u][r] = ga[r] * is[r] * (gg - k0[r] - zh * k2[r]);
         }
-        st4<F32>(dz, p * dz_cs + dz_co + c, v[u]);
+        stv<F32, V>(dz, p * dz_cs + dz_co + c, v[u]);
       }
     }
   }
@@ -268,14 +298,15 @@ int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   const int C = op.i[3], slots = slots_of(op, 21);
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_apply: bad args");
   MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14] && slots <= MSL_MAX_SLOTS, "bn_act_bwd_apply: bad dz view");
-  const int PL = 256 / (C / 4);
+  const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15]);
+  const int PL = 256 / (C / (v8 ? 8 : 4));
   const int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;  // pixels per thread (multiple of 4): amortises the per-channel constants, keeps >= 2048 blocks on large layers
   const long per_block = (long)PL * PPT;
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
   float* dgamma = (float*)op.p[7];
   float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
-#define BB(F) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<F>, grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT)
-  if (op.dtype == MSL_F32) BB(true); else BB(false);
+#define BB(F, V) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT)
+  if (op.dtype == MSL_F32) { if (v8) BB(true, 8); else BB(true, 4); } else { if (v8) BB(false, 8); else BB(false, 4); }
 #undef BB
   MSL_CHECK_LAUNCH("bn_act_bwd_apply");
   return MSL_OK;
@@ -286,9 +317,9 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[4] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[11] + C <= op.i[10], "colsum: bad args");
-  dim3 grid(reduce_grid(M, C, 1));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
-  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
+  dim3 grid(reduce_grid(M, C, 1, 4));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
+  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
   MSL_CHECK_LAUNCH("colsum");
   return MSL_OK;
 }
