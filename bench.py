@@ -237,7 +237,9 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             fl = conv_flops(it)
             cv_ms, cv_fl = cv_ms + ms, cv_fl + fl
             if best is None or ms > best[0]:
-                best = (ms, fl, f"conv kernel<{args.dtype}> ({tag})", args.dtype, tag, it)
+                kn = "conv3x3_lds_kernel" if it.i[25] else "conv_igemm_kernel"
+                mode = "dgrad, transposed-conv gather" if it.i[22] else ("dgrad as a stride-1 conv with flipped weights" if tag == "bwd" else "forward")
+                best = (ms, fl, f"{kn}<{args.dtype}> ({mode})", args.dtype, tag, it)
     ms, fl, kname, kdt, tag, op = best
     peak = PEAK[kdt]
     ach = fl / (ms * 1e-3) / 1e12
@@ -265,7 +267,7 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
     return roof
 
 
-def cpu_baseline_train(state, batch, seconds_budget=25.0):
+def cpu_baseline_train(state, batch, seconds_budget=20.0):
     """Oracle train step (train-mode forward + oracle loss + autograd backward) on the host cores, bounded sample."""
     from oracle import loss as OL
     from oracle import yolo11seg as Y
@@ -276,7 +278,7 @@ def cpu_baseline_train(state, batch, seconds_budget=25.0):
     m.load_state_dict(state)
     m.train()
     n_img, t0, steps, bs = 0, time.perf_counter(), 0, 2
-    while (time.perf_counter() - t0) < seconds_budget and steps < 8:
+    while (time.perf_counter() - t0) < seconds_budget and steps < 400:  # bounded sample: ~20 s of host work
         lo = (steps * bs) % len(batch["img"])
         x = torch.from_numpy(batch["img"][lo : lo + bs]).permute(0, 3, 1, 2).float() / 255
         keep = np.isin(batch["batch_idx"], np.arange(lo, lo + bs))

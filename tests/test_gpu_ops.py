@@ -54,6 +54,14 @@ CONV_CASES = [
     (1, 8, 8, 32, 32, 1, 1, 32, 0, 32, 0, 0, 0, 1),        # mask-coefficient head: fp32 out
     (3, 7, 5, 16, 8, 3, 1, 16, 0, 8, 0, 1, 0, 0),          # Cout=8 (half a channel tile), ragged pixel count
     (1, 40, 40, 32, 64, 3, 1, 32, 0, 64, 0, 1, 0, 0),
+    # 1x1 streaming kernel (bf16): LDS-resident weights, per-wave LDS-DMA rings, 16-byte stores
+    (2, 40, 40, 64, 256, 1, 1, 64, 0, 256, 0, 1, 0, 0),    # 8 output groups → 16-pixel slices
+    (2, 33, 47, 256, 64, 1, 1, 384, 128, 192, 64, 1, 1, 0),  # K = 256 from a concat slice, residual, ragged pixel count
+    (4, 80, 80, 48, 64, 1, 1, 48, 0, 64, 0, 1, 0, 0),      # K padded 48 → 64; several slices per wave
+    (1, 50, 50, 64, 48, 1, 1, 64, 0, 48, 0, 0, 1, 0),      # Cout = 48: half-filled output group; dgrad-like (no act, accumulate)
+    (1, 30, 30, 32, 64, 1, 1, 32, 0, 64, 0, 0, 0, 1),      # fp32 output (box head)
+    (1, 20, 20, 128, 96, 1, 1, 128, 0, 96, 0, 1, 0, 0),
+    (2, 20, 20, 384, 128, 1, 1, 384, 0, 128, 0, 1, 0, 0),  # too wide for LDS → generic kernel
 ]
 
 
@@ -427,3 +435,40 @@ def test_dw_wgrad(shape, dtype):
     torch.cuda.synchronize()
     err = float((dw.cpu() - 0.25 - ref).abs().max() / ref.abs().max())
     assert err < (1e-4 if dtype == MSL_F32 else 2e-3), err
+
+
+@pytest.mark.parametrize("case", [(2, 40, 40, 64, 64), (3, 33, 21, 48, 32), (1, 80, 80, 32, 128), (2, 20, 20, 256, 96), (1, 7, 5, 16, 8)])
+def test_conv1x1_batchnorm_statistics_epilogue(case):
+    """1x1 conv op with p[5]: per-channel (sum z, sum z^2) of the bf16-rounded outputs land in the slot-replicated fp64 accumulators."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    slots = 8
+    xbuf = _rand_act((N, H, W, Cin), MSL_BF16, g)
+    w = ((torch.rand((Cout, Cin, 1, 1), generator=g) * 2 - 1) / Cin**0.5).to(torch.bfloat16).float()
+    wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), torch.zeros(Cout), MSL_BF16, DEV)
+    xd = xbuf.to(DEV)
+    yd = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=DEV)
+    acc = torch.zeros(slots * 2 * Cout, dtype=torch.float64, device=DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr(), acc.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: Cout, 7: 1, 8: 1, 9: 0, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"],
+                           18: 0, 19: 0, 20: 0, 21: m["Cout_pad"], 23: slots})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    z = yd.float().cpu().reshape(-1, Cout).double()  # the stored (rounded) values
+    ref = F.conv2d(xbuf.float().permute(0, 3, 1, 2), w).permute(0, 2, 3, 1)
+    _close(yd.cpu(), ref, MSL_BF16, f"conv1x1 {case}")
+    got = acc.cpu().view(slots, Cout, 2).sum(0)
+    assert torch.allclose(got[:, 0], z.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(got[:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_conv_statistics_epilogue_is_refused_outside_the_1x1_kernel():
+    x = torch.zeros((1, 8, 8, 16), dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros((16, 16, 3, 3))
+    wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), torch.zeros(16), MSL_BF16, DEV)
+    y = torch.zeros((1, 8, 8, 16), dtype=torch.bfloat16, device=DEV)
+    acc = torch.zeros(64, dtype=torch.float64, device=DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(x.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.data_ptr(), acc.data_ptr()),
+                        i={0: 1, 1: 8, 2: 8, 3: 16, 4: 8, 5: 8, 6: 16, 7: 3, 8: 1, 9: 1, 10: 16, 11: 0, 12: 16, 13: 0, 16: m["K"], 17: m["Kpad"], 21: m["Cout_pad"], 23: 1})
+    with pytest.raises(hiplib.MslError):
+        hiplib.launch(op, _stream())

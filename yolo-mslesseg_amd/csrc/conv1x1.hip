@@ -1,0 +1,249 @@
+// 1x1 convolution (a skinny GEMM over the pixel stream) for bf16 tensors:  y[p][co] = act(sum_ci x[p][ci] * w[co][ci] + b[co]) (+ res)
+//
+// These layers carry 2 * (Cin + Cout) bytes per pixel and only Cin * Cout MACs: they are HBM streams, and the point of the
+// kernel is to keep enough bytes in flight while touching every activation byte once:
+//   * the whole weight matrix sits in LDS for the life of the workgroup (<= 64 KB; loaded once, persistent grid);
+//   * every WAVE owns its pixels: it copies 32-pixel slices of x to its private LDS ring with 16-byte LDS-DMA transfers
+//     (double-buffered: slice t+1 is in flight while slice t is multiplied) — no workgroup barrier in the loop;
+//   * one wave computes ALL output channels of its pixels (accumulators: 2 pixel tiles x Cout/16 MFMA tiles), so x is read once;
+//   * the A-operand rows are permuted so that a lane ends up with 8 CONSECUTIVE channels of its pixel → one 16-byte store;
+//   * optional epilogue for train-mode BatchNorm: per-channel sum and sum of squares of the (bf16-rounded) outputs, kept per
+//     lane across the wave's slices, folded once per workgroup and added to the slot-replicated fp64 accumulators that
+//     BN_FINALIZE reads — the separate BN_STATS pass over z disappears.
+// GEMM orientation as conv_igemm: D[co][p] = W[co][k] * X[k][p], v_mfma_f32_16x16x32_bf16.
+//
+// Replaces the 1x1 Conv arithmetic of ultralytics' C3k2 / C2PSA / SPPF / Segment modules (forward and input gradient) that the
+// reference reaches through model(img) / model.train()  [REF generar_predicciones.py:114, train.py:358].
+#include "msl_common.h"
+
+__device__ __attribute__((aligned(16))) unsigned c1_zero_page[4];
+
+struct C1Args {
+  const char* x;
+  const char* w;      // packed GEMM rows [Cout_pad16][Kpad] bf16
+  const float* bias;  // fp32 [Cout] or NULL
+  const char* res;
+  char* y;
+  double* acc;        // [slots][2*Cout] or NULL
+  long M;
+  int Cin, Cout, Kpad, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, slots, w_rows;
+};
+
+template <int NCP, bool STATS, int PT>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
+__global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int KS = a.Kpad >> 5;
+  const int pitch = a.Kpad * 2 + 16, cps = pitch >> 4;  // bytes / 16-byte chunks per LDS row (x pixels and weight rows alike)
+  constexpr int SP = PT * 16;                                        // pixels per slice
+  const int w_bytes = ((NCP * 32 * cps + 63) & ~63) * 16;            // LDS regions are whole 64-chunk DMA pieces
+  const int slice_chunks = SP * cps, slice_bytes = ((slice_chunks + 63) & ~63) * 16;
+  unsigned char* s_w = smem;
+  unsigned char* s_x = smem + w_bytes + wave * 2 * slice_bytes;      // this wave's ring: 2 slices
+
+  // ---- weights → LDS (rows >= w_rows and the pad chunk read the zero page)
+  {
+    const int total = NCP * 32 * cps, kchunks = a.Kpad >> 3;
+    for (int c0 = threadIdx.x & ~63; c0 < total; c0 += 256) {
+      const int cidx = c0 + lane, row = cidx / cps, ch = cidx - row * cps;
+      const bool ok = cidx < total && row < a.w_rows && ch < kchunks;
+      const char* src = ok ? a.w + ((long)row * a.Kpad + ch * 8) * 2 : (const char*)c1_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_w + (long)c0 * 16), 16, 0, 0);
+    }
+  }
+  const long tiles = (a.M + SP - 1) / SP;
+  const long stride = (long)gridDim.x * 4;
+  const int xchunks = a.Cin >> 3;
+
+  auto stage = [&](long tile, int buf) __attribute__((always_inline)) {
+    unsigned char* dst = s_x + buf * slice_bytes;
+    const long p0 = tile * SP;
+    for (int c0 = 0; c0 < slice_chunks; c0 += 64) {
+      const int cidx = c0 + lane, px = cidx / cps, ch = cidx - px * cps;
+      const bool ok = cidx < slice_chunks && ch < xchunks && p0 + px < a.M;
+      const char* src = ok ? a.x + ((p0 + px) * a.x_cs + a.x_co + ch * 8) * 2 : (const char*)c1_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + c0 * 16), 16, 0, 0);
+    }
+  };
+
+  float s1[STATS ? NCP : 1][2][4], s2[STATS ? NCP : 1][2][4];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int c = 0; c < NCP; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[c][m][r] = 0.f; s2[c][m][r] = 0.f; }
+  }
+
+  long tile = (long)blockIdx.x * 4 + wave;
+  if (tile < tiles) stage(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // weights visible to every wave (the only workgroup barrier before the epilogue)
+  int buf = 0;
+  const int arow = 8 * (li >> 2) + (li & 3);  // A-operand row permutation: MFMA row 4g+r of tile m ↔ channel 8g + 4m + r
+  for (; tile < tiles; tile += stride) {  // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slice (and its previous stores) have landed
+    if (tile + stride < tiles) stage(tile + stride, buf ^ 1);
+    const unsigned char* xs = s_x + buf * slice_bytes;
+    f32x4 acc[PT][NCP][2];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int c = 0; c < NCP; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[pt][c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kb = (ks * 32 + 8 * g) * 2;
+      bf16x8 bfr[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const bf16x8*)(xs + (pt * 16 + li) * pitch + kb);
+#pragma unroll
+      for (int c = 0; c < NCP; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x8 af = *(const bf16x8*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: lane (li, g) holds channels c*32 + 8g .. +7 of pixel p0 + 16*pt + li
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const long p = tile * SP + pt * 16 + li;
+      if (p >= a.M) continue;
+#pragma unroll
+      for (int c = 0; c < NCP; ++c) {
+        const int c0 = c * 32 + 8 * g;
+        if (c0 >= a.Cout) continue;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[pt][c][0][r]; v[4 + r] = acc[pt][c][1][r]; }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float vr = bf16_bits_to_f32(f32_to_bf16_bits(v[r]));  // statistics of the values actually stored
+            s1[c][r >> 2][r & 3] += vr;
+            s2[c][r >> 2][r & 3] = fmaf(vr, vr, s2[c][r >> 2][r & 3]);
+          }
+        }
+        if (a.bias) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += a.bias[c0 + r];
+        }
+        if (a.act) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+        }
+        if (a.res) {
+          float rv[8];
+          ldv<false, 8>(a.res, p * a.res_cs + a.res_co + c0, rv);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += rv[r];
+        }
+        if (a.out_f32) stv<true, 8>(a.y, p * a.y_cs + a.y_co + c0, v);
+        else stv<false, 8>(a.y, p * a.y_cs + a.y_co + c0, v);
+      }
+    }
+    buf ^= 1;
+  }
+  if constexpr (STATS) {
+    // fold: over the 16 pixel lanes (shuffles), over the 4 waves (LDS), then one fp64 atomic per channel and statistic
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done with LDS
+    float* red = (float*)smem;  // [4 waves][2][NCP*32]
+#pragma unroll
+    for (int c = 0; c < NCP; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t1 = s1[c][m][r], t2 = s2[c][m][r];
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
+          if (li == 0) {
+            const int ch = c * 32 + 8 * g + 4 * m + r;
+            red[(wave * 2 + 0) * NCP * 32 + ch] = t1;
+            red[(wave * 2 + 1) * NCP * 32 + ch] = t2;
+          }
+        }
+    __syncthreads();
+    double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * a.Cout;
+    for (int ch = threadIdx.x; ch < a.Cout; ch += 256) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * NCP * 32 + ch]; t2 += red[(w * 2 + 1) * NCP * 32 + ch]; }
+      atomicAdd(dst + 2 * ch, (double)t1);
+      atomicAdd(dst + 2 * ch + 1, (double)t2);
+    }
+  }
+}
+
+// ---- host
+static size_t c1_lds(int ncp, int Kpad, int pt) {
+  const int cps = (Kpad * 2 + 16) / 16;
+  return (size_t)(((ncp * 32 * cps + 63) & ~63) + 8 * ((pt * 16 * cps + 63) & ~63)) * 16;
+}
+static const size_t C1_LDS_MAX = 150 * 1024;
+
+// Eligibility test used by msl_launch_conv (bf16, 1x1, stride 1, pad 0, plain store, everything a multiple of 8, weights + rings fit in LDS)
+bool msl_conv1x1_eligible(const msl_op& op) {
+  const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
+  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0) return false;
+  if (Cin % 8 || Cout % 8 || Kpad % 32 || Kpad < Cin || Cout > 256) return false;
+  if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) return false;
+  if (op.p[3] && ((op.i[14] | op.i[15]) & 7)) return false;
+  return c1_lds((Cout + 31) / 32, Kpad, 1) <= C1_LDS_MAX;
+}
+
+template <int NCP, bool STATS, int PT>
+static int c1_launch(const C1Args& a, hipStream_t s) {
+  const size_t lds = c1_lds(NCP, a.Kpad, PT);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const long tiles = (a.M + PT * 16 - 1) / (PT * 16);
+  long per_cu = (160 * 1024) / (long)lds;  // workgroups that fit a CU's LDS
+  if (per_cu > 6) per_cu = 6;
+  if (per_cu < 1) per_cu = 1;
+  long blocks = (tiles + 3) / 4;
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  MSL_CHECK_LAUNCH("conv1x1");
+  return MSL_OK;
+}
+template <int NCP, bool STATS>
+static int c1_launch_pt(const C1Args& a, hipStream_t s) {
+  // 32-pixel slices (each weight fragment feeds two MFMAs) when at least two workgroups still fit a CU, else 16-pixel slices
+  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2) * 2 <= 160 * 1024) return c1_launch<NCP, STATS, 2>(a, s);  // wide outputs: keep the accumulators at one pixel tile
+  return c1_launch<NCP, STATS, 1>(a, s);
+}
+
+// MSL_OP_CONV slots (see msl_launch_conv) + p 5 = BatchNorm accumulator f64[slots][2*Cout] (optional, Cout <= 128), i 23 = slots
+int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
+  C1Args a;
+  a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2]; a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];
+  a.acc = (double*)op.p[5];
+  a.M = (long)op.i[0] * op.i[1] * op.i[2];
+  a.Cin = op.i[3]; a.Cout = op.i[6]; a.Kpad = op.i[17];
+  a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
+  a.act = op.i[18]; a.out_f32 = op.i[19]; a.slots = op.i[23] > 0 ? op.i[23] : 1;
+  a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
+  MSL_REQUIRE(a.x && a.w && a.y && a.M > 0 && msl_conv1x1_eligible(op), "conv1x1: bad args");
+  MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs, "conv1x1: bad dims / views");
+  MSL_REQUIRE(!a.acc || (a.Cout <= 128 && a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs Cout <= 128 and bf16 output");
+  const int ncp = (a.Cout + 31) / 32;
+#define C1(N) case N: return a.acc ? c1_launch_pt<N, true>(a, s) : c1_launch_pt<N, false>(a, s)
+#define C1N(N) case N: return c1_launch_pt<N, false>(a, s)
+  switch (ncp) {
+    C1(1); C1(2); C1(3); C1(4);
+    C1N(5); C1N(6); C1N(7); C1N(8);
+  }
+#undef C1
+#undef C1N
+  msl_set_error("conv1x1: Cout %d not supported", a.Cout);
+  return MSL_EINVAL;
+}

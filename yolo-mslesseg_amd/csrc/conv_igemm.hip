@@ -183,6 +183,8 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 
 int msl_launch_conv(const msl_op& op, hipStream_t s) {
   if (op.i[25] == 1) return msl_launch_conv3x3_lds(op, s);  // weights packed as the LDS image: tiled 3x3 kernel
+  if (msl_conv1x1_eligible(op)) return msl_launch_conv1x1(op, s);  // bf16 1x1: streaming kernel with LDS-resident weights (conv1x1.hip)
+  MSL_REQUIRE(!op.p[5], "conv: the BatchNorm-statistics epilogue (p[5]) exists only in the 1x1 streaming kernel and this op is not eligible for it");
   ConvArgs a;
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2];
   a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];

@@ -15,6 +15,9 @@
 // M ~ 3e6 pixels).  Same-address fp64 atomics serialise in L2 (~30 ns each, measured), so the accumulator is
 // replicated over `slots` copies (block b adds into copy b % slots) and the consumer sums the copies: that lets
 // the grid grow to ~4 blocks per CU — enough loads in flight to stream at HBM rate — without an atomic tail.
+// (Measured and rejected: folding the copies in the last-arriving workgroup — the arrival counter is itself a chain of
+// same-address RETURNING atomics, ~150 ns each, 4x slower than the separate finalize launch; and summing the copies in
+// every BN_ACT workgroup — the 2C x slots fp64 loads outweigh the small layers' own traffic.)
 // =========================================================================================================
 #define MSL_MAX_SLOTS 16
 // V = channels per thread: 8 (one 16-byte access of bf16) when the channel count and the views allow it, else 4
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
     }
   };
   if (pl < PL) {
-    constexpr int U = V == 8 ? 2 : 4;
+    constexpr int U = 4;
     const long step = (long)gridDim.x * PL;
     long p = (long)blockIdx.x * PL + pl;
     for (; p + (U - 1) * step < M; p += U * step) {

@@ -297,7 +297,18 @@ class TrainPlan(graph.Visitor):
         ar["n"] += n + pad
         return dst
 
-    def _conv_op(self, x: View, y: View, wt, bias_ptr, m, k, s, pad, act=0, res: Optional[View] = None, out_f32=False, store_mode=0, dgrad=0, cout=None):
+    def _conv1x1_stats_ok(self, x: View, z: View, cout, k, s, pad, m) -> bool:
+        """Mirror of msl_conv1x1_eligible + the statistics epilogue's limits (conv1x1.hip): only then may the conv op carry p[5]."""
+        if self.dtype != MSL_BF16 or k != 1 or s != 1 or pad != 0 or m.get("lds", 0):
+            return False
+        kpad = m["Kpad"]
+        if x.C % 8 or cout % 8 or kpad % 32 or cout > 128 or any(v % 8 for v in (x.cs, x.co, z.cs, z.co)):
+            return False
+        cps = (kpad * 2 + 16) // 16
+        lds = ((((cout + 31) // 32) * 32 * cps + 63) // 64 * 64 + 8 * ((16 * cps + 63) // 64 * 64)) * 16
+        return lds <= 150 * 1024
+
+    def _conv_op(self, x: View, y: View, wt, bias_ptr, m, k, s, pad, act=0, res: Optional[View] = None, out_f32=False, store_mode=0, dgrad=0, cout=None, stats_acc=None):
         cout = y.C if cout is None else cout
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: (y.H // 2 if store_mode else y.H), 5: (y.W // 2 if store_mode else y.W), 6: cout, 7: k, 8: s, 9: pad,
              10: x.cs, 11: x.co, 12: y.cs, 13: y.co, 16: m["K"], 17: m["Kpad"], 18: act, 19: 1 if out_f32 else 0, 20: store_mode, 21: m["Cout_pad"],
@@ -305,15 +316,20 @@ class TrainPlan(graph.Visitor):
         rp = 0
         if res is not None:
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
-        return hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bias_ptr, rp, y.t.data_ptr()), i=i)
+        if stats_acc is not None:  # BatchNorm sums in the conv epilogue (1x1 streaming kernel only)
+            i[23] = ACC_SLOTS
+        return hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bias_ptr, rp, y.t.data_ptr(), 0 if stats_acc is None else stats_acc.data_ptr()), i=i)
 
-    def _bn_forward(self, name, z: View, y: View, C, act, res):
+    def _bn_forward(self, name, z: View, y: View, C, act, res, acc=None):
+        """`acc` given: the producing conv already accumulated (sum z, sum z^2) into it — no BN_STATS pass."""
         st = self.store
-        acc = self._acc(C)
+        fused = acc is not None
+        acc = self._acc(C) if acc is None else acc
         stats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
         self._keep.append(stats)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C}
-        self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co, 21: ACC_SLOTS}))
+        if not fused:
+            self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co, 21: ACC_SLOTS}))
         self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var")),
                                i={**dims, 21: ACC_SLOTS}, f=(BN_EPS, BN_MOM)))
         i = {**dims, 10: z.cs, 11: z.co, 12: y.cs, 13: y.co, 18: 1 if act else 0}
@@ -400,8 +416,9 @@ class TrainPlan(graph.Visitor):
         self.taps[name] = y
         if bn:
             z = self._new(Ho, Wo, cout)
-            self._f(self._conv_op(x, z, wt, self.zeros.data_ptr(), wm, k, s, pad))
-            stats = self._bn_forward(name, z, y, cout, act, res)
+            acc = self._acc(cout) if self._conv1x1_stats_ok(x, z, cout, k, s, pad, wm) else None
+            self._f(self._conv_op(x, z, wt, self.zeros.data_ptr(), wm, k, s, pad, stats_acc=acc))
+            stats = self._bn_forward(name, z, y, cout, act, res, acc=acc)
         else:
             z, stats = None, None
             self._f(self._conv_op(x, y, wt, st.ptr(name + ".bias"), wm, k, s, pad, act=1 if act else 0, res=res, out_f32=f32_out))
