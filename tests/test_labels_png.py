@@ -1,0 +1,133 @@
+"""Dataset-preparation formats: PNG reader/writer and the mask → polygon converter.
+
+OpenCV is not in this image, so `find_external_contours` is checked against hand-derived cases of cv2.findContours'
+documented behaviour (Suzuki-Abe border following, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) and against its defining properties;
+parity with cv2 itself is unpinned.  The PNG reader is cross-checked against Pillow on files Pillow / matplotlib write."""
+import numpy as np
+import pytest
+
+from mslesseg_amd import labels as L
+from mslesseg_amd import pngio
+
+
+def test_png_roundtrip_and_gray_rule(tmp_path):
+    rng = np.random.default_rng(0)
+    for shape in [(37, 53), (20, 31, 3), (16, 16, 4), (5, 7, 1)]:
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        pngio.write_png(tmp_path / "a.png", a)
+        raw = pngio.read_png(tmp_path / "a.png", "raw")
+        assert np.array_equal(raw.reshape(a.shape), a)
+    rgb = rng.integers(0, 256, size=(9, 11, 3), dtype=np.uint8)
+    pngio.write_png(tmp_path / "c.png", rgb)
+    assert np.array_equal(pngio.read_png(tmp_path / "c.png", "bgr"), rgb[..., ::-1])
+    g = pngio.read_png(tmp_path / "c.png", "gray").astype(np.int64)
+    r_, g_, b_ = (rgb[..., i].astype(np.int64) for i in range(3))
+    assert np.array_equal(g, (r_ * 4899 + g_ * 9617 + b_ * 1868 + 8192) >> 14)
+    grey3 = np.repeat(rng.integers(0, 256, size=(8, 8, 1), dtype=np.uint8), 3, axis=2)
+    pngio.write_png(tmp_path / "g.png", grey3)
+    assert np.array_equal(pngio.read_png(tmp_path / "g.png", "gray"), grey3[..., 0])  # equal channels survive the fixed-point grey exactly
+
+
+def test_png_reader_matches_pillow_on_filtered_files(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:64, 0:80]
+    smooth = ((np.sin(yy / 7.0) + np.cos(xx / 5.0)) * 60 + 128).clip(0, 255).astype(np.uint8)  # smooth → Pillow picks Sub/Up/Avg/Paeth filters
+    cases = {"L": smooth, "RGB": np.stack([smooth, smooth[::-1], rng.integers(0, 256, smooth.shape, dtype=np.uint8)], -1),
+             "RGBA": np.stack([smooth, smooth.T[:64, :64].repeat(2, 1)[:, :80], smooth, 255 - smooth], -1), "LA": np.stack([smooth, 255 - smooth], -1)}
+    for mode, arr in cases.items():
+        Image.fromarray(arr, mode).save(tmp_path / f"{mode}.png", optimize=True)
+        ref = np.asarray(Image.open(tmp_path / f"{mode}.png"))
+        got = pngio.read_png(tmp_path / f"{mode}.png", "raw")
+        assert np.array_equal(got.reshape(ref.shape), ref), mode
+    pal = Image.fromarray(smooth // 32, "P")
+    pal.putpalette([v for i in range(256) for v in (i, 255 - i, (i * 7) % 256)])
+    pal.save(tmp_path / "p.png")
+    assert np.array_equal(pngio.read_png(tmp_path / "p.png", "bgr")[..., ::-1], np.asarray(Image.open(tmp_path / "p.png").convert("RGB")))
+    bw = Image.fromarray((smooth > 128).astype(np.uint8) * 255).convert("1")
+    bw.save(tmp_path / "b.png")
+    assert np.array_equal(pngio.read_png(tmp_path / "b.png", "gray"), (smooth > 128).astype(np.uint8) * 255)
+
+
+def test_png_reader_on_a_slice_saved_like_the_reference(tmp_path):
+    """plt.imsave(path, corte.T, cmap="gray", origin="lower") [REF extraer_dataset.py:192] → what cv2.imread would give = our slice_as_png_array."""
+    plt = pytest.importorskip("matplotlib.pyplot")
+    from mslesseg_amd.volume import slice_as_png_array
+
+    rng = np.random.default_rng(2)
+    corte = rng.random((31, 45)) * 900.0
+    plt.imsave(tmp_path / "s.png", corte.T, cmap="gray", origin="lower")
+    assert np.array_equal(pngio.read_png(tmp_path / "s.png", "bgr"), slice_as_png_array(corte))
+
+
+def _mask(rows):
+    return np.array([[1 if c == "#" else 0 for c in r] for r in rows], np.uint8)
+
+
+def test_contours_hand_cases():
+    sq = _mask(["##", "##"])
+    (c,) = L.find_external_contours(sq)
+    assert c.tolist() == [[0, 0], [0, 1], [1, 1], [1, 0]]  # top-left, bottom-left, bottom-right, top-right (as cv2 orders a filled square)
+    (c,) = L.find_external_contours(_mask(["###"]))
+    assert c.tolist() == [[0, 0], [2, 0]]
+    (c,) = L.find_external_contours(_mask(["#"]))
+    assert c.tolist() == [[0, 0]]
+    (c,) = L.find_external_contours(_mask([".....", ".###.", ".###.", ".###.", "....."]))
+    assert c.tolist() == [[1, 1], [1, 3], [3, 3], [3, 1]]
+    (c,) = L.find_external_contours(_mask(["..#..", ".###.", "#####", ".###.", "..#.."]))  # diamond: 4 diagonal runs
+    assert c.tolist() == [[2, 0], [0, 2], [2, 4], [4, 2]]
+    ring_with_island = _mask(["#######", "#.....#", "#..#..#", "#.....#", "#######"])
+    cs = L.find_external_contours(ring_with_island)
+    assert len(cs) == 1 and cs[0].tolist() == [[0, 0], [0, 4], [6, 4], [6, 0]]  # hole border and the island inside it are not external
+    two = L.find_external_contours(_mask(["##..#", "##..#", "....."]))
+    assert [c.tolist() for c in two] == [[[0, 0], [0, 1], [1, 1], [1, 0]], [[4, 0], [4, 1]]]
+    diag = L.find_external_contours(_mask(["#.", ".#"]))  # 8-connectivity: one component
+    assert len(diag) == 1
+
+
+def test_contours_properties_on_random_blobs():
+    from scipy import ndimage
+
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        m = ndimage.binary_dilation(rng.random((40, 56)) > 0.985, iterations=int(rng.integers(1, 4)))
+        m &= rng.random(m.shape) > 0.03  # pepper holes
+        cs = L.find_external_contours(m)
+        padded = np.pad(m, 1)
+        lab, n = ndimage.label(padded, structure=np.ones((3, 3), int))
+        bg, _ = ndimage.label(~padded)
+        outer = set()
+        for k in range(1, n + 1):
+            ys, xs = np.nonzero(lab == k)
+            i = np.lexsort((xs, ys))[0]
+            if bg[ys[i], xs[i] - 1] == bg[0, 0]:
+                outer.add(k)
+        assert len(cs) == len(outer)
+        for c in cs:
+            assert m[c[:, 1], c[:, 0]].all()  # vertices are foreground pixels
+            k = lab[c[0, 1] + 1, c[0, 0] + 1]
+            assert all(lab[y + 1, x + 1] == k for x, y in c.tolist())  # all on one component
+            d = np.diff(np.vstack([c, c[:1]]), axis=0)
+            assert all(dx == 0 or dy == 0 or abs(dx) == abs(dy) for dx, dy in d.tolist())  # straight or diagonal runs only
+            for x, y in c.tolist():  # every vertex touches the background (8-neighbourhood, frame = background)
+                assert not padded[y : y + 3, x : x + 3].all()
+
+
+def test_convert_segment_masks_to_yolo_seg(tmp_path):
+    from ultralytics.data.converter import convert_segment_masks_to_yolo_seg
+
+    masks, out = tmp_path / "GT_masks", tmp_path / "labels"
+    masks.mkdir()
+    m = np.zeros((20, 40), np.uint8)
+    m[2:6, 4:10] = 1      # rectangle → 4 points
+    m[10, 30] = 1         # single pixel → dropped (< 3 points)
+    m[12:15, 12] = 1      # vertical bar → 2 points → dropped
+    m[15:19, 20:25] = 7   # unknown class value → warning, skipped
+    pngio.write_png(masks / "P1_10.png", m)
+    pngio.write_png(masks / "P1_11.png", np.zeros((20, 40), np.uint8))
+    convert_segment_masks_to_yolo_seg(masks_dir=masks, output_dir=out, classes=1)
+    assert (out / "P1_11.txt").read_text() == ""
+    lines = (out / "P1_10.txt").read_text().splitlines()
+    assert lines == ["0 0.1 0.1 0.1 0.25 0.225 0.25 0.225 0.1"]
+    (inst,) = L.read_label_file(out / "P1_10.txt")
+    assert inst[0] == 0 and inst[1].shape == (4, 2)
