@@ -1,0 +1,63 @@
+"""Enhancement variants against their definitions and, where the library exists in this image, against the
+real thing: matplotlib renders the enhanced uint8 slice exactly as `slice_as_png_array` predicts; `equalize_hist` / `clahe_apply`
+are checked on hand-computable cases of OpenCV's algorithms (OpenCV itself is absent: CLAHE parity unpinned)."""
+import numpy as np
+import pytest
+
+from mslesseg_amd import enhance as E
+from mslesseg_amd import pngio
+from mslesseg_amd.volume import slice_as_png_array
+
+
+def test_normalise_gc_lt_follow_the_reference_expressions():
+    rng = np.random.default_rng(0)
+    x = rng.random((40, 30)) * 1234.5
+    u = E.normalizar_a_uint8(x)
+    f = x.astype(np.float32)
+    f -= f.min()
+    assert u.dtype == np.uint8 and np.array_equal(u, (255 * (f / np.ptp(f))).astype(np.uint8)) and u.max() == 255 and u.min() == 0
+    assert np.array_equal(E.normalizar_a_uint8(np.zeros((4, 4))), np.zeros((4, 4), np.uint8))
+    table = ((np.linspace(0, 1, 256) ** 2.0) * 255).astype(np.uint8)
+    assert np.array_equal(E.gc(x), table[u]) and table[255] == 255 and table[128] == 64
+    l = E.lt(x)
+    assert l.dtype == np.uint8 and l.max() == 255 and l[u == 0].max() == 0 and (np.diff(l.reshape(-1)[np.argsort(u.reshape(-1), kind="stable")].astype(int)) >= 0).all()
+
+
+def test_equalize_hist_hand_cases():
+    g = np.array([[10, 10, 20, 30]], np.uint8)  # hist: 10→2, 20→1, 30→1; scale = 255/(4-2)
+    assert E.equalize_hist(g).tolist() == [[0, 0, 128, 255]]  # 127.5 rounds half to even → 128
+    assert E.equalize_hist(np.full((3, 3), 77, np.uint8)).tolist() == [[77] * 3] * 3
+    rng = np.random.default_rng(1)
+    r = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    e = E.equalize_hist(r)
+    assert e.min() == 0 and e.max() == 255 and (np.diff(e.reshape(-1)[np.argsort(r.reshape(-1), kind="stable")].astype(int)) >= 0).all()
+
+
+def test_clahe_apply_properties():
+    flat = np.full((64, 64), 100, np.uint8)
+    out = E.clahe_apply(flat, 2.0, (8, 8))
+    assert (out == out[0, 0]).all()  # identical tile LUTs blend to a constant
+    rng = np.random.default_rng(2)
+    img = (rng.random((70, 90)) * 255).astype(np.uint8)  # not divisible by 8: reflection padding path
+    out = E.clahe_apply(img, 2.0, (8, 8))
+    assert out.shape == img.shape and out.dtype == np.uint8
+    # no clipping + one tile = plain histogram equalisation with CLAHE's (area-normalised, inclusive) LUT
+    one = E.clahe_apply(img[:64, :64], 0.0, (1, 1))
+    hist = np.bincount(img[:64, :64].reshape(-1), minlength=256)
+    lut = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * (np.float32(255) / np.float32(64 * 64))), 0, 255).astype(np.uint8)
+    assert np.array_equal(one, lut[img[:64, :64]])
+
+
+@pytest.mark.parametrize("mejora", ["HE", "CLAHE", "GC", "LT"])
+def test_enhanced_slice_renders_like_matplotlib(tmp_path, mejora):
+    """aplicar_mejora → plt.imsave(.T, cmap="gray", origin="lower") → imread  ==  slice_as_png_array(aplicar_mejora(...))."""
+    plt = pytest.importorskip("matplotlib.pyplot")
+    rng = np.random.default_rng(3)
+    corte = rng.random((37, 52)) ** 2 * 700.0
+    enh = E.aplicar_mejora(corte, mejora)
+    assert enh.dtype == np.uint8 and enh.shape == corte.shape
+    plt.imsave(tmp_path / "e.png", enh.T, cmap="gray", origin="lower")
+    assert np.array_equal(pngio.read_png(tmp_path / "e.png", "bgr"), slice_as_png_array(enh))
+    assert E.aplicar_mejora(corte, None) is corte
+    with pytest.raises(ValueError):
+        E.aplicar_mejora(corte, "XX")

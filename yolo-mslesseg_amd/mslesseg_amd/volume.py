@@ -88,11 +88,14 @@ def take_slice(vol: np.ndarray, plano: str, i: int) -> np.ndarray:
 
 
 def slice_as_png_array(vol_slice: np.ndarray) -> np.ndarray:
-    """The uint8 [H,W,3] array cv2.imread returns for a slice saved by plt.imsave(corte.T, cmap="gray", origin="lower")."""
-    a = np.asarray(vol_slice, dtype=np.float64).T
+    """The uint8 [H,W,3] array cv2.imread returns for a slice saved by plt.imsave(corte.T, cmap="gray", origin="lower").
+    matplotlib normalises in the input's own float type and in float32 for integer input (the enhanced uint8 variants)."""
+    src = np.asarray(vol_slice)
+    ft = np.float64 if src.dtype == np.float64 else np.float32
+    a = src.astype(ft).T
     vmin, vmax = a.min(), a.max()
     norm = (a - vmin) / (vmax - vmin) if vmax > vmin else np.zeros_like(a)
-    g = _GRAY_LUT[np.clip((norm * 256).astype(np.int64), 0, 255)][::-1]
+    g = _GRAY_LUT[np.clip((norm * ft(256)).astype(np.int64), 0, 255)][::-1]
     return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
 
 
@@ -140,16 +143,19 @@ def dice(gt: torch.Tensor, pred: torch.Tensor) -> Tuple[float, float]:
     return d, float(np.round(d, 3))
 
 
-def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Iterable[int]] = None, batch: int = 128) -> torch.Tensor:
+def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Iterable[int]] = None, batch: int = 128, mejora: Optional[str] = None) -> torch.Tensor:
     """FLAIR volume → float32 {0,1} volume of `plano` predictions on device (slices never predicted stay 0).
-    Whole-volume batched replacement of generar_predicciones + reconstruir_volumen for one plane."""
+    Whole-volume batched replacement of generar_predicciones + reconstruir_volumen for one plane.  `mejora` ∈ {None, "HE", "CLAHE", "GC",
+    "LT"} applies the reference's enhancement variant to every slice before it is rendered [REF Paciente.py:195-222]."""
+    from .enhance import aplicar_mejora
+
     eng = model._get_engine()
     dev = eng.device
     idx = list(range(flair.shape[PLANE_AXIS[plano]])) if indices is None else [int(i) for i in indices]
     vol = torch.zeros(flair.shape, dtype=torch.float32, device=dev)
     for b0 in range(0, len(idx), batch):
         chunk = idx[b0 : b0 + batch]
-        imgs = np.stack([slice_as_png_array(take_slice(flair, plano, i)) for i in chunk])
+        imgs = np.stack([slice_as_png_array(aplicar_mejora(take_slice(flair, plano, i), mejora)) for i in chunk])
         out = eng.predict_slices(torch.from_numpy(imgs))  # uint8 [S, W, H] = the array the reference would save per slice
         insert_slices(vol, out, chunk, plano)
     return vol
