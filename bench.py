@@ -253,6 +253,18 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             "program_ms": {"total_fwd_bwd_pack": round(total, 3),
                            **{f"{t}:{names.get(k, 'torch-attention')}": round(v, 3) for (t, k), v in sorted(by_kind.items(), key=lambda x: -x[1])[:14]}},
             "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP_PER_SLICE_640 * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4)}
+    pmc = ROOT / "profiles" / "pmc_latest.json"  # written by scripts/pmc_traffic.py from rocprofv3 --pmc passes over --replay-dominant
+    if pmc.exists():
+        rec = json.loads(pmc.read_text())
+        if rec.get("kernel") == kname and rec.get("launch_shape") == roof["launch_shape"]:
+            roof["traffic"] = rec["traffic_bytes_per_launch"]
+            roof["traffic_note"] = rec.get("note", "")
+    if args.replay_dominant > 0:  # for the PMC passes: the dominant op alone, back to back, as the LAST dispatches of its kernel
+        s_ = torch.cuda.current_stream(tr.device).cuda_stream
+        for _ in range(args.replay_dominant):
+            hiplib.launch(op, s_)
+        torch.cuda.synchronize(tr.device)
+        roof["replayed"] = args.replay_dominant
     if args.op_table:
         with open(args.op_table, "w") as f:
             f.write(f"# train: per-op HIP-event times, batch {tr.batch}, {args.size}x{args.size}, {args.dtype}; total {total:.3f} ms\n")
@@ -305,6 +317,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replay-dominant", type=int, default=0, help="after the roofline pass, launch the dominant op this many more times (PMC collection)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-op replay (for a clean rocprofv3 trace of the timed steps only)")
     ap.add_argument("--no-infer", action="store_true", help="train mode: skip the short predict run reported under 'infer'")
     ap.add_argument("--op-table", default="", help="write the per-op timing table to this file")
