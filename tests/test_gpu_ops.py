@@ -472,3 +472,33 @@ def test_conv_statistics_epilogue_is_refused_outside_the_1x1_kernel():
                         i={0: 1, 1: 8, 2: 8, 3: 16, 4: 8, 5: 8, 6: 16, 7: 3, 8: 1, 9: 1, 10: 16, 11: 0, 12: 16, 13: 0, 16: m["K"], 17: m["Kpad"], 21: m["Cout_pad"], 23: 1})
     with pytest.raises(hiplib.MslError):
         hiplib.launch(op, _stream())
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1)])
+def test_stride2_input_gradient_as_parity_classes(case, dtype):
+    """dx of a 3x3/s2/p1 conv = four stride-1 passes over dz (1x1, 1x2, 2x1, 2x2 kernels) stored on the (2Y+a, 2X+b) sub-lattices
+    (MSL_OP_CONV store mode 2, rectangular kernels) — against torch.nn.grad.conv2d_input; with and without accumulation."""
+    N, H, W, Cin, Cout, accumulate = case
+    g = torch.Generator().manual_seed(sum(case))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cout * 9) ** 0.5).to(_tdt(dtype)).float()
+    dz = _rand_act((N, Ho, Wo, Cout), dtype, g)
+    prev = _rand_act((N, H, W, Cin), dtype, g)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dz.float().permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    if accumulate:
+        ref = ref + prev.float()
+    dzd, gx = dz.to(DEV), prev.clone().to(DEV)
+    for a in (0, 1):
+        for b in (0, 1):
+            kys, kxs = ([1] if a == 0 else [2, 0]), ([1] if b == 0 else [2, 0])
+            wc = w.permute(1, 2, 3, 0)[:, kys][:, :, kxs].reshape(Cin, -1)  # rows ci, K = (ty, tx, co)
+            wt, bt, m = E.pack_gemm(wc, torch.zeros(Cin), dtype, DEV)
+            kh, kw = len(kys), len(kxs)
+            op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(dzd.data_ptr(), wt.data_ptr(), bt.data_ptr(), gx.data_ptr() if accumulate else 0, gx.data_ptr()),
+                                i={0: N, 1: Ho, 2: Wo, 3: Cout, 4: (H - a + 1) // 2, 5: (W - b + 1) // 2, 6: Cin, 7: kh if kh == kw else kh * 16 + kw, 8: 1, 9: 0,
+                                   10: Cout, 11: 0, 12: Cin, 13: 0, 14: Cin, 15: 0, 16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 2, 21: m["Cout_pad"],
+                                   23: a | (b << 1) | ((H & 1) << 2) | ((W & 1) << 3)})
+            hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(gx.cpu(), ref, dtype, f"s2 dgrad {case}")

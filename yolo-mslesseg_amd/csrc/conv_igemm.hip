@@ -29,6 +29,7 @@ struct ConvArgs {
   int N, H, W, Cin, Ho, Wo, Cout, k, stride, pad;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int K, Kpad, act, out_f32, store_mode, Cout_pad, dgrad;
+  int kw, lat_a, lat_b, full_h, full_w;  // kernel width (taps per row); store_mode 2: output pixel (Y,X) → (2Y+lat_a, 2X+lat_b) of a full_h x full_w image
 };
 
 template <bool F32, int COT, int PT>
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   int kk = g * CH;
   int tap = kk / a.Cin;
   int ci = kk - tap * a.Cin;
-  int ty = tap / a.k, tx = tap - ty * a.k;
+  int ty = tap / a.kw, tx = tap - ty * a.kw;
 
   for (int ks = 0; ks < a.Kpad; ks += KSTEP) {
     uint4 av[COT], bv[PT];
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     ci += KSTEP;
     while (ci >= a.Cin) {
       ci -= a.Cin;
-      if (++tx == a.k) { tx = 0; ++ty; }
+      if (++tx == a.kw) { tx = 0; ++ty; }
     }
   }
 
@@ -124,12 +125,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     long p = pbase + pt * 16 + lp;
     long opix = p;
     int n = 0, oy = 0, ox = 0;
-    if (a.store_mode == 1) {
+    if (a.store_mode != 0) {
       n = (int)(p / HoWo);
       int r = (int)(p - (long)n * HoWo);
       oy = r / a.Wo;
       ox = r - oy * a.Wo;
     }
+    if (a.store_mode == 2) opix = ((long)n * a.full_h + (2 * oy + a.lat_a)) * a.full_w + (2 * ox + a.lat_b);  // sub-lattice of the full image
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
       int co0 = cobase + c * 16 + g * 4;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
       const bool full = (co0 + 4 <= a.Cout) && ((a.Cout & 3) == 0);
       if (a.res) {
-        long ri = p * a.res_cs + a.res_co + co0;
+        long ri = opix * a.res_cs + a.res_co + co0;  // store_mode 1 carries no residual; mode 2 adds at the lattice position
         if (full) {
           float rv[4];
           ld4<F32>(a.res, ri, rv);
@@ -192,6 +194,11 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
   a.k = op.i[7]; a.stride = op.i[8]; a.pad = op.i[9]; a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12];
   a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15]; a.K = op.i[16]; a.Kpad = op.i[17]; a.act = op.i[18];
   a.out_f32 = op.i[19]; a.store_mode = op.i[20]; a.Cout_pad = op.i[21]; a.dgrad = op.i[22];
+  int kh = a.k;
+  a.kw = a.k;
+  if (op.i[7] >= 16) { kh = op.i[7] >> 4; a.kw = op.i[7] & 15; a.k = kh > a.kw ? kh : a.kw; }  // rectangular kernel: i[7] = kh*16 + kw
+  a.lat_a = op.i[23] & 1; a.lat_b = (op.i[23] >> 1) & 1;
+  a.full_h = 2 * a.H - ((op.i[23] >> 2) & 1); a.full_w = 2 * a.W - ((op.i[23] >> 3) & 1);  // (H, W) = the stride-2 conv's output = this pass's source
   const bool f32 = op.dtype == MSL_F32;
   const int ch = f32 ? 4 : 8, kstep = f32 ? 16 : 32;
   MSL_REQUIRE(op.dtype == MSL_F32 || op.dtype == MSL_BF16, "conv: bad dtype %d", op.dtype);
@@ -199,21 +206,24 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.Cout > 0 && a.Cin > 0, "conv: bad dims");
   MSL_REQUIRE(a.k >= 1 && a.k <= 3, "conv: k=%d unsupported", a.k);
   MSL_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride=%d unsupported", a.stride);
-  if (!a.dgrad)
-    MSL_REQUIRE(a.Ho == (a.H + 2 * a.pad - a.k) / a.stride + 1 && a.Wo == (a.W + 2 * a.pad - a.k) / a.stride + 1,
+  if (a.store_mode == 2)  // one parity class of a stride-2 transposed conv: a stride-1 pass over the (H, W) gradient, outputs on a sub-lattice
+    MSL_REQUIRE(!a.dgrad && a.stride == 1 && a.pad == 0 && a.Ho <= a.H && a.Wo <= a.W && a.Ho >= a.H - 1 && a.Wo >= a.W - 1 && 2 * (a.Ho - 1) + a.lat_a < a.full_h &&
+                    2 * (a.Wo - 1) + a.lat_b < a.full_w, "conv lattice store: class grid %dx%d inconsistent with source %dx%d", a.Ho, a.Wo, a.H, a.W);
+  else if (!a.dgrad)
+    MSL_REQUIRE(kh == a.kw && a.Ho == (a.H + 2 * a.pad - a.k) / a.stride + 1 && a.Wo == (a.W + 2 * a.pad - a.k) / a.stride + 1,
                 "conv: output dims %dx%d inconsistent with input %dx%d k%d s%d p%d", a.Ho, a.Wo, a.H, a.W, a.k, a.stride, a.pad);
   else  // dgrad: (H,W) is the gradient being read, (Ho,Wo) the forward input being produced
     MSL_REQUIRE(a.H == (a.Ho + 2 * a.pad - a.k) / a.stride + 1 && a.W == (a.Wo + 2 * a.pad - a.k) / a.stride + 1 && a.store_mode == 0,
                 "conv dgrad: source dims %dx%d inconsistent with destination %dx%d k%d s%d p%d", a.H, a.W, a.Ho, a.Wo, a.k, a.stride, a.pad);
   MSL_REQUIRE(a.Cin % ch == 0 && a.x_cs % ch == 0 && a.x_co % ch == 0, "conv: Cin/x_cs/x_co must be multiples of %d", ch);
   MSL_REQUIRE(a.x_co + a.Cin <= a.x_cs, "conv: input view exceeds channel stride");
-  MSL_REQUIRE(a.K == a.k * a.k * a.Cin && a.Kpad % kstep == 0 && a.Kpad >= a.K, "conv: K=%d Kpad=%d inconsistent", a.K, a.Kpad);
+  MSL_REQUIRE(a.K == kh * a.kw * a.Cin && a.Kpad % kstep == 0 && a.Kpad >= a.K, "conv: K=%d Kpad=%d inconsistent", a.K, a.Kpad);
   MSL_REQUIRE(a.Cout_pad % 16 == 0 && a.Cout_pad >= a.Cout, "conv: Cout_pad=%d", a.Cout_pad);
-  MSL_REQUIRE(a.store_mode == 0 || (a.store_mode == 1 && a.Cout % 16 == 0), "conv: bad store_mode");
+  MSL_REQUIRE(a.store_mode == 0 || a.store_mode == 2 || (a.store_mode == 1 && a.Cout % 16 == 0), "conv: bad store_mode");
   const int cstore = a.store_mode == 1 ? a.Cout / 4 : a.Cout;
   MSL_REQUIRE(a.y_co + cstore <= a.y_cs, "conv: output view exceeds channel stride");
   if ((a.Cout & 3) == 0) MSL_REQUIRE(a.y_cs % 4 == 0 && a.y_co % 4 == 0, "conv: y_cs/y_co must be multiples of 4");
-  if (a.res) MSL_REQUIRE(a.store_mode == 0 && a.res_co + a.Cout <= a.res_cs && ((a.Cout & 3) || (a.res_cs % 4 == 0 && a.res_co % 4 == 0)),
+  if (a.res) MSL_REQUIRE(a.store_mode != 1 && a.res_co + a.Cout <= a.res_cs && ((a.Cout & 3) || (a.res_cs % 4 == 0 && a.res_co % 4 == 0)),
                          "conv: bad residual view");
   const int tiles = a.Cout_pad / 16;
   const int cot = tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1);

@@ -401,9 +401,27 @@ class TrainPlan(graph.Visitor):
             widx, wm = _gemm_rows_idx(idx4.permute(0, 2, 3, 1).reshape(cout, -1), self.dtype)
         wt = self._packed(widx)
         # dgrad weights: rows = ci, K = (ky,kx,co)
+        dcls = []
         if k == 3 and s == 1 and _lds_ok(cout, cin, 3, self.dtype):
             didx, dm = _lds_image_idx(idx4.permute(1, 0, 2, 3).flip(2, 3), self.dtype)  # forward-style conv of dz with flipped taps
             d_mode = 0
+        elif k == 3 and s == 2 and pad == 1:
+            # stride-2 input gradient as 4 parity classes: dx[2Y+a, 2X+b] only receives the taps ky ≡ a+1, kx ≡ b+1 (mod 2) — a stride-1
+            # pass over dz with a 1x1 / 1x2 / 2x1 / 2x2 kernel (offset 0 ↔ tap 1 or 2, offset +1 ↔ tap 0) stored on that sub-lattice.
+            # The all-taps gather form does 9 tap-GEMMs per output pixel of which 2.25 are non-zero.
+            d_mode = 2
+            base = idx4.permute(1, 2, 3, 0)  # [ci][ky][kx][co]
+            for pa in (0, 1):
+                for pb in (0, 1):
+                    kys, kxs = ([1] if pa == 0 else [2, 0]), ([1] if pb == 0 else [2, 0])
+                    rows = base[:, kys][:, :, kxs]
+                    if cpad != cout:
+                        padded = torch.full((cin, len(kys), len(kxs), cpad), -1, dtype=torch.int64)
+                        padded[..., :cout] = rows
+                        rows = padded
+                    cidx, cm = _gemm_rows_idx(rows.reshape(cin, -1), self.dtype)
+                    dcls.append((pa, pb, len(kys), len(kxs), self._packed(cidx), cm))
+            didx, dm = dcls[0][4], dcls[0][5]
         else:
             drows = idx4.permute(1, 2, 3, 0)  # [ci][ky][kx][co]
             if cpad != cout:
@@ -412,7 +430,7 @@ class TrainPlan(graph.Visitor):
                 drows = padded
             didx, dm = _gemm_rows_idx(drows.reshape(cin, -1), self.dtype)
             d_mode = 1
-        wd = self._packed(didx)
+        wd = self._packed(didx) if d_mode != 2 else None
         self.taps[name] = y
         if bn:
             z = self._new(Ho, Wo, cout)
@@ -450,6 +468,13 @@ class TrainPlan(graph.Visitor):
             gres = None if first else gx
             if d_mode == 0:
                 ops.append(self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, 3, 1, 1, res=gres, cout=cin))
+            elif d_mode == 2:
+                for pa, pb, kh, kw, wcls, cm in dcls:
+                    op = self._conv_op(dz, gx, wcls, self.zeros.data_ptr(), cm, kh, 1, 0, res=gres, cout=cin, store_mode=2)
+                    op.i[4], op.i[5] = (x.H - pa + 1) // 2, (x.W - pb + 1) // 2  # class grid
+                    op.i[7] = kh if kh == kw else kh * 16 + kw
+                    op.i[23] = pa | (pb << 1) | ((x.H & 1) << 2) | ((x.W & 1) << 3)
+                    ops.append(op)
             else:
                 op = self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, k, s, pad, res=gres, dgrad=1, cout=cin)
                 ops.append(op)
