@@ -320,24 +320,31 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[4] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[11] + C <= op.i[10], "colsum: bad args");
-  dim3 grid(reduce_grid(M, C, 1, 4));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
-  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], 1);
+  const int slots = slots_of(op, 21);  // acc = f64[slots][C]; F64_DRAIN (i 2 = slots, i 3 = C) folds them
+  MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "colsum: too many accumulator slots");
+  dim3 grid(reduce_grid(M, C, slots, 4));
+  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots);
+  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots);
   MSL_CHECK_LAUNCH("colsum");
   return MSL_OK;
 }
 
 // F64_TO_F32: dst f32[n] = (float)src f64[n]; src = 0 (drains a reduction accumulator into the flat gradient buffer)
-__global__ void f64_drain_kernel(double* __restrict__ src, float* __restrict__ dst, int n, int stride) {
+__global__ void f64_drain_kernel(double* __restrict__ src, float* __restrict__ dst, int n, int stride, int slots, int slot_stride) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  dst[i] = (float)src[(long)i * stride];
-  src[(long)i * stride] = 0.0;
+  double a = 0.0;
+  for (int j = 0; j < slots; ++j) {
+    double* q = src + (long)j * slot_stride + (long)i * stride;
+    a += *q;
+    *q = 0.0;
+  }
+  dst[i] = (float)a;
 }
-// p 0 src f64, 4 dst f32 ; i 0 n, 1 stride
+// p 0 src f64, 4 dst f32 ; i 0 n, 1 stride, 2 slots (0 = 1), 3 elements between slot copies
 int msl_launch_f64_drain(const msl_op& op, hipStream_t s) {
-  MSL_REQUIRE(op.p[0] && op.p[4] && op.i[0] > 0 && op.i[1] > 0, "f64_drain: bad args");
-  hipLaunchKernelGGL(f64_drain_kernel, dim3((op.i[0] + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[4], op.i[0], op.i[1]);
+  MSL_REQUIRE(op.p[0] && op.p[4] && op.i[0] > 0 && op.i[1] > 0 && op.i[2] >= 0 && (op.i[2] <= 1 || op.i[3] > 0), "f64_drain: bad args");
+  hipLaunchKernelGGL(f64_drain_kernel, dim3((op.i[0] + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[4], op.i[0], op.i[1], op.i[2] > 0 ? op.i[2] : 1, op.i[3]);
   MSL_CHECK_LAUNCH("f64_drain");
   return MSL_OK;
 }

@@ -450,10 +450,10 @@ class TrainPlan(graph.Visitor):
             else:  # plain conv + bias: dz = dy (the loss writes it, zeros in the padding channels)
                 gy = self.G(y)
                 gyw = View(gy.t, gy.N, gy.H, gy.W, cpad, gy.cs, gy.co, gy.f32)
-                acc = self._acc_bwd(cpad)
+                acc = self._acc_bwd(cpad, ACC_SLOTS)  # COLSUM uses C doubles per slot: half of each slice stays unused
                 ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gyw.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
-                                          i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0}))
-                ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
+                                          i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0, 21: ACC_SLOTS}))
+                ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cpad}))
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
             if dz_f32 and self.dtype != MSL_F32:  # the MFMA operands must be the compute dtype (as autocast feeds these convs upstream)
                 dzc = self._new(Ho, Wo, dz.C)
@@ -503,10 +503,10 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             gy = self.G(y)
-            acc = self._acc_bwd(cout)
+            acc = self._acc_bwd(cout, ACC_SLOTS)
             ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gy.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
-                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co}))
-            ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1}))
+                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co, 21: ACC_SLOTS}))
+            ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cout}))
             # dW[ci][(dy,dx,co)] = sum_p x[p][ci] * dy[(2y+dy,2x+dx)][co]: CONV_WGRAD with the operands swapped
             ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co, 21: WG_SCRATCH_FLOATS}))
