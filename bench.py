@@ -222,25 +222,27 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             return 2.0 * I[0] * I[4] * I[5] * I[6] * I[7] * I[7] * I[3]
         return 2.0 * I[0] * I[4] * I[5] * I[6] * I[16]
 
-    best, wg_ms, wg_fl, cv_ms, cv_fl = None, 0.0, 0.0, 0.0, 0.0
+    wg_ms, wg_fl, cv_ms, cv_fl = 0.0, 0.0, 0.0, 0.0
+    cands = []  # every MFMA launch as (ms, flops, kernel label, dtype, tag, op); the longest is the "dominant kernel", the top 3 are replayed for PMC
     for tag, what, kind, ms, it in rows:
+        I = it.i if what == "op" else None
         if kind == hiplib.OP_CONV_WGRAD:
             fl = conv_flops(it, True)
             wg_ms, wg_fl = wg_ms + ms, wg_fl + fl
-            if best is None or ms > best[0]:
-                I = it.i  # same dispatch rule as msl_launch_conv_wgrad (train_kernels.hip): bf16 tensors + 3x3/p1 (s1|s2) or 1x1/p0/s1 + 8-aligned views
-                geom = (I[7] == 3 and I[9] == 1 and I[8] in (1, 2)) or (I[7] == 1 and I[9] == 0 and I[8] == 1)
-                tr_kernel = it.dtype == hiplib.MSL_BF16 and not I[19] and geom and all(I[j] % 8 == 0 for j in (3, 6, 10, 11, 12, 13)) and I[20] == 0
-                best = (ms, fl, "conv_wgrad_tr_kernel (bf16 MFMA 16x16x32, LDS transposed reads, pixel contraction)", "bf16", tag, it) if tr_kernel else \
-                       (ms, fl, "conv_wgrad_kernel (fp32 MFMA 16x16x4, pixel contraction)", "fp32", tag, it)
+            # same dispatch rule as msl_launch_conv_wgrad (train_kernels.hip): bf16 tensors, 3x3/p1 (s1|s2) | 2x2/p0/s2 | 1x1/p0/s1, 8-aligned views
+            geom = (I[7] == 3 and I[9] == 1 and I[8] in (1, 2)) or (I[7] == 1 and I[9] == 0 and I[8] == 1) or (I[7] == 2 and I[9] == 0 and I[8] == 2)
+            trk = it.dtype == hiplib.MSL_BF16 and not I[19] and geom and all(I[j] % 8 == 0 for j in (3, 10, 11, 12, 13))
+            cands.append((ms, fl, "conv_wgrad_tr_kernel (bf16 MFMA 16x16x32, LDS transposed reads, pixel contraction)" if trk else "conv_wgrad_kernel (fp32 MFMA 16x16x4, pixel contraction)",
+                          "bf16" if trk else "fp32", tag, it))
         elif kind == hiplib.OP_CONV:
             fl = conv_flops(it)
             cv_ms, cv_fl = cv_ms + ms, cv_fl + fl
-            if best is None or ms > best[0]:
-                kn = "conv3x3_lds_kernel" if it.i[25] else "conv_igemm_kernel"
-                mode = "dgrad, transposed-conv gather" if it.i[22] else ("dgrad as a stride-1 conv with flipped weights" if tag == "bwd" else "forward")
-                best = (ms, fl, f"{kn}<{args.dtype}> ({mode})", args.dtype, tag, it)
-    ms, fl, kname, kdt, tag, op = best
+            one = I[7] == 1 and I[8] == 1 and I[20] == 0 and args.dtype == "bf16" and I[3] % 8 == 0 and I[6] % 8 == 0 and I[6] <= 256
+            kn = "conv3x3_lds_kernel" if I[25] else ("conv1x1_kernel" if one else "conv_igemm_kernel")
+            mode = "input gradient, transposed-conv gather" if I[22] else ("input gradient" if tag == "bwd" else "forward")
+            cands.append((ms, fl, f"{kn}<{args.dtype}> ({mode})", args.dtype, tag, it))
+    cands.sort(key=lambda c: -c[0])
+    ms, fl, kname, kdt, tag, op = cands[0]
     peak = PEAK[kdt]
     ach = fl / (ms * 1e-3) / 1e12
     I = op.i
@@ -253,18 +255,32 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             "program_ms": {"total_fwd_bwd_pack": round(total, 3),
                            **{f"{t}:{names.get(k, 'torch-attention')}": round(v, 3) for (t, k), v in sorted(by_kind.items(), key=lambda x: -x[1])[:14]}},
             "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP_PER_SLICE_640 * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4)}
+    def shape_of(o):
+        J = o.i
+        return {"N": J[0], "H": J[1], "W": J[2], "Cin": J[3], "Ho": J[4], "Wo": J[5], "Cout": J[6], "k": J[7], "stride": J[8]}
+
     pmc = ROOT / "profiles" / "pmc_latest.json"  # written by scripts/pmc_traffic.py from rocprofv3 --pmc passes over --replay-dominant
     if pmc.exists():
-        rec = json.loads(pmc.read_text())
-        if rec.get("kernel") == kname and rec.get("launch_shape") == roof["launch_shape"]:
-            roof["traffic"] = rec["traffic_bytes_per_launch"]
-            roof["traffic_note"] = rec.get("note", "")
-    if args.replay_dominant > 0:  # for the PMC passes: the dominant op alone, back to back, as the LAST dispatches of its kernel
+        for rec in json.loads(pmc.read_text()).get("records", []):
+            if rec.get("kernel") == kname and rec.get("launch_shape") == roof["launch_shape"]:
+                roof["traffic"] = rec["traffic_bytes_per_launch"]
+                roof["traffic_note"] = rec.get("note", "")
+    if args.replay_dominant > 0:  # for the PMC passes: the three longest MFMA launches, each alone and back to back, as the LAST dispatches of the process
         s_ = torch.cuda.current_stream(tr.device).cuda_stream
-        for _ in range(args.replay_dominant):
-            hiplib.launch(op, s_)
         torch.cuda.synchronize(tr.device)
-        roof["replayed"] = args.replay_dominant
+        roof["replay"] = []
+        picks, fams = list(cands[:3]), set()  # the three longest launches + the longest of every kernel family (ranks shift a little under the profiler)
+        for c in cands:
+            fam = (c[2].split("<")[0].split(" ")[0], c[4])
+            if fam not in fams:
+                fams.add(fam)
+                if c not in picks:
+                    picks.append(c)
+        for c in picks:
+            for _ in range(args.replay_dominant):
+                hiplib.launch(c[5], s_)
+            roof["replay"].append({"kernel": c[2], "launch_shape": shape_of(c[5]), "launch_ms": round(c[0], 4)})
+        torch.cuda.synchronize(tr.device)
     if args.op_table:
         with open(args.op_table, "w") as f:
             f.write(f"# train: per-op HIP-event times, batch {tr.batch}, {args.size}x{args.size}, {args.dtype}; total {total:.3f} ms\n")

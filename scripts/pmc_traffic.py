@@ -35,28 +35,38 @@ def one_pass(counter, outdir):
 
 def main():
     out = Path("/tmp/pmc_traffic")
-    res = {}
-    roof = None
+    per_counter, replay = {}, None
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         bench, rows = one_pass(counter, out / counter)
-        roof = bench["roofline"]
-        base = roof["kernel"].split("<")[0].split(" ")[0]  # e.g. conv_igemm_kernel
-        mine = [r for r in rows if r["Counter_Name"] == counter and base in r["Kernel_Name"]]
+        replay = bench["roofline"]["replay"]
+        mine = [r for r in rows if r["Counter_Name"] == counter]
         mine.sort(key=lambda r: int(r["Dispatch_Id"]))
-        last = mine[-K:]
-        if len(last) < K or len({r["Grid_Size"] for r in last}) != 1:
-            sys.exit(f"{counter}: could not isolate the {K} replayed dispatches of {base}: {[(r['Dispatch_Id'], r['Grid_Size']) for r in mine[-8:]]}")
-        res[counter] = sum(float(r["Counter_Value"]) for r in last) / K * 1024.0
-        res["kernel_name"] = last[0]["Kernel_Name"]
-        res["grid"] = last[0]["Grid_Size"]
-    traffic = 2.0 * res["FETCH_SIZE"] + res["WRITE_SIZE"]
-    rec = {"kernel": roof["kernel"], "launch_shape": roof["launch_shape"], "traffic_bytes_per_launch": round(traffic),
-           "fetch_size_bytes_raw": round(res["FETCH_SIZE"]), "write_size_bytes": round(res["WRITE_SIZE"]), "dispatch_kernel_name": res["kernel_name"], "grid_size": res["grid"],
-           "note": "rocprofv3 --pmc, two passes, mean of 5 replayed launches; FETCH_SIZE doubled (gfx950), both counters KiB → bytes"}
-    (ROOT / "profiles" / "pmc_latest.json").write_text(json.dumps(rec, indent=1) + "\n")
+        # the replayed ops are the last dispatches of the process; an op may launch helper kernels (e.g. the partial-sum reduction after a
+        # weight-gradient kernel), so walk backwards and pick K dispatches of each record's own kernel
+        pos, found = len(mine), []
+        for rp in reversed(replay):
+            base = rp["kernel"].split("<")[0].split(" ")[0]
+            g = []
+            while pos > 0 and len(g) < K:
+                pos -= 1
+                if base in mine[pos]["Kernel_Name"]:
+                    g.append(mine[pos])
+            if len(g) < K or len({(r["Kernel_Name"], r["Grid_Size"]) for r in g}) != 1:
+                sys.exit(f"{counter}: could not isolate {K} launches of {base}: {[(r['Dispatch_Id'], r['Kernel_Name'][:40], r['Grid_Size']) for r in g]}")
+            found.append((sum(float(r["Counter_Value"]) for r in g) / K * 1024.0, g[0]["Kernel_Name"], g[0]["Grid_Size"]))
+        per_counter[counter] = found[::-1]
+    records = []
+    for i, rp in enumerate(replay):
+        fetch, name, grid = per_counter["FETCH_SIZE"][i]
+        write = per_counter["WRITE_SIZE"][i][0]
+        records.append({"kernel": rp["kernel"], "launch_shape": rp["launch_shape"], "traffic_bytes_per_launch": round(2.0 * fetch + write),
+                        "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write), "dispatch_kernel_name": name, "grid_size": grid,
+                        "note": "rocprofv3 --pmc, two passes, mean of 5 replayed launches; FETCH_SIZE doubled (gfx950), both counters KiB -> bytes"})
+    doc = {"records": records}
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
-    (ROOT / "gpurun_out" / "pmc_latest.json").write_text(json.dumps(rec, indent=1) + "\n")
-    print(json.dumps(rec))
+    for dst in (ROOT / "profiles" / "pmc_latest.json", ROOT / "gpurun_out" / "pmc_latest.json"):
+        dst.write_text(json.dumps(doc, indent=1) + "\n")
+    print(json.dumps(doc))
 
 
 if __name__ == "__main__":
