@@ -82,6 +82,116 @@ __global__ __launch_bounds__(128) void attention_kernel(const void* __restrict__
   }
 }
 
+// ---- bf16: the same attention on the matrix cores ---------------------------------------------------------------------
+// One workgroup per (slice, head): K [HW][32] and V [HW][64] are copied once to LDS (LDS-DMA, padded rows); each wave then
+// takes 16-query tiles.  Everything is computed TRANSPOSED so that no register-layout conversion is needed:
+//   S^T[key][query] = K · Q^T    (A = K rows from LDS, B = Q^T straight from global; one MFMA per 16 keys since key_dim = 32)
+//   softmax over keys: a lane holds, for ITS query (column), 4 keys of every S^T tile → in-lane max / sum + two cross-group shuffles
+//   O^T[d][query]   = V^T · P^T  (B = exp(S^T - max) of two S^T tiles, i.e. keys {4g..4g+3} ∪ {16+4g..16+4g+3} of a 32-key step;
+//                                 A = V^T for exactly those keys through ds_read_b64_tr_b16 — the contraction order is free)
+// fp32 softmax, P rounded to bf16 for the second product, 1/sum applied at the end.  77 MFMAs per 16 queries at 400 tokens.
+typedef __attribute__((ext_vector_type(4))) short at_s16x4;
+typedef __attribute__((ext_vector_type(8))) short at_s16x8;
+__device__ __attribute__((aligned(16))) unsigned at_zero_page[4];
+#define AT_MAX_KT 32  // up to 512 tokens (S^T kept in registers: 4 VGPRs per 16 keys)
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ y, int HW, int x_cs, int x_co,
+                                                             int y_cs, int y_co, float scale) {
+  constexpr int KD = 32, HD = 64, PK = KD * 2 + 16, PV = HD * 2 + 16;  // LDS row pitches (bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int head = blockIdx.x, n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+  const int KT = (HW + 15) >> 4, HWp = KT * 16 + 16;  // rows staged (padded with zeros: tail keys and the +16 of the last 32-key step)
+  unsigned char* s_k = smem;
+  unsigned char* s_v = smem + ((HWp * (PK / 16) + 63) & ~63) * 16;
+  const long rowbase = (long)n * HW;
+  const int hoff = x_co + head * (2 * KD + HD);
+  // ---- stage K and V (16-byte chunks; chunk index → (token, chunk in row); pad chunk and rows >= HW from the zero page)
+  {
+    const int ck = HWp * (PK / 16), cv = HWp * (PV / 16);
+    for (int c0 = (threadIdx.x & ~63); c0 < ck; c0 += 256) {
+      const int cidx = c0 + lane, t = cidx / (PK / 16), ch = cidx - t * (PK / 16);
+      const bool ok = cidx < ck && t < HW && ch < KD / 8;
+      const void* src = ok ? (const void*)(qkv + (rowbase + t) * x_cs + hoff + KD + ch * 8) : (const void*)at_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_k + (long)c0 * 16), 16, 0, 0);
+    }
+    for (int c0 = (threadIdx.x & ~63); c0 < cv; c0 += 256) {
+      const int cidx = c0 + lane, t = cidx / (PV / 16), ch = cidx - t * (PV / 16);
+      const bool ok = cidx < cv && t < HW && ch < HD / 8;
+      const void* src = ok ? (const void*)(qkv + (rowbase + t) * x_cs + hoff + 2 * KD + ch * 8) : (const void*)at_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_v + (long)c0 * 16), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qt = wave; qt < KT; qt += 4) {  // wave-uniform
+    const int qi = qt * 16 + li;  // this lane's query (column)
+    bf16x8 qf = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+    if (qi < HW) qf = *(const bf16x8*)(qkv + (rowbase + qi) * x_cs + hoff + 8 * g);
+    f32x4 st[AT_MAX_KT];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < AT_MAX_KT; ++kt) {
+      if (kt < KT) {
+        const bf16x8 kf = *(const bf16x8*)(s_k + (kt * 16 + li) * PK + 16 * g);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          z[r] = (kt * 16 + 4 * g + r < HW) ? z[r] * scale : -__builtin_inff();
+          m = fmaxf(m, z[r]);
+        }
+        st[kt] = z;
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < AT_MAX_KT; ++kt) {
+      if (kt < KT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); l += st[kt][r]; }
+      }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < AT_MAX_KT / 2; ++ks) {
+      if (2 * ks < KT) {
+        at_s16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (short)f32_to_bf16_bits(st[2 * ks][r]);
+          pf[4 + r] = (2 * ks + 1 < KT) ? (short)f32_to_bf16_bits(st[2 * ks + 1][r]) : (short)0;
+        }
+        const unsigned char* vb = s_v + (ks * 32 + 4 * g + q) * PV + (4 * pp) * 2;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(vb + dt * 32));
+          const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(vb + 16 * PV + dt * 32));
+          const at_s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (qi < HW) {
+      const float inv = 1.0f / l;
+      unsigned short* dst = y + (rowbase + qi) * y_cs + y_co + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const float v[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+        st4<false>(dst, dt * 16 + 4 * g, v);
+      }
+    }
+  }
+}
+
 int msl_launch_attention(const msl_op& op, hipStream_t s) {
   int N = op.i[0], H = op.i[1], W = op.i[2], heads = op.i[3], kd = op.i[4], hd = op.i[5];
   int x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13];
@@ -91,6 +201,15 @@ int msl_launch_attention(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && x_co + heads * (2 * kd + hd) <= x_cs &&
                   y_co + heads * hd <= y_cs, "attention: bad views");
   const int HW = H * W;
+  if (op.dtype == MSL_BF16 && HW <= 16 * AT_MAX_KT - 16 && ((x_cs | x_co | y_cs | y_co) & 7) == 0) {  // matrix-core kernel: K/V of one (slice, head) in LDS
+    const int HWp = ((HW + 15) / 16) * 16 + 16;
+    const size_t lds = (size_t)(((HWp * 5 + 63) & ~63) + ((HWp * 9 + 63) & ~63)) * 16;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)heads, (unsigned)N), dim3(256), lds, s, (const unsigned short*)op.p[0], (unsigned short*)op.p[4], HW, x_cs, x_co, y_cs, y_co, op.f[0]);
+    MSL_CHECK_LAUNCH("attention");
+    return MSL_OK;
+  }
   dim3 grid((HW + 127) / 128, heads, N);
   if (op.dtype == MSL_F32) hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(128), 0, s, op.p[0], op.p[4], HW, x_cs, x_co, y_cs, y_co, op.f[0]);
   else hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(128), 0, s, op.p[0], op.p[4], HW, x_cs, x_co, y_cs, y_co, op.f[0]);
