@@ -39,21 +39,33 @@ __global__ __launch_bounds__(256) void head_decode_kernel(const float* __restric
   }
   const float cx = (float)ax + 0.5f, cy = (float)ay + 0.5f;
   const float x1 = cx - d[0], y1 = cy - d[1], x2 = cx + d[2], y2 = cy + d[3];
-  float* o = pred + ((long)n * A + aoff + a) * MSL_PRED_STRIDE;
-  o[0] = ((x1 + x2) / 2.f) * stride;
-  o[1] = ((y1 + y2) / 2.f) * stride;
-  o[2] = (x2 - x1) * stride;
-  o[3] = (y2 - y1) * stride;
+  float* o = pred + ((long)n * A + aoff + a) * MSL_PRED_STRIDE;  // 160-byte rows: written as 16-byte stores
   float best = -1.f;
   int bj = 0;
   for (int j = 0; j < nc; ++j) {
     float sc = 1.0f / (1.0f + expf(-cls[t * nc + j]));
     if (sc > best) { best = sc; bj = j; }
   }
-  o[4] = best;
-  o[5] = (float)bj;
-  for (int j = 0; j < nm; ++j) o[6 + j] = coef[t * nm + j];
-  for (int j = 6 + nm; j < MSL_PRED_STRIDE; ++j) o[j] = 0.f;
+  float row[MSL_PRED_STRIDE];
+  row[0] = ((x1 + x2) / 2.f) * stride;
+  row[1] = ((y1 + y2) / 2.f) * stride;
+  row[2] = (x2 - x1) * stride;
+  row[3] = (y2 - y1) * stride;
+  row[4] = best;
+  row[5] = (float)bj;
+  if (nm == 32) {
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+      const float4 q = *(const float4*)(coef + t * 32 + j);
+      row[6 + j] = q.x; row[7 + j] = q.y; row[8 + j] = q.z; row[9 + j] = q.w;
+    }
+    row[38] = 0.f; row[39] = 0.f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < MSL_PRED_STRIDE - 6; ++j) row[6 + j] = j < nm ? coef[t * nm + j] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < MSL_PRED_STRIDE; j += 4) *(float4*)(o + j) = make_float4(row[j], row[j + 1], row[j + 2], row[j + 3]);
 }
 
 int msl_launch_head_decode(const msl_op& op, hipStream_t s) {
