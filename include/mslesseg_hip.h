@@ -148,6 +148,8 @@ enum {
   MSL_OP_GATHER_CAST = 30,        /* dst[i] = idx[i]>=0 ? src[idx[i]] : 0, cast to op dtype: packs weight images from the flat master buffer */
   MSL_OP_ADAMW = 31,              /* fused AdamW step over a flat fp32 range */
   MSL_OP_EMA = 32,                /* e = d*e + (1-d)*p over a flat fp32 range */
+  MSL_OP_ATTENTION_BWD = 34,      /* PSA attention core backward (bf16): dq, dk written, dv added into the qkv gradient view; p 0 qkv, 1 y, 2 dy,
+                                     3 statistics scratch f32 [N][heads][ceil16(HW)+16][4], 4 gqkv ; i as ATTENTION + 14,15 gradient view cs/co */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

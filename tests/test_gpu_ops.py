@@ -502,3 +502,35 @@ def test_stride2_input_gradient_as_parity_classes(case, dtype):
             hiplib.launch(op, _stream())
     torch.cuda.synchronize()
     _close(gx.cpu(), ref, dtype, f"s2 dgrad {case}")
+
+
+@pytest.mark.parametrize("hw", [(20, 20), (20, 17), (5, 3)])
+def test_attention_backward_bf16(hw):
+    """MSL_OP_ATTENTION_BWD (matrix-core kernels, probabilities recomputed) against torch autograd of the fp32 attention on the same
+    bf16 inputs: dq, dk overwrite, dv is added to what the gradient view already holds."""
+    g = torch.Generator().manual_seed(23)
+    N, (H, W), heads, kd, hd = 3, hw, 2, 32, 64
+    HW = H * W
+    qkv = _rand_act((N, H, W, heads * 128), MSL_BF16, g, scale=1.5)
+    dy = _rand_act((N, H, W, heads * hd), MSL_BF16, g)
+    pre = _rand_act((N, H, W, heads * 128), MSL_BF16, g)  # what the gradient view holds before the op
+    t = qkv.float().view(N, HW, heads, 128).permute(0, 2, 1, 3).clone().requires_grad_()
+    q, k, v = t[..., :kd], t[..., kd : 2 * kd], t[..., 2 * kd :]
+    o = torch.softmax((q @ k.transpose(-1, -2)) * kd**-0.5, -1) @ v  # [N,heads,HW,hd]
+    (gt,) = torch.autograd.grad(o, t, dy.float().view(N, HW, heads, hd).permute(0, 2, 1, 3))
+    ref = gt.permute(0, 2, 1, 3).reshape(N, H, W, heads * 128).clone()
+    refv = ref.view(N, H, W, heads, 128)
+    refv[..., 2 * kd :] += pre.float().view(N, H, W, heads, 128)[..., 2 * kd :]
+    qd, dyd, gqd = qkv.to(DEV), dy.to(DEV), pre.clone().to(DEV)
+    yd = torch.zeros((N, H, W, heads * hd), dtype=torch.bfloat16, device=DEV)
+    dims = {0: N, 1: H, 2: W, 3: heads, 4: kd, 5: hd, 10: heads * 128, 11: 0, 12: heads * hd, 13: 0}
+    hiplib.launch(hiplib.make_op(hiplib.OP_ATTENTION, MSL_BF16, p=(qd.data_ptr(), 0, 0, 0, yd.data_ptr()), i=dims, f=(kd**-0.5,)), _stream())
+    stats = torch.zeros(N * heads * ((HW + 15) // 16 * 16 + 16) * 4, dtype=torch.float32, device=DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_ATTENTION_BWD, MSL_BF16, p=(qd.data_ptr(), yd.data_ptr(), dyd.data_ptr(), stats.data_ptr(), gqd.data_ptr()),
+                                 i={**dims, 14: heads * 128, 15: 0}, f=(kd**-0.5,)), _stream())
+    torch.cuda.synchronize()
+    got = gqd.float().cpu().view(N, H, W, heads, 128)
+    for name, sl in (("dq", slice(0, kd)), ("dk", slice(kd, 2 * kd)), ("dv", slice(2 * kd, 128))):
+        a, b = got[..., sl], refv[..., sl]
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+        assert err < 2e-2, f"attention bwd {name} {hw}: rel err {err:.3e}"  # P, dS and the outputs are rounded to bf16

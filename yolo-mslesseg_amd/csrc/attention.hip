@@ -192,6 +192,286 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
   }
 }
 
+// ---- bf16 backward (training): dQ, dK, dV from dO, recomputing the probabilities -------------------------------------------
+//   P = softmax(scale Q K^T),  dV = P^T dO,  dP = dO V^T,  D_i = sum_d dO_id O_id,  dS = P o (dP - D),  dQ = scale dS K,  dK = scale dS^T Q
+// Two kernels with the forward's structure (one workgroup per (slice, head), K/V resp. Q/dO resident in LDS, transposed products so
+// that every MFMA result already has the operand layout of the next MFMA):
+//   bwd_q  per 16-query tile: S^T, row max / sum (stored for the second kernel), D, dP^T = V dO^T, dS^T, dQ^T = K^T dS^T
+//   bwd_kv per 16-key tile  : S = Q K^T (queries as rows), P from the stored row statistics, dP = dO V^T, dS; the contractions over
+//          QUERIES, dV^T = dO^T P and dK^T = Q^T dS, take P / dS of two query tiles as the B operand and dO^T / Q^T through
+//          ds_read_b64_tr_b16.  dV is ADDED to the gradient view (the positional-encoding branch wrote there first); dQ, dK overwrite.
+__global__ __launch_bounds__(256) void attention_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ yo,
+                                                              const unsigned short* __restrict__ dyo, float* __restrict__ stats, unsigned short* __restrict__ gqkv,
+                                                              int HW, int x_cs, int x_co, int y_cs, int y_co, int g_cs, int g_co, float scale) {
+  constexpr int KD = 32, HD = 64, PK = KD * 2 + 16, PV = HD * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int head = blockIdx.x, n = blockIdx.y, heads = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+  const int KT = (HW + 15) >> 4, HWp = KT * 16 + 16;
+  unsigned char* s_k = smem;
+  unsigned char* s_v = smem + ((HWp * (PK / 16) + 63) & ~63) * 16;
+  const long rowbase = (long)n * HW;
+  const int hoff = x_co + head * (2 * KD + HD), goff = g_co + head * (2 * KD + HD), yoff = y_co + head * HD;
+  {
+    const int ck = HWp * (PK / 16), cv = HWp * (PV / 16);
+    for (int c0 = (threadIdx.x & ~63); c0 < ck; c0 += 256) {
+      const int cidx = c0 + lane, t = cidx / (PK / 16), ch = cidx - t * (PK / 16);
+      const bool ok = cidx < ck && t < HW && ch < KD / 8;
+      const void* src = ok ? (const void*)(qkv + (rowbase + t) * x_cs + hoff + KD + ch * 8) : (const void*)at_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_k + (long)c0 * 16), 16, 0, 0);
+    }
+    for (int c0 = (threadIdx.x & ~63); c0 < cv; c0 += 256) {
+      const int cidx = c0 + lane, t = cidx / (PV / 16), ch = cidx - t * (PV / 16);
+      const bool ok = cidx < cv && t < HW && ch < HD / 8;
+      const void* src = ok ? (const void*)(qkv + (rowbase + t) * x_cs + hoff + 2 * KD + ch * 8) : (const void*)at_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_v + (long)c0 * 16), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* st_out = stats + ((long)n * heads + head) * HWp * 4;
+
+  for (int qt = wave; qt < KT; qt += 4) {
+    const int qi = qt * 16 + li;
+    const bool qv = qi < HW;
+    bf16x8 qf = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+    bf16x8 dof[2] = {qf, qf};
+    float dpart = 0.f;
+    if (qv) {
+      qf = *(const bf16x8*)(qkv + (rowbase + qi) * x_cs + hoff + 8 * g);
+      const unsigned short* dr = dyo + (rowbase + qi) * y_cs + yoff;
+      const unsigned short* orow = yo + (rowbase + qi) * y_cs + yoff;
+      dof[0] = *(const bf16x8*)(dr + 8 * g);
+      dof[1] = *(const bf16x8*)(dr + 32 + 8 * g);
+      float a8[8], b8[8];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {  // D = sum_d dO*O: this lane covers d = 16g .. 16g+15
+        ldv<false, 8>(dr, 16 * g + 8 * h2, a8);
+        ldv<false, 8>(orow, 16 * g + 8 * h2, b8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dpart = fmaf(a8[r], b8[r], dpart);
+      }
+    }
+    dpart += __shfl_xor(dpart, 16);
+    dpart += __shfl_xor(dpart, 32);
+    f32x4 st[AT_MAX_KT];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < AT_MAX_KT; ++kt) {
+      if (kt < KT) {
+        const bf16x8 kf = *(const bf16x8*)(s_k + (kt * 16 + li) * PK + 16 * g);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          z[r] = (kt * 16 + 4 * g + r < HW) ? z[r] * scale : -__builtin_inff();
+          m = fmaxf(m, z[r]);
+        }
+        st[kt] = z;
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < AT_MAX_KT; ++kt) {
+      if (kt < KT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); l += st[kt][r]; }
+      }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (g == 0) *(float4*)(st_out + (long)qi * 4) = make_float4(m, inv, dpart, 0.f);  // rows up to KT*16 exist in the buffer
+    // dS^T = P^T o (dP^T - D), dP^T = V dO^T (contraction over the 64 head dims)
+#pragma unroll
+    for (int kt = 0; kt < AT_MAX_KT; ++kt) {
+      if (kt < KT) {
+        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 vf = *(const bf16x8*)(s_v + (kt * 16 + li) * PV + (ks * 32 + 8 * g) * 2);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * inv * (dp[r] - dpart);
+      }
+    }
+    // dQ^T[d][query] = scale * sum_keys K^T[d][key] dS^T[key][query]
+    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < AT_MAX_KT / 2; ++ks) {
+      if (2 * ks < KT) {
+        at_s16x8 sf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sf[r] = (short)f32_to_bf16_bits(st[2 * ks][r]);
+          sf[4 + r] = (2 * ks + 1 < KT) ? (short)f32_to_bf16_bits(st[2 * ks + 1][r]) : (short)0;
+        }
+        const unsigned char* kb = s_k + (ks * 32 + 4 * g + q) * PK + (4 * pp) * 2;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(kb + dt * 32));
+          const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(kb + 16 * PK + dt * 32));
+          const at_s16x8 kf2 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf2), __builtin_bit_cast(bf16x8, sf), dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (qv) {
+      unsigned short* dst = gqkv + (rowbase + qi) * g_cs + goff;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
+        st4<false>(dst, dt * 16 + 4 * g, v);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dyo,
+                                                               const float* __restrict__ stats, unsigned short* __restrict__ gqkv, int HW, int x_cs, int x_co,
+                                                               int y_cs, int y_co, int g_cs, int g_co, float scale) {
+  constexpr int KD = 32, HD = 64, PK = KD * 2 + 16, PV = HD * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int head = blockIdx.x, n = blockIdx.y, heads = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+  const int KT = (HW + 15) >> 4, HWp = KT * 16 + 16;
+  unsigned char* s_q = smem;                                              // Q  [HWp][32]
+  unsigned char* s_d = smem + ((HWp * (PK / 16) + 63) & ~63) * 16;        // dO [HWp][64]
+  float* s_st = (float*)(s_d + ((HWp * (PV / 16) + 63) & ~63) * 16);      // (m, 1/l, D, -) per query
+  const long rowbase = (long)n * HW;
+  const int hoff = x_co + head * (2 * KD + HD), goff = g_co + head * (2 * KD + HD), yoff = y_co + head * HD;
+  {
+    const int ck = HWp * (PK / 16), cv = HWp * (PV / 16);
+    for (int c0 = (threadIdx.x & ~63); c0 < ck; c0 += 256) {
+      const int cidx = c0 + lane, t = cidx / (PK / 16), ch = cidx - t * (PK / 16);
+      const bool ok = cidx < ck && t < HW && ch < KD / 8;
+      const void* src = ok ? (const void*)(qkv + (rowbase + t) * x_cs + hoff + ch * 8) : (const void*)at_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_q + (long)c0 * 16), 16, 0, 0);
+    }
+    for (int c0 = (threadIdx.x & ~63); c0 < cv; c0 += 256) {
+      const int cidx = c0 + lane, t = cidx / (PV / 16), ch = cidx - t * (PV / 16);
+      const bool ok = cidx < cv && t < HW && ch < HD / 8;
+      const void* src = ok ? (const void*)(dyo + (rowbase + t) * y_cs + yoff + ch * 8) : (const void*)at_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_d + (long)c0 * 16), 16, 0, 0);
+    }
+    const float* st_in = stats + ((long)n * heads + head) * HWp * 4;
+    for (int i = threadIdx.x; i < KT * 16; i += 256) *(float4*)(s_st + i * 4) = *(const float4*)(st_in + (long)i * 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = wave; kt < KT; kt += 4) {
+    const int kj = kt * 16 + li;  // this lane's key (column)
+    const bool kv = kj < HW;
+    bf16x8 kf = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+    bf16x8 vf[2] = {kf, kf};
+    if (kv) {
+      const unsigned short* row = qkv + (rowbase + kj) * x_cs + hoff;
+      kf = *(const bf16x8*)(row + KD + 8 * g);
+      vf[0] = *(const bf16x8*)(row + 2 * KD + 8 * g);
+      vf[1] = *(const bf16x8*)(row + 2 * KD + 32 + 8 * g);
+    }
+    f32x4 dv[4], dk[2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dk[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[1] = dk[0];
+    for (int qp = 0; 2 * qp < KT; ++qp) {  // pairs of query tiles = one 32-query contraction step
+      at_s16x8 pf, sf;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int qt = 2 * qp + h2;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (qt < KT) {
+          const bf16x8 qa = *(const bf16x8*)(s_q + (qt * 16 + li) * PK + 16 * g);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, sc, 0, 0, 0);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 da = *(const bf16x8*)(s_d + (qt * 16 + li) * PV + (ks * 32 + 8 * g) * 2);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qt * 16 + 4 * g + r;  // row of the S tile held by this lane
+          float pv_ = 0.f, ds_ = 0.f;
+          if (qt < KT && qi < HW && kv) {
+            const float4 s4 = *(const float4*)(s_st + qi * 4);
+            pv_ = __expf(sc[r] * scale - s4.x) * s4.y;
+            ds_ = pv_ * (dp[r] - s4.z);
+          }
+          pf[4 * h2 + r] = (short)f32_to_bf16_bits(pv_);
+          sf[4 * h2 + r] = (short)f32_to_bf16_bits(ds_);
+        }
+      }
+      // contractions over the 32 queries {32qp + 4g + r} U {32qp + 16 + 4g + r}: A operands transposed out of LDS
+      const unsigned char* db = s_d + (qp * 32 + 4 * g + q) * PV + (4 * pp) * 2;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(db + dt * 32));
+        const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(db + 16 * PV + dt * 32));
+        const at_s16x8 af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, pf), dv[dt], 0, 0, 0);
+      }
+      const unsigned char* qb = s_q + (qp * 32 + 4 * g + q) * PK + (4 * pp) * 2;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(qb + dt * 32));
+        const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(qb + 16 * PK + dt * 32));
+        const at_s16x8 af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, sf), dk[dt], 0, 0, 0);
+      }
+    }
+    if (kv) {
+      unsigned short* dst = gqkv + (rowbase + kj) * g_cs + goff;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const float v[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
+        st4<false>(dst, KD + dt * 16 + 4 * g, v);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        float old[4];
+        ld4<false>(dst, 2 * KD + dt * 16 + 4 * g, old);
+        const float v[4] = {old[0] + dv[dt][0], old[1] + dv[dt][1], old[2] + dv[dt][2], old[3] + dv[dt][3]};
+        st4<false>(dst, 2 * KD + dt * 16 + 4 * g, v);
+      }
+    }
+  }
+}
+
+// ATTENTION_BWD (bf16 only): p 0 qkv view, 1 forward output view y, 2 gradient of y (same view geometry), 3 statistics scratch
+// f32 [N][heads][ceil16(HW)+16][4], 4 gradient view of qkv (dq, dk written; dv ADDED) ; i 0 N,1 H,2 W,3 heads,4 kd,5 hd,
+// 10 x_cs,11 x_co,12 y_cs,13 y_co,14 g_cs,15 g_co ; f 0 scale
+int msl_launch_attention_bwd(const msl_op& op, hipStream_t s) {
+  const int N = op.i[0], H = op.i[1], W = op.i[2], heads = op.i[3], kd = op.i[4], hd = op.i[5];
+  const int x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13], g_cs = op.i[14], g_co = op.i[15];
+  MSL_REQUIRE(op.dtype == MSL_BF16, "attention_bwd: bf16 tensors only (the fp32 engine differentiates the attention core with tensor ops)");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && N > 0 && H > 0 && W > 0 && heads > 0 && kd == 32 && hd == 64, "attention_bwd: bad args");
+  const int HW = H * W;
+  MSL_REQUIRE(HW <= 16 * AT_MAX_KT - 16 && ((x_cs | x_co | y_cs | y_co | g_cs | g_co) & 7) == 0 && x_co + heads * 128 <= x_cs && g_co + heads * 128 <= g_cs &&
+                  y_co + heads * 64 <= y_cs, "attention_bwd: at most %d tokens; views must be 8-aligned", 16 * AT_MAX_KT - 16);
+  const int HWp = ((HW + 15) / 16) * 16 + 16;
+  const size_t lds = (size_t)(((HWp * 5 + 63) & ~63) + ((HWp * 9 + 63) & ~63)) * 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attention_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attention_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const dim3 grid((unsigned)heads, (unsigned)N);
+  hipLaunchKernelGGL(attention_bwd_q_kernel, grid, dim3(256), lds, s, (const unsigned short*)op.p[0], (const unsigned short*)op.p[1], (const unsigned short*)op.p[2],
+                     (float*)op.p[3], (unsigned short*)op.p[4], HW, x_cs, x_co, y_cs, y_co, g_cs, g_co, op.f[0]);
+  hipLaunchKernelGGL(attention_bwd_kv_kernel, grid, dim3(256), lds + (size_t)HWp * 16, s, (const unsigned short*)op.p[0], (const unsigned short*)op.p[2],
+                     (const float*)op.p[3], (unsigned short*)op.p[4], HW, x_cs, x_co, y_cs, y_co, g_cs, g_co, op.f[0]);
+  MSL_CHECK_LAUNCH("attention_bwd");
+  return MSL_OK;
+}
+
 int msl_launch_attention(const msl_op& op, hipStream_t s) {
   int N = op.i[0], H = op.i[1], W = op.i[2], heads = op.i[3], kd = op.i[4], hd = op.i[5];
   int x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13];

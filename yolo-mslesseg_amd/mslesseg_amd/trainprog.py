@@ -605,10 +605,25 @@ class TrainPlan(graph.Visitor):
         self._bw_builders.append(bw)
 
     def attention(self, qkv, heads, kd, hd):
-        """PSA attention core through torch (batched GEMMs + softmax), forward and backward."""
+        """PSA attention core.  bf16: the matrix-core kernels of attention.hip, forward (MSL_OP_ATTENTION) and backward
+        (MSL_OP_ATTENTION_BWD, probabilities recomputed).  fp32 (parity engine): torch batched GEMMs + softmax and the hand-derived backward."""
         y = self._new(qkv.H, qkv.W, heads * hd)
         HW, N = qkv.H * qkv.W, self.N
         scale = kd**-0.5
+        if self.dtype == MSL_BF16 and HW <= 496 and not any(v % 8 for v in (qkv.cs, qkv.co, y.cs, y.co)):
+            dims = {0: N, 1: qkv.H, 2: qkv.W, 3: heads, 4: kd, 5: hd, 10: qkv.cs, 11: qkv.co, 12: y.cs, 13: y.co}
+            self._f(hiplib.make_op(hiplib.OP_ATTENTION, self.dtype, p=(qkv.t.data_ptr(), 0, 0, 0, y.t.data_ptr()), i=dims, f=(scale,)))
+            stats = torch.zeros(N * heads * ((HW + 15) // 16 * 16 + 16) * 4, dtype=torch.float32, device=self.device)
+            self._keep.append(stats)
+
+            def bw_hip():
+                gq, gy = self.G(qkv), self.G(y)
+                self._init.mark(gq)  # dq, dk are written, dv is added to what the positional-encoding branch left there
+                return [hiplib.make_op(hiplib.OP_ATTENTION_BWD, self.dtype, p=(qkv.t.data_ptr(), y.t.data_ptr(), gy.t.data_ptr(), stats.data_ptr(), gq.t.data_ptr()),
+                                       i={**dims, 14: gq.cs, 15: gq.co}, f=(scale,))]
+
+            self._bw_builders.append(bw_hip)
+            return y
         saved = {}
 
         def split():
