@@ -21,7 +21,7 @@ st = torch.cuda.current_stream().cuda_stream
 flops = 2.0 * N * Ho * Wo * Cout * Cin * 9
 for kern in a.kernels.split(","):
     if kern == "lds":
-        wt, bt, m = E.pack_conv3x3_lds(w, b, dt, dev); extra = {24: m["cot"], 25: 1, 23: 4 if a.rw4 else 0}
+        wt, bt, m = E.pack_conv3x3_lds(w, b, dt, dev); extra = {24: m["cot"], 25: 1, 23: -4 if a.rw4 else 0}
     else:
         wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), b, dt, dev); extra = {}
     i = {0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 18: 1, 21: m["Cout_pad"]}

@@ -534,3 +534,31 @@ def test_attention_backward_bf16(hw):
         a, b = got[..., sl], refv[..., sl]
         err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
         assert err < 2e-2, f"attention bwd {name} {hw}: rel err {err:.3e}"  # P, dS and the outputs are rounded to bf16
+
+
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("case", [(2, 16, 40, 64, 64, 1), (1, 21, 35, 32, 32, 2), (3, 9, 33, 32, 16, 1), (1, 20, 20, 128, 128, 1)])
+def test_conv3x3_lds_batchnorm_statistics_epilogue(case, dtype):
+    """LDS-tiled 3x3 conv with p[5]: (sum z, sum z^2) per channel of the values it stores, in slot-replicated fp64 accumulators."""
+    N, H, W, Cin, Cout, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    slots = 16
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    xbuf = _rand_act((N, H, W, Cin), dtype, g)
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cin * 9) ** 0.5).to(_tdt(dtype)).float()
+    assert E.lds3x3_eligible(Cin, Cout, 3, dtype)
+    wt, bt, m = E.pack_conv3x3_lds(w, torch.zeros(Cout), dtype, DEV)
+    xd = xbuf.to(DEV)
+    yd = torch.zeros((N, Ho, Wo, Cout), dtype=_tdt(dtype), device=DEV)
+    acc = torch.zeros(slots * 2 * Cout, dtype=torch.float64, device=DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr(), acc.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 0,
+                           21: m["Cout_pad"], 23: slots, 24: m["cot"], 25: 1})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    ref = F.conv2d(xbuf.float().permute(0, 3, 1, 2), w, stride=s, padding=1).permute(0, 2, 3, 1)
+    _close(yd.cpu(), ref, dtype, f"conv3x3 {case}")
+    z = yd.float().cpu().reshape(-1, Cout).double()
+    got = acc.cpu().view(slots, Cout, 2).sum(0)
+    assert torch.allclose(got[:, 0], z.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(got[:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)

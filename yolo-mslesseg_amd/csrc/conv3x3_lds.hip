@@ -28,6 +28,8 @@ struct Conv3Args {
   int N, H, W, Cin, Ho, Wo, Cout;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int act, out_f32, tiles_x, tiles_y;
+  double* acc;  // optional BatchNorm accumulator f64[slots][2*Cout]: per-channel (sum, sum of squares) of the stored outputs
+  int slots;
 };
 
 template <int S, int RW>
@@ -156,6 +158,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 
   // ---- epilogue: bias + SiLU (+ residual); 4 consecutive channels per lane and tile
+  float s1[COT][4], s2[COT][4];  // BatchNorm sums of this lane's pixels (train-mode raw conv: bias 0, no activation)
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
@@ -168,6 +175,14 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       float v[4];
       const float4 b4 = *(const float4*)(a.bias + co0);
       v[0] = acc[c][p][0] + b4.x; v[1] = acc[c][p][1] + b4.y; v[2] = acc[c][p][2] + b4.z; v[3] = acc[c][p][3] + b4.w;
+      if (a.acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vr = F32 ? v[r] : bf16_bits_to_f32(f32_to_bf16_bits(v[r]));  // statistics of the values actually stored
+          s1[c][r] += vr;
+          s2[c][r] = fmaf(vr, vr, s2[c][r]);
+        }
+      }
       if (a.act == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
@@ -180,6 +195,31 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       }
       const long oi = pix * a.y_cs + a.y_co + co0;
       if (a.out_f32) st4<true>(a.y, oi, v); else st4<F32>(a.y, oi, v);
+    }
+  }
+  if (a.acc) {  // block-uniform: fold over the 16 pixel lanes, over the 4 waves (LDS), then one fp64 atomic per channel and statistic
+    __syncthreads();  // every wave is done with the staged tiles
+    float* red = (float*)smem;  // [4 waves][2][COB]
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = s1[c][r], t2 = s2[c][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
+        if (lp == 0) {
+          red[(wave * 2 + 0) * COB + c * 16 + g * 4 + r] = t1;
+          red[(wave * 2 + 1) * COB + c * 16 + g * 4 + r] = t2;
+        }
+      }
+    __syncthreads();
+    double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * a.Cout;
+    for (int ch = threadIdx.x; ch < COB; ch += 256) {
+      const int co = cob * COB + ch;
+      if (co < a.Cout) {
+        atomicAdd(dst + 2 * co, (double)(red[0 * COB + ch] + red[2 * COB + ch] + red[4 * COB + ch] + red[6 * COB + ch]));
+        atomicAdd(dst + 2 * co + 1, (double)(red[1 * COB + ch] + red[3 * COB + ch] + red[5 * COB + ch] + red[7 * COB + ch]));
+      }
     }
   }
 }
@@ -207,6 +247,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const int k = op.i[7], stride = op.i[8], pad = op.i[9];
   a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
   a.act = op.i[18]; a.out_f32 = op.i[19];
+  a.acc = (double*)op.p[5]; a.slots = op.i[23] > 0 ? op.i[23] : 1;  // BatchNorm-statistics epilogue (train-mode raw convs)
+  if (a.acc) MSL_REQUIRE(a.slots <= 16 && !a.out_f32 && !a.res && a.act == 0, "conv3x3_lds: the statistics epilogue is for raw convs (no activation / residual / fp32 output)");
   const bool f32 = op.dtype == MSL_F32;
   const int chunk = f32 ? 16 : 32, v = f32 ? 4 : 8;
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv3x3_lds: null pointer");
@@ -219,7 +261,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const int cout_blocks = a.Cout / (16 * cot);
   MSL_REQUIRE(op.i[24] == cot, "conv3x3_lds: weights were packed for COT=%d but the launch needs %d", op.i[24], cot);
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
-  const int rw = stride == 1 ? (op.i[23] == 4 && cot == 4 ? 4 : 2) : 1;  // i[23]=4 opts into the 16x32 tile (measured slower: kept for experiments)
+  const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : 1;  // i[23]=-4 opts into the 16x32 tile (measured slower: kept for experiments)
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;

@@ -434,7 +434,8 @@ class TrainPlan(graph.Visitor):
         self.taps[name] = y
         if bn:
             z = self._new(Ho, Wo, cout)
-            acc = self._acc(cout) if self._conv1x1_stats_ok(x, z, cout, k, s, pad, wm) else None
+            # BatchNorm sums in the producing kernel's epilogue where it has one: the 1x1 streaming kernel and the LDS-tiled 3x3 kernel
+            acc = self._acc(cout) if (self._conv1x1_stats_ok(x, z, cout, k, s, pad, wm) or wm.get("lds", 0) == 1) else None
             self._f(self._conv_op(x, z, wt, self.zeros.data_ptr(), wm, k, s, pad, stats_acc=acc))
             stats = self._bn_forward(name, z, y, cout, act, res, acc=acc)
         else:
