@@ -222,7 +222,7 @@ static int c1_launch_pt(const C1Args& a, hipStream_t s) {
   return c1_launch<NCP, STATS, 1>(a, s);
 }
 
-// MSL_OP_CONV slots (see msl_launch_conv) + p 5 = BatchNorm accumulator f64[slots][2*Cout] (optional, Cout <= 128), i 23 = slots
+// MSL_OP_CONV slots (see msl_launch_conv) + p 5 = BatchNorm accumulator f64[slots][2*Cout] (optional), i 23 = slots
 int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   C1Args a;
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2]; a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];
@@ -234,13 +234,13 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
   MSL_REQUIRE(a.x && a.w && a.y && a.M > 0 && msl_conv1x1_eligible(op), "conv1x1: bad args");
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs, "conv1x1: bad dims / views");
-  MSL_REQUIRE(!a.acc || (a.Cout <= 128 && a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs Cout <= 128 and bf16 output");
+  MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
 #define C1(N) case N: return a.acc ? c1_launch_pt<N, true>(a, s) : c1_launch_pt<N, false>(a, s)
 #define C1N(N) case N: return c1_launch_pt<N, false>(a, s)
   switch (ncp) {
     C1(1); C1(2); C1(3); C1(4);
-    C1N(5); C1N(6); C1N(7); C1N(8);
+    C1(5); C1(6); C1(7); C1(8);
   }
 #undef C1
 #undef C1N
