@@ -176,6 +176,8 @@ const char* msl_last_error(void);
 int msl_launch(const msl_op* op, void* stream);
 /* Enqueue ops[0..n) in order on `stream` (one host call per forward pass). */
 int msl_run_program(const msl_op* ops, int32_t n, void* stream);
+/* Same, with a lane per op (0 = `stream`, 1..3 = library-owned side streams): independent chains overlap; see capi.hip for the ordering rules. */
+int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream);
 
 /* hipGraph capture of a program: launch-bound inner loops (batch-1 predict, ~110 small kernels) replay as one graph. */
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out);

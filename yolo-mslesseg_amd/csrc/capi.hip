@@ -80,6 +80,72 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream) {
   return MSL_OK;
 }
 
+// Program with lanes: ops tagged lane 0 run on `stream`; ops tagged 1..MSL_MAX_LANES-1 run on library-owned side streams, so that
+// independent chains (the detection-head branches of different pyramid levels) overlap their launch-latency-bound kernels.
+// Ordering: ops of one lane keep program order; a side lane starts after everything issued to `stream` so far (fork event); a lane-0
+// op that follows side-lane ops waits for all of them (join), and so does the end of the program.
+#define MSL_MAX_LANES 4
+static hipStream_t g_side[16][MSL_MAX_LANES];
+static hipEvent_t g_fork[16], g_join[16][MSL_MAX_LANES];
+static bool g_lanes_ready[16];
+
+static int lanes_init(int dev) {
+  if (g_lanes_ready[dev]) return MSL_OK;
+  if (hipEventCreateWithFlags(&g_fork[dev], hipEventDisableTiming) != hipSuccess) { msl_set_error("lanes: hipEventCreate failed"); return MSL_ELAUNCH; }
+  for (int k = 1; k < MSL_MAX_LANES; ++k) {
+    if (hipStreamCreateWithFlags(&g_side[dev][k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_join[dev][k], hipEventDisableTiming) != hipSuccess) {
+      msl_set_error("lanes: cannot create side stream %d", k);
+      return MSL_ELAUNCH;
+    }
+  }
+  g_lanes_ready[dev] = true;
+  return MSL_OK;
+}
+
+int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream) {
+  if (!ops || !lanes || n < 0) { msl_set_error("msl_run_program_lanes: bad arguments"); return MSL_EINVAL; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { msl_set_error("msl_run_program_lanes: bad device"); return MSL_ELAUNCH; }
+  int rc = lanes_init(dev);
+  if (rc != MSL_OK) return rc;
+  hipStream_t main_s = (hipStream_t)stream;
+  bool active[MSL_MAX_LANES] = {false, false, false, false};
+  auto join_all = [&]() {
+    for (int k = 1; k < MSL_MAX_LANES; ++k)
+      if (active[k]) {
+        (void)hipEventRecord(g_join[dev][k], g_side[dev][k]);
+        (void)hipStreamWaitEvent(main_s, g_join[dev][k], 0);
+        active[k] = false;
+      }
+  };
+  for (int32_t i = 0; i < n; ++i) {
+    const int L = lanes[i];
+    if (L < 0 || L >= MSL_MAX_LANES) { msl_set_error("op %d: lane %d out of range", i, L); join_all(); return MSL_EINVAL; }
+    hipStream_t s = main_s;
+    if (L == 0) {
+      join_all();
+    } else {
+      if (!active[L]) {  // fork: the side lane sees everything issued to the main stream so far
+        (void)hipEventRecord(g_fork[dev], main_s);
+        (void)hipStreamWaitEvent(g_side[dev][L], g_fork[dev], 0);
+        active[L] = true;
+      }
+      s = g_side[dev][L];
+    }
+    rc = dispatch(ops[i], s);
+    if (rc != MSL_OK) {
+      char tmp[400];
+      strncpy(tmp, g_err, sizeof(tmp) - 1);
+      tmp[sizeof(tmp) - 1] = 0;
+      msl_set_error("op %d (kind %d, lane %d): %s", i, ops[i].kind, L, tmp);
+      join_all();
+      return rc;
+    }
+  }
+  join_all();
+  return MSL_OK;
+}
+
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out) {
   if (!ops || n <= 0 || !graph_exec_out) { msl_set_error("msl_graph_create: bad arguments"); return MSL_EINVAL; }
   hipStream_t s = (hipStream_t)stream;

@@ -21,7 +21,7 @@ OP_CONV_WGRAD, OP_DW_WGRAD, OP_STEM_WGRAD, OP_CAST_PAD, OP_GATHER_CAST, OP_ADAMW
 OP_SEG_LOSS, OP_ATTENTION_BWD = 33, 34
 
 EXPORTS = (
-    "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_graph_create", "msl_graph_launch",
+    "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_launch",
     "msl_graph_destroy", "msl_event_create", "msl_event_record", "msl_event_elapsed_ms", "msl_event_destroy",
     "msl_seg_loss_workspace",
 )
@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
         L.msl_last_error.restype = C.c_char_p
         L.msl_launch.argtypes = [C.POINTER(MslOp), C.c_void_p]
         L.msl_run_program.argtypes = [C.POINTER(MslOp), C.c_int32, C.c_void_p]
+        L.msl_run_program_lanes.argtypes = [C.POINTER(MslOp), C.POINTER(C.c_int32), C.c_int32, C.c_void_p]
         L.msl_graph_create.argtypes = [C.POINTER(MslOp), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
         L.msl_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
         L.msl_graph_destroy.argtypes = [C.c_void_p]
@@ -97,13 +98,17 @@ def launch(op: MslOp, stream: int) -> None:
 class Program:
     """A fixed list of ops (device pointers baked in) enqueued with one host call, optionally as a hipGraph."""
 
-    def __init__(self, ops):
+    def __init__(self, ops, lanes=None):
         self.n = len(ops)
         self.arr = (MslOp * self.n)(*ops)
+        self.lanes = (C.c_int32 * self.n)(*lanes) if lanes is not None and any(lanes) else None  # per-op side-stream lane (0 = caller's stream)
         self._graph = None
 
     def run(self, stream: int) -> None:
-        check(lib().msl_run_program(self.arr, self.n, C.c_void_p(stream)), "msl_run_program")
+        if self.lanes is not None:
+            check(lib().msl_run_program_lanes(self.arr, self.lanes, self.n, C.c_void_p(stream)), "msl_run_program_lanes")
+        else:
+            check(lib().msl_run_program(self.arr, self.n, C.c_void_p(stream)), "msl_run_program")
 
     def capture(self, stream: int) -> None:
         g = C.c_void_p()

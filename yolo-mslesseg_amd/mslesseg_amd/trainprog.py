@@ -14,6 +14,9 @@ Layout decisions
 """
 from __future__ import annotations
 
+import os
+import re
+
 import math
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Tuple
@@ -241,7 +244,9 @@ class TrainPlan(graph.Visitor):
         self._arena: Dict[int, dict] = {}
         self._bwd_acc = torch.zeros(1 << 19, dtype=torch.float64, device=self.device)  # all backward reduction accumulators
         self._bwd_acc_n = 0
-        self._wg_scratch = torch.empty(WG_SCRATCH_FLOATS, dtype=torch.float32, device=self.device)  # per-workgroup dW partials (one wgrad runs at a time)
+        self._wg_scratch: Dict[int, torch.Tensor] = {}  # per-workgroup dW partials: one buffer per lane (one wgrad runs at a time on a lane)
+        self._lane = 0
+        self.use_lanes = os.environ.get("MSLESSEG_LANES", "1") != "0"
         self._keep: List[torch.Tensor] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.levels, self.proto_view, self.in_view = {}, None, None
@@ -266,7 +271,30 @@ class TrainPlan(graph.Visitor):
         return View(g, v.N, v.H, v.W, v.C, v.cs, v.co, v.f32)
 
     def _f(self, op):
+        op._lane = self._lane
         self._fwd[-1].append(op)
+
+    def _set_lane(self, name: Optional[str]) -> int:
+        """Lane (side stream) of the layer being visited: the detection-head chains of pyramid level i run on lane 1+i, concurrently with
+        the other levels (their kernels at 40x40 / 20x20 are launch-latency bound); the prototype branch shares lane 1 with level 0
+        because both accumulate into the gradient of the same P3 feature.  Everything else: lane 0 = the caller's stream."""
+        lane = 0
+        if self.use_lanes and name:
+            m = re.match(r"model\.\d+\.cv[234]\.(\d+)\.", name)
+            if m:
+                lane = 1 + min(int(m.group(1)), 2)
+            elif re.match(r"model\.\d+\.proto\.", name):
+                lane = 1
+        self._lane = lane
+        return lane
+
+    def _scratch(self, lane: int) -> int:
+        if lane not in self._wg_scratch:
+            self._wg_scratch[lane] = torch.empty(WG_SCRATCH_FLOATS, dtype=torch.float32, device=self.device)
+        return self._wg_scratch[lane].data_ptr()
+
+    def _add_bw(self, build):
+        self._bw_builders.append((build, self._lane))
 
     def _acc(self, C) -> torch.Tensor:
         t = torch.zeros(2 * C * ACC_SLOTS, dtype=torch.float64, device=self.device)
@@ -362,6 +390,7 @@ class TrainPlan(graph.Visitor):
         return self.in_view
 
     def stem(self, name, x, cout):
+        lane = self._set_lane(name)
         st = self.store
         Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
         z, y = self._new(Ho, Wo, cout), self._new(Ho, Wo, cout)
@@ -373,14 +402,15 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             self._bn_backward(ops, name, z, y, cout, True, stats, None)
-            ops.append(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+            ops.append(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
                                       i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS}))
             return ops
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return y
 
     def conv(self, name, x, cout, k=1, s=1, act=True, bn=True, out=None, res=None, f32_out=False):
+        lane = self._set_lane(name)
         st = self.store
         pad = k // 2
         Ho, Wo = (x.H + 2 * pad - k) // s + 1, (x.W + 2 * pad - k) // s + 1
@@ -462,7 +492,7 @@ class TrainPlan(graph.Visitor):
                 ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dzc.t.data_ptr(), dz.t.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
                 dz, dz_f32 = dzc, 0
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
                                       i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}))
             gx = self.G(x)
             first = self._init.first_write(gx)
@@ -481,10 +511,11 @@ class TrainPlan(graph.Visitor):
                 ops.append(op)
             return ops
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return y
 
     def convT2x2(self, name, x, cout):
+        lane = self._set_lane(name)
         st = self.store
         y = self._new(2 * x.H, 2 * x.W, cout)
         cin = x.C
@@ -509,17 +540,18 @@ class TrainPlan(graph.Visitor):
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co, 21: ACC_SLOTS}))
             ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cout}))
             # dW[ci][(dy,dx,co)] = sum_p x[p][ci] * dy[(2y+dy,2x+dx)][co]: CONV_WGRAD with the operands swapped
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co, 21: WG_SCRATCH_FLOATS}))
             gx = self.G(x)
             first = self._init.first_write(gx)
             ops.append(self._conv_op(gy, gx, wd, self.zeros.data_ptr(), dm, 2, 2, 0, res=None if first else gx, cout=cin))
             return ops
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return y
 
     def dwconv(self, name, x, act=True, res=None, gmap=None, out=None):
+        lane = self._set_lane(name)
         st = self.store
         C = x.C if gmap is None else x.C // gmap[1] * gmap[0]
         y = out if out is not None else self._new(x.H, x.W, C)
@@ -534,7 +566,7 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             self._bn_backward(ops, name, z, y, C, act, stats, res, res_inplace=inplace)
-            ops.append(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._wg_scratch.data_ptr()),
+            ops.append(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
                                       i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS, **gm}))
             gx = self.G(x)
             if gmap is None:
@@ -551,7 +583,7 @@ class TrainPlan(graph.Visitor):
             ops.append(hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(z.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), rp, gx.t.data_ptr()), i=i))
             return ops
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return y
 
     def cat_buffer(self, like, C, scale=1.0):
@@ -561,6 +593,7 @@ class TrainPlan(graph.Visitor):
         return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32)
 
     def upsample2x(self, x, out):
+        self._set_lane(None)
         self._f(hiplib.make_op(hiplib.OP_UPSAMPLE2X, self.dtype, p=(x.t.data_ptr(), 0, 0, 0, out.t.data_ptr()),
                                i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: x.cs, 11: x.co, 12: out.cs, 13: out.co}))
 
@@ -570,10 +603,11 @@ class TrainPlan(graph.Visitor):
             return [hiplib.make_op(hiplib.OP_UPSAMPLE2X_BWD, self.dtype, p=(gx.t.data_ptr(), go.t.data_ptr()),
                                    i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: gx.cs, 11: gx.co, 12: go.cs, 13: go.co})]
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return out
 
     def copy(self, src, dst):
+        self._set_lane(None)
         dims = {0: self.N, 1: src.H, 2: src.W, 3: src.C}
         self._f(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dst.t.data_ptr(), src.t.data_ptr()),
                                i={**dims, 10: dst.cs, 11: dst.co, 12: src.cs, 13: src.co, 20: 1}))
@@ -584,10 +618,11 @@ class TrainPlan(graph.Visitor):
             return [hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gs.t.data_ptr(), gd.t.data_ptr()),
                                    i={**dims, 10: gs.cs, 11: gs.co, 12: gd.cs, 13: gd.co, 20: 1 if first else 0})]
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return dst
 
     def sppf_pool(self, buf, c):
+        self._set_lane(None)
         self._f(hiplib.make_op(hiplib.OP_SPPF_POOL, self.dtype, p=(buf.t.data_ptr(),), i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: buf.cs, 11: buf.co}))
         scratch = torch.zeros(self.N * buf.H * buf.W * c, dtype=torch.float32, device=self.device)
         self._keep.append(scratch)
@@ -603,9 +638,10 @@ class TrainPlan(graph.Visitor):
                                i={0: self.N, 1: buf.H, 2: buf.W, 3: c, 10: g.cs, 11: g.co, 12: c, 13: 0, 19: 1, 20: 0}),
             ]
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
 
     def attention(self, qkv, heads, kd, hd):
+        self._set_lane(None)
         """PSA attention core.  bf16: the matrix-core kernels of attention.hip, forward (MSL_OP_ATTENTION) and backward
         (MSL_OP_ATTENTION_BWD, probabilities recomputed).  fp32 (parity engine): torch batched GEMMs + softmax and the hand-derived backward."""
         y = self._new(qkv.H, qkv.W, heads * hd)
@@ -623,7 +659,7 @@ class TrainPlan(graph.Visitor):
                 return [hiplib.make_op(hiplib.OP_ATTENTION_BWD, self.dtype, p=(qkv.t.data_ptr(), y.t.data_ptr(), gy.t.data_ptr(), stats.data_ptr(), gq.t.data_ptr()),
                                        i={**dims, 14: gq.cs, 15: gq.co}, f=(scale,))]
 
-            self._bw_builders.append(bw_hip)
+            self._add_bw(bw_hip)
             return y
         saved = {}
 
@@ -658,7 +694,7 @@ class TrainPlan(graph.Visitor):
             self._init.mark(self.G(qkv))
             return [run]
 
-        self._bw_builders.append(bw)
+        self._add_bw(bw)
         return y
 
     def head_level(self, i, box, cls, coef):
@@ -675,15 +711,20 @@ class TrainPlan(graph.Visitor):
                 self._init.mark(self.G(v))
         self._init.mark(self.G(self.proto_view))
         bwd_segments: List = [[]]
-        for build in reversed(self._bw_builders):
+        for build, lane in reversed(self._bw_builders):
             for op in build():
                 if callable(op):
                     bwd_segments.append(op)
                     bwd_segments.append([])
                 else:
+                    op._lane = lane
                     bwd_segments[-1].append(op)
-        self.forward_segments = [hiplib.Program(s) if isinstance(s, list) and s else s for s in self._fwd if not (isinstance(s, list) and not s)]
-        self.backward_segments = [hiplib.Program(s) if isinstance(s, list) and s else s for s in bwd_segments if not (isinstance(s, list) and not s)]
+
+        def prog(ops):
+            return hiplib.Program(ops, lanes=[getattr(o, "_lane", 0) for o in ops])
+
+        self.forward_segments = [prog(s) if isinstance(s, list) and s else s for s in self._fwd if not (isinstance(s, list) and not s)]
+        self.backward_segments = [prog(s) if isinstance(s, list) and s else s for s in bwd_segments if not (isinstance(s, list) and not s)]
         for dt, ar in self._arena.items():
             idx_d = torch.cat(ar["idx"]).to(self.device)
             self._keep += [idx_d, ar["buf"]]
