@@ -106,6 +106,23 @@ class PackedWeights:
         self.t[name] = pack_gemm(wg, b, self.dtype, self.device)
 
 
+def _lane_of(name: str) -> int:
+    """Side-stream lane of an inference op (hiplib.Program lanes): the head chains of the three pyramid levels and the prototype branch
+    are independent, and at 40x40 / 20x20 their kernels are launch-latency bound — level 0 → lane 1, prototypes → lane 2, levels 1 and 2 →
+    lane 3; backbone, neck, decode, NMS and mask assembly stay on the caller's stream (lane 0), which joins the lanes before decode."""
+    import os
+    import re
+
+    if os.environ.get("MSLESSEG_LANES", "1") == "0":
+        return 0
+    m = re.match(r"model\.\d+\.cv[234]\.(\d+)\.", name)
+    if m:
+        return 1 if int(m.group(1)) == 0 else 3
+    if re.match(r"model\.\d+\.proto\.", name):
+        return 2
+    return 0
+
+
 class ProgramBuilder(graph.Visitor):
     """graph.Visitor that allocates buffers and emits msl_op descriptors for a fixed (N, Hlb, Wlb)."""
 
@@ -127,6 +144,7 @@ class ProgramBuilder(graph.Visitor):
         return View(t, self.N, H, W, C, C, 0, f32)
 
     def _emit(self, name, op):
+        op._lane = _lane_of(name)
         self.ops.append(op)
         self.names.append(name)
 
@@ -258,7 +276,7 @@ class Plan:
         b._emit("mask_lowres", hiplib.make_op(hiplib.OP_MASK_LOWRES, self.dtype,
                                               p=(self.proto.t.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), 0, self.lowres.data_ptr(), self.range.data_ptr(), self.posbits.data_ptr()),
                                               i={0: N, 1: mh, 2: mw, 4: graph.NM, 7: max_det, 8: Hlb, 9: Wlb, 10: self.proto.cs, 11: self.proto.co}))
-        self.program = hiplib.Program(b.ops)
+        self.program = hiplib.Program(b.ops, lanes=[getattr(o, "_lane", 0) for o in b.ops])
         self.op_names = list(b.names)
         self._merge = {}
 
