@@ -88,75 +88,105 @@ int msl_launch_stem(const msl_op& op, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Depthwise 3x3, stride 1, pad 1.  One thread = one pixel x 4 channels.
+// Depthwise 3x3, stride 1, pad 1.  One thread = V channels (4, or 8 = one 16-byte access of bf16) x 2 horizontally adjacent
+// pixels: the 3 x 4 input window is loaded once for both outputs, the 9 x V weights of the thread's channels come from an LDS
+// copy of the filter bank.  The fma order per output is unchanged (bias, then taps row-major): bit-identical results.
 // [UPSTREAM DWConv in Segment.cv3; Attention.pe]
 // ---------------------------------------------------------------------------------------------------------
-template <bool F32>
+template <bool F32, int V>
 __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const void* __restrict__ res,
                                                      void* __restrict__ y, int N, int H, int W, int C, int x_cs, int x_co,
                                                      int y_cs, int y_co, int res_cs, int res_co, int act, int gsz,
                                                      int gstride, int goff, int flip, int omap) {
-  const int C4 = C >> 2;
-  long t = (long)blockIdx.x * 256 + threadIdx.x;
-  long total = (long)N * H * W * C4;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [10][C]: 9 taps (already flipped if asked) + bias
+  for (int i = threadIdx.x; i < 10 * C; i += 256) {
+    const int t = i / C, ch = i - t * C;
+    sw[i] = t < 9 ? w[(flip ? 8 - t : t) * C + ch] : bias[ch];
+  }
+  __syncthreads();
+  const int CV = C / V, Wp = (W + 1) >> 1;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * H * Wp * CV;
   if (t >= total) return;
-  int c = (int)(t % C4) * 4;
-  long p = t / C4;
-  int ix = (int)(p % W);
-  long q = p / W;
-  int iy = (int)(q % H);
-  int n = (int)(q / H);
+  const int c = (int)(t % CV) * V;
+  const long pr = t / CV;
+  const int xp = (int)(pr % Wp);
+  const long q = pr / Wp;
+  const int iy = (int)(q % H), n = (int)(q / H);
+  const int x0 = 2 * xp;
+  const bool two = x0 + 1 < W;
   const int cmap = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
   const int cin = omap ? c : cmap;    // channel map on the input side (Attention.pe forward) ...
   const int cdst = omap ? cmap : c;   // ... or on the output/residual side (its backward: gradient lands in the v slots of qkv)
-  float4 b4 = *(const float4*)(bias + c);
-  float acc[4] = {b4.x, b4.y, b4.z, b4.w};
+  float acc0[V], acc1[V];
+#pragma unroll
+  for (int r = 0; r < V; ++r) { acc0[r] = sw[9 * C + c + r]; acc1[r] = acc0[r]; }
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
-    int yy = iy - 1 + ky;
+    const int yy = iy - 1 + ky;
     if ((unsigned)yy >= (unsigned)H) continue;
+    float col[4][V];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = x0 - 1 + j;
+      if ((unsigned)xx < (unsigned)W) ldv<F32, V>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin, col[j]);
+      else {
+#pragma unroll
+        for (int r = 0; r < V; ++r) col[j][r] = 0.f;
+      }
+    }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      int xx = ix - 1 + kx;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      float v[4];
-      ld4<F32>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin, v);
-      float4 w4 = *(const float4*)(w + (flip ? 8 - (ky * 3 + kx) : ky * 3 + kx) * C + c);
-      acc[0] = fmaf(v[0], w4.x, acc[0]); acc[1] = fmaf(v[1], w4.y, acc[1]);
-      acc[2] = fmaf(v[2], w4.z, acc[2]); acc[3] = fmaf(v[3], w4.w, acc[3]);
+      const float* wr = sw + (ky * 3 + kx) * C + c;
+      // a tap that falls outside the image is skipped, as before (its product would be an exact 0 * w anyway, but -0/NaN weights must not leak)
+      const bool in0 = (unsigned)(x0 - 1 + kx) < (unsigned)W, in1 = (unsigned)(x0 + kx) < (unsigned)W;
+#pragma unroll
+      for (int r = 0; r < V; ++r) {
+        if (in0) acc0[r] = fmaf(col[kx][r], wr[r], acc0[r]);
+        if (in1) acc1[r] = fmaf(col[kx + 1][r], wr[r], acc1[r]);
+      }
     }
   }
+  const long p0 = ((long)n * H + iy) * W + x0;
   if (act) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = silu_f(acc[r]);
+    for (int r = 0; r < V; ++r) { acc0[r] = silu_f(acc0[r]); acc1[r] = silu_f(acc1[r]); }
   }
   if (res) {
-    float rv[4];
-    ld4<F32>(res, p * res_cs + res_co + cdst, rv);
+    float rv[V];
+    ldv<F32, V>(res, p0 * res_cs + res_co + cdst, rv);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += rv[r];
+    for (int r = 0; r < V; ++r) acc0[r] += rv[r];
+    if (two) {
+      ldv<F32, V>(res, (p0 + 1) * res_cs + res_co + cdst, rv);
+#pragma unroll
+      for (int r = 0; r < V; ++r) acc1[r] += rv[r];
+    }
   }
-  st4<F32>(y, p * y_cs + y_co + cdst, acc);
+  stv<F32, V>(y, p0 * y_cs + y_co + cdst, acc0);
+  if (two) stv<F32, V>(y, (p0 + 1) * y_cs + y_co + cdst, acc1);
 }
 
 int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
   int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13];
   int res_cs = op.i[14], res_co = op.i[15], act = op.i[18], gsz = op.i[22], gstride = op.i[23], goff = op.i[24];
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[4], "dwconv: null pointer");
-  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv: bad dims");
+  MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, "dwconv: bad dims (C <= 1024: the filter bank is kept in LDS)");
   MSL_REQUIRE(x_cs % 4 == 0 && x_co % 4 == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && (op.i[21] || y_co + C <= y_cs), "dwconv: bad views");
   const int flip = op.i[20], omap = op.i[21];
   if (gsz && !omap) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && x_co + (C / gsz - 1) * gstride + goff + gsz <= x_cs, "dwconv: bad group map");
   else MSL_REQUIRE(x_co + C <= x_cs, "dwconv: input view exceeds stride");
   if (gsz && omap) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && y_co + (C / gsz - 1) * gstride + goff + gsz <= y_cs, "dwconv: bad output group map");
   if (op.p[3]) MSL_REQUIRE(res_cs % 4 == 0 && res_co % 4 == 0 && res_co + C <= res_cs, "dwconv: bad residual view");
-  long total = (long)N * H * W * (C / 4);
-  unsigned grid = (unsigned)((total + 255) / 256);
-  if (op.dtype == MSL_F32)
-    hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap);
-  else
-    hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap);
+  const bool v8 = C % 8 == 0 && ((x_cs | x_co | y_cs | y_co) & 7) == 0 && (!op.p[3] || ((res_cs | res_co) & 7) == 0) && (!gsz || ((gsz | gstride | goff) & 7) == 0);
+  const int V = v8 ? 8 : 4;
+  const long total = (long)N * H * ((W + 1) / 2) * (C / V);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  const size_t lds = (size_t)10 * C * 4;
+#define DW(F, VV) hipLaunchKernelGGL((dwconv_kernel<F, VV>), dim3(grid), dim3(256), lds, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap)
+  if (op.dtype == MSL_F32) { if (v8) DW(true, 8); else DW(true, 4); } else { if (v8) DW(false, 8); else DW(false, 4); }
+#undef DW
   MSL_CHECK_LAUNCH("dwconv");
   return MSL_OK;
 }
