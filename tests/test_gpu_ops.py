@@ -109,6 +109,9 @@ LDS3_CASES = [
     (1, 21, 35, 32, 32, 2, 32, 0, 32, 0, 1, 0, 0),       # stride 2, odd size
     (1, 80, 80, 64, 64, 2, 64, 0, 192, 0, 1, 0, 0),      # model.17-like: into a concat slice
     (1, 160, 160, 64, 64, 1, 64, 0, 64, 0, 1, 0, 0),     # proto.cv2 shape at batch 1
+    (2, 40, 56, 16, 32, 2, 16, 0, 32, 0, 1, 0, 0),       # model.1-like: ONE partial channel chunk (missing k-group planes staged as zeros)
+    (1, 33, 47, 8, 16, 1, 24, 8, 16, 0, 1, 1, 0),        # 8 → 16 out of a concat slice, residual
+    (1, 20, 20, 8, 32, 2, 8, 0, 32, 0, 0, 0, 1),         # stride 2, fp32 output
 ]
 
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const char* ximg = a.x + ((long)n * a.H * a.W * a.x_cs + a.x_co) * ES;
-  const int nchunks = a.Cin / CHUNK;
+  const int nchunks = (a.Cin + CHUNK - 1) / CHUNK;  // whole chunks, or one partial chunk whose missing k-group planes are staged as zeros
   const char* wblk = a.w + (long)cob * nchunks * W_BYTES;
 
   // ---- per-lane staging sources, computed once: piece j of this wave covers plane gq, slots sl..sl+63
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       c = pos * 2 + (rr & 1);
     }
     const int iy = iy0 + r, ix = ix0 + c;
-    const bool ok = pc < IN_PIECES && sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const bool ok = pc < IN_PIECES && sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && gq * (CHUNK / 4) < a.Cin;
     in_off[j] = ok ? ((iy * a.W + ix) * a.x_cs) * ES + gq * 16 : -1;
   }
   const char* wlane = wblk + wave * 1024 + lane * 16;
@@ -254,7 +254,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv3x3_lds: null pointer");
   MSL_REQUIRE(k == 3 && pad == 1 && (stride == 1 || stride == 2) && op.i[20] == 0, "conv3x3_lds: needs k=3 pad=1 stride 1|2, plain store");
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho == (a.H + 2 - 3) / stride + 1 && a.Wo == (a.W + 2 - 3) / stride + 1, "conv3x3_lds: bad dims");
-  MSL_REQUIRE(a.Cin > 0 && a.Cin % chunk == 0 && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs, "conv3x3_lds: Cin must be a multiple of %d", chunk);
+  MSL_REQUIRE(a.Cin > 0 && a.Cin % v == 0 && (a.Cin % chunk == 0 || a.Cin < chunk) && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs,
+              "conv3x3_lds: Cin must be a multiple of %d, or a multiple of %d below it", chunk, v);
   MSL_REQUIRE(a.Cout % 16 == 0 && a.y_cs % 4 == 0 && a.y_co % 4 == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: Cout must be a multiple of 16");
   if (a.res) MSL_REQUIRE(a.res_cs % 4 == 0 && a.res_co % 4 == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
   const int cot = a.Cout % 64 == 0 ? 4 : (a.Cout % 32 == 0 ? 2 : 1);

@@ -59,7 +59,8 @@ def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
 
 def lds3x3_eligible(cin: int, cout: int, k: int, dtype: int) -> bool:
     chunk = 16 if dtype == MSL_F32 else 32
-    return k == 3 and cin % chunk == 0 and cout % 16 == 0
+    # whole channel chunks, or ONE partial chunk (narrow layers: the missing k-group planes are staged as zeros)
+    return k == 3 and cout % 16 == 0 and (cin % chunk == 0 or (cin < chunk and cin % (chunk // 4) == 0))
 
 
 def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
@@ -69,7 +70,11 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
     chunk = 4 * ch
     cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
     cob = 16 * cot
-    wv = w.reshape(cout // cob, cob, cin // chunk, 4, ch, 3, 3)          # [blk, col, cc, g, e, ky, kx]
+    if cin % chunk:  # one partial chunk: zero weights for the channels that do not exist
+        wp = torch.zeros(cout, (cin + chunk - 1) // chunk * chunk, 3, 3, dtype=w.dtype)
+        wp[:, :cin] = w
+        w = wp
+    wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)   # [blk, col, cc, g, e, ky, kx]
     img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
     return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
 

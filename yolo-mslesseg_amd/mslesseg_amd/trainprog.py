@@ -188,13 +188,18 @@ def _lds_image_idx(idx4: torch.Tensor, dtype: int):
     chunk = 4 * ch
     cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
     cob = 16 * cot
-    v = idx4.reshape(cout // cob, cob, cin // chunk, 4, ch, 3, 3).permute(0, 2, 5, 6, 3, 1, 4).contiguous()
+    if cin % chunk:  # one partial chunk: index -1 = zero weight (GATHER_CAST)
+        padded = torch.full((cout, (cin + chunk - 1) // chunk * chunk, 3, 3), -1, dtype=idx4.dtype)
+        padded[:, :cin] = idx4
+        idx4 = padded
+    v = idx4.reshape(cout // cob, cob, idx4.shape[1] // chunk, 4, ch, 3, 3).permute(0, 2, 5, 6, 3, 1, 4).contiguous()
     return v.reshape(-1).to(torch.int32), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
 
 
 def _lds_ok(cin, cout, k, dtype):
-    chunk = 16 if dtype == MSL_F32 else 32
-    return k == 3 and cin % chunk == 0 and cout % 16 == 0
+    from .engine import lds3x3_eligible
+
+    return lds3x3_eligible(cin, cout, k, dtype)
 
 
 class _Init:
