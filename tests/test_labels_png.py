@@ -40,6 +40,7 @@ def test_png_reader_matches_pillow_on_filtered_files(tmp_path):
         ref = np.asarray(Image.open(tmp_path / f"{mode}.png"))
         got = pngio.read_png(tmp_path / f"{mode}.png", "raw")
         assert np.array_equal(got.reshape(ref.shape), ref), mode
+        assert np.array_equal(pngio.read_bgr(tmp_path / f"{mode}.png"), pngio.read_png(tmp_path / f"{mode}.png", "bgr")), mode  # fast path = own decoder
     pal = Image.fromarray(smooth // 32, "P")
     pal.putpalette([v for i in range(256) for v in (i, 255 - i, (i * 7) % 256)])
     pal.save(tmp_path / "p.png")

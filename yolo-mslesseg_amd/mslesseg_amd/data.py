@@ -83,10 +83,10 @@ class SegDataset:
             raise FileNotFoundError(f"no PNG images under {root / 'images'}")
         self.imgsz = imgsz
         self.items = []
-        from PIL import Image
+        from .pngio import read_bgr
 
         for f in self.im_files:
-            rgb = np.asarray(Image.open(f).convert("RGB"))
+            rgb = np.ascontiguousarray(read_bgr(f)[..., ::-1])
             inst = L.read_label_file(root / "labels" / (f.stem + ".txt"))
             self.items.append((resize_keep_ratio(rgb, imgsz), [(c, p.copy()) for c, p in inst]))
 

@@ -136,3 +136,18 @@ def read_png(path, mode: str = "bgr") -> np.ndarray:
         r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
         return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
     raise ValueError(f"read_png: unknown mode {mode!r}")
+
+
+def read_bgr(path) -> np.ndarray:
+    """`cv2.imread(path)` for a PNG: Pillow's C decoder when it is installed (the pure-NumPy un-filtering above walks Paeth / Average
+    scanlines byte by byte — fine for tests and single files, slow for a dataset of thousands of slices), else `read_png`.  Both give the
+    same pixels (tests/test_labels_png.py)."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return read_png(path, "bgr")
+    with Image.open(path) as im:
+        if im.format != "PNG" or im.mode not in ("L", "LA", "RGB", "RGBA", "P", "1"):
+            return read_png(path, "bgr")
+        rgb = np.asarray(im.convert("RGB"))
+    return np.ascontiguousarray(rgb[..., ::-1])

@@ -138,10 +138,14 @@ class YOLO:
     @staticmethod
     def _load_image(src) -> np.ndarray:
         if isinstance(src, (str, Path)):
-            from PIL import Image
+            if str(src).lower().endswith(".png"):  # the reference's slices are PNGs: own decoder, cv2.imread channel order (BGR)
+                from .pngio import read_bgr
+
+                return read_bgr(src)
+            from PIL import Image  # other formats only if Pillow happens to be installed
 
             rgb = np.asarray(Image.open(src).convert("RGB"))
-            return np.ascontiguousarray(rgb[..., ::-1])  # cv2.imread order (BGR)
+            return np.ascontiguousarray(rgb[..., ::-1])
         arr = np.asarray(src)
         if arr.ndim == 2:
             arr = np.repeat(arr[..., None], 3, axis=2)
