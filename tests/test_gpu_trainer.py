@@ -57,3 +57,41 @@ def test_adamw_kernel_matches_torch_adamw():
                                      i={0: n, 1: 0, 2: _fbits(5e-4), 3: _fbits(1 - 0.9**t), 4: _fbits(1 - 0.999**t)}, f=(2e-3, 0.9, 0.999, 1e-8)), s)
     torch.cuda.synchronize()
     assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_train_through_the_reference_call_signature(tmp_path):
+    """`entrenar_fold` [REF scripts/train.py:346-366]: staged `images/` + `labels/` folders (labels from the mask converter, PNG slices
+    like `plt.imsave` writes them), the YAML of `generar_yaml`, then `.train(data=<yaml>, epochs=E, batch=-1, cache=True, project=…,
+    name="fold<k>", verbose=False)` — and the files `entrenamiento_exitoso` looks for."""
+    import yaml
+    from ultralytics import YOLO
+    from ultralytics.data.converter import convert_segment_masks_to_yolo_seg
+
+    from mslesseg_amd import pngio
+
+    rng = np.random.default_rng(0)
+    for split, n in (("train", 10), ("val", 4)):
+        img_dir, mask_dir, lab_dir = (tmp_path / split / d for d in ("images", "GT_masks", "labels"))
+        for i in range(n):
+            mask = np.zeros((182, 218), np.uint8)
+            for _ in range(int(rng.integers(1, 4))):
+                cy, cx, ry, rx = rng.integers(30, 150), rng.integers(30, 180), rng.integers(4, 14), rng.integers(4, 14)
+                yy, xx = np.ogrid[:182, :218]
+                mask[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1] = 1
+            grey = np.clip(rng.normal(90, 30, mask.shape) + 80 * mask, 0, 255).astype(np.uint8)
+            pngio.write_png(img_dir / f"P{split}_FLAIR_{i}.png", np.repeat(grey[..., None], 3, 2))
+            pngio.write_png(mask_dir / f"P{split}_FLAIR_{i}.png", mask)
+        convert_segment_masks_to_yolo_seg(masks_dir=mask_dir, output_dir=lab_dir, classes=1)
+        assert len(list(lab_dir.glob("*.txt"))) == n
+    cfg = {"path": str(tmp_path), "train": str(tmp_path / "train"), "val": str(tmp_path / "val"), "names": ["lesion"], "nc": 1}
+    (tmp_path / "dataset.yaml").write_text(yaml.safe_dump(cfg))
+    model = YOLO("yolo11n-seg.pt")
+    model.train(data=tmp_path / "dataset.yaml", epochs=1, batch=-1, cache=True, project=tmp_path / "trains", name="fold1", verbose=False)
+    run = tmp_path / "trains" / "fold1"
+    for f in ("weights/best.pt", "weights/last.pt", "results.csv", "args.yaml"):
+        assert (run / f).exists() and (run / f).stat().st_size > 0, f
+    rows = list(csv.DictReader(open(run / "results.csv")))
+    assert len(rows) == 1 and all(np.isfinite(float(v)) for v in rows[0].values())
+    m2 = YOLO(run / "weights" / "best.pt")
+    res = m2(str(tmp_path / "val" / "images" / "Pval_FLAIR_0.png"), verbose=False)[0]  # a PNG path as the source
+    assert res.masks is None or res.masks.data.shape[1:] == (544, 640)  # 182x218 letterboxes to 544x640
