@@ -121,7 +121,8 @@ def test_forward_bf16_close_to_oracle(eng_bf16, oracle_model, golden):
     """bf16 storage (8 significand bits) against the fp32 oracle.  The calibrated-random test network amplifies a
     perturbation ~2x per stage (measured: 1.9e-3 rel-L2 after the stem = one bf16 rounding, 0.22 after layer 10;
     profiles/r01_bf16_error_growth.txt), so only distribution-level bounds are meaningful here; the per-op bf16
-    parity is in test_gpu_ops.py and the storage-emulation check in test_gpu_bf16_emulation.py."""
+    parity is in test_gpu_ops.py.  (A bf16-storage emulation of the oracle would not tighten this: a value that sits on a
+    rounding boundary flips with fp32 summation order, and the flip is amplified the same way.)"""
     img = _img(golden, 0)
     _, y, proto = _oracle_forward(oracle_model, img)
     plan = eng_bf16.predict_batch(torch.from_numpy(img[None]))
