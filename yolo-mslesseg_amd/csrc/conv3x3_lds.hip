@@ -259,9 +259,9 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
               "conv3x3_lds: Cin must be a multiple of %d, or a multiple of %d below it", chunk, v);
   MSL_REQUIRE(a.Cout % 16 == 0 && a.y_cs % 4 == 0 && a.y_co % 4 == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: Cout must be a multiple of 16");
   if (a.res) MSL_REQUIRE(a.res_cs % 4 == 0 && a.res_co % 4 == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
-  const int cot = a.Cout % 64 == 0 ? 4 : (a.Cout % 32 == 0 ? 2 : 1);
+  const int cot = op.i[24];  // channel tiles per workgroup = how the host packed the weight image (4 for Cout % 64 == 0, else 2 or 1)
+  MSL_REQUIRE((cot == 4 || cot == 2 || cot == 1) && a.Cout % (16 * cot) == 0, "conv3x3_lds: weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
   const int cout_blocks = a.Cout / (16 * cot);
-  MSL_REQUIRE(op.i[24] == cot, "conv3x3_lds: weights were packed for COT=%d but the launch needs %d", op.i[24], cot);
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
   const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : 1;  // i[23]=-4 opts into the 16x32 tile (measured slower: kept for experiments)
   const int TH = 4 * rw;
