@@ -4,7 +4,7 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Default workload = BASELINE.json configs[1]: **YOLO11n-seg TRAIN step, 640x640 bf16**.  A "step" = one optimisation step over
+Default workload = BASELINE.json configs[1]: **YOLO11n-seg TRAIN step, 640x640 bf16, 128 slices per GPU** (north_star: batch >= 128).  A "step" = one optimisation step over
 one batch of synthetic slices already resident in HBM: weight pack → HIP forward (train-mode BatchNorm) → segmentation loss
 → HIP backward → [all-reduce of the flat gradient over ranks] → gradient clip + fused AdamW + EMA.  Nothing is skipped.
 Slices shard over ranks (data parallel); the only collective is the one gradient all-reduce → "scaling": "weak".
@@ -329,7 +329,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="train", choices=["train", "predict"])
-    ap.add_argument("--batch", type=int, default=0, help="slices per GPU per step (default: 64 train, 128 predict)")
+    ap.add_argument("--batch", type=int, default=0, help="slices per GPU per step (default: 128 for both legs — north_star: batch >= 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -348,7 +348,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
 
     if args.mode == "train":
-        B = args.batch or 64
+        B = args.batch or 128
         tr, dbatch, batch = train_setup(args, dev, rank, world, state, B)
         lr = tr.lr0
 

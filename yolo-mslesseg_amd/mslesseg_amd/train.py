@@ -40,11 +40,21 @@ RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cl
                   "val/box_loss", "val/seg_loss", "val/cls_loss", "val/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"]  # [REF trains/…/results.csv:1]
 
 DEFAULTS = dict(imgsz=640, nbs=64, seed=0, lrf=0.01, warmup_epochs=3.0, warmup_bias_lr=0.0, weight_decay=0.0005, close_mosaic=10,
-                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=64, augment=True, val_max=None)
+                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=None, augment=True, val_max=None)
 
 
 def _fbits(x: float) -> int:
     return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+def auto_batch_size(device, imgsz: int, fraction: float = 0.6, cap: int = 256) -> int:
+    """Per-GPU batch for `batch=-1`: the largest multiple of 32 whose train plan fits `fraction` of the device memory [UPSTREAM
+    utils/autobatch.py check_train_batch_size(batch=0.6)], capped at 256 slices to bound the step latency.  Memory per slice is the
+    measured footprint of the train plan (activations + their gradients, bf16): 36.8 GB at batch 256 and 640x640 → 0.145 GB per slice."""
+    total = torch.cuda.get_device_properties(device).total_memory
+    per_slice = 0.145e9 * (imgsz / 640.0) ** 2
+    b = int(fraction * total / per_slice) // 32 * 32
+    return int(max(16, min(cap, b)))
 
 
 class Schedule:
@@ -111,7 +121,8 @@ class Trainer:
             val_dataset = D.SegDataset(va if va.is_absolute() else root / va, self.hyp["imgsz"])
         self.ds, self.val_ds = dataset, val_dataset
         self.data_path = str(data) if data is not None else "synthetic"
-        self.batch = int(batch) if batch and batch > 0 else int(self.hyp["auto_batch"])  # batch=-1: "choose for me"
+        # batch=-1: "choose for me" [REF train.py:361] — upstream's autobatch fills 60 % of the device memory; same rule here (see auto_batch_size)
+        self.batch = int(batch) if batch and batch > 0 else int(self.hyp["auto_batch"] or auto_batch_size(self.device, self.hyp["imgsz"]))
         self.save_dir = Path(project or "runs/segment") / name
         self.wdir = self.save_dir / "weights"
         if self.rank == 0:
