@@ -30,10 +30,10 @@ struct C1Args {
 };
 
 template <int NCP, bool STATS, int PT>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
-__global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
+__global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 waves: 8 when the weight matrix is large, so that fewer LDS copies of it buy more pixels in flight per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, g = lane >> 4;
+  const int li = lane & 15, g = lane >> 4, NW = blockDim.x >> 6;
   const int KS = a.Kpad >> 5;
   const int pitch = a.Kpad * 2 + 16, cps = pitch >> 4;  // bytes / 16-byte chunks per LDS row (x pixels and weight rows alike)
   constexpr int SP = PT * 16;                                        // pixels per slice
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
   // ---- weights → LDS (rows >= w_rows and the pad chunk read the zero page)
   {
     const int total = NCP * 32 * cps, kchunks = a.Kpad >> 3;
-    for (int c0 = threadIdx.x & ~63; c0 < total; c0 += 256) {
+    for (int c0 = threadIdx.x & ~63; c0 < total; c0 += blockDim.x) {
       const int cidx = c0 + lane, row = cidx / cps, ch = cidx - row * cps;
       const bool ok = cidx < total && row < a.w_rows && ch < kchunks;
       const char* src = ok ? a.w + ((long)row * a.Kpad + ch * 8) * 2 : (const char*)c1_zero_page;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
     }
   }
   const long tiles = (a.M + SP - 1) / SP;
-  const long stride = (long)gridDim.x * 4;
+  const long stride = (long)gridDim.x * NW;
   const int xchunks = a.Cin >> 3;
 
   auto stage = [&](long tile, int buf) __attribute__((always_inline)) {
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
         for (int r = 0; r < 4; ++r) { s1[c][m][r] = 0.f; s2[c][m][r] = 0.f; }
   }
 
-  long tile = (long)blockIdx.x * 4 + wave;
+  long tile = (long)blockIdx.x * NW + wave;
   if (tile < tiles) stage(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // weights visible to every wave (the only workgroup barrier before the epilogue)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
     // fold: over the 16 pixel lanes (shuffles), over the 4 waves (LDS), then one fp64 atomic per channel and statistic
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done with LDS
-    float* red = (float*)smem;  // [4 waves][2][NCP*32]
+    float* red = (float*)smem;  // [NW waves][2][NCP*32]
 #pragma unroll
     for (int c = 0; c < NCP; ++c)
 #pragma unroll
@@ -170,10 +170,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
         }
     __syncthreads();
     double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * a.Cout;
-    for (int ch = threadIdx.x; ch < a.Cout; ch += 256) {
+    for (int ch = threadIdx.x; ch < a.Cout; ch += blockDim.x) {
       float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * NCP * 32 + ch]; t2 += red[(w * 2 + 1) * NCP * 32 + ch]; }
+      for (int w = 0; w < NW; ++w) { t1 += red[(w * 2 + 0) * NCP * 32 + ch]; t2 += red[(w * 2 + 1) * NCP * 32 + ch]; }
       atomicAdd(dst + 2 * ch, (double)t1);
       atomicAdd(dst + 2 * ch + 1, (double)t2);
     }
@@ -181,9 +180,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Args a) {
 }
 
 // ---- host
-static size_t c1_lds(int ncp, int Kpad, int pt) {
+static size_t c1_lds(int ncp, int Kpad, int pt, int nw = 4) {
   const int cps = (Kpad * 2 + 16) / 16;
-  return (size_t)(((ncp * 32 * cps + 63) & ~63) + 8 * ((pt * 16 * cps + 63) & ~63)) * 16;
+  return (size_t)(((ncp * 32 * cps + 63) & ~63) + 2 * nw * ((pt * 16 * cps + 63) & ~63)) * 16;
 }
 static const size_t C1_LDS_MAX = 150 * 1024;
 
@@ -199,7 +198,9 @@ bool msl_conv1x1_eligible(const msl_op& op) {
 
 template <int NCP, bool STATS, int PT>
 static int c1_launch(const C1Args& a, hipStream_t s) {
-  const size_t lds = c1_lds(NCP, a.Kpad, PT);
+  // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
+  const int nw = (c1_lds(NCP, a.Kpad, PT, 4) * 3 > 160 * 1024 && c1_lds(NCP, a.Kpad, PT, 8) <= C1_LDS_MAX) ? 8 : 4;
+  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -209,9 +210,9 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   long per_cu = (160 * 1024) / (long)lds;  // workgroups that fit a CU's LDS
   if (per_cu > 6) per_cu = 6;
   if (per_cu < 1) per_cu = 1;
-  long blocks = (tiles + 3) / 4;
+  long blocks = (tiles + nw - 1) / nw;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
   MSL_CHECK_LAUNCH("conv1x1");
   return MSL_OK;
 }
