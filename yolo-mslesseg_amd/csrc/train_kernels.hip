@@ -19,6 +19,7 @@
 // same-address RETURNING atomics, ~150 ns each, 4x slower than the separate finalize launch; and summing the copies in
 // every BN_ACT workgroup — the 2C x slots fp64 loads outweigh the small layers' own traffic.)
 // =========================================================================================================
+typedef float f2_t __attribute__((ext_vector_type(2)));
 #define MSL_MAX_SLOTS 16
 // V = channels per thread: 8 (one 16-byte access of bf16) when the channel count and the views allow it, else 4
 template <bool F32, int MODE, int V>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
@@ -43,18 +44,25 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
     } else if (MODE == 2) {
 #pragma unroll
       for (int r = 0; r < V; ++r) s1[r] += va[r];
-    } else {  // a = dy, b = z
+    } else {  // a = dy, b = z.  Written on float pairs so that the compiler emits packed fp32 ops (v_pk_mul/add/fma_f32): the kernel is
+              // VALU-bound (two quarter-rate transcendentals per element), and packing cuts the remaining ops by a third
 #pragma unroll
-      for (int r = 0; r < V; ++r) {
-        const float zh = (vb[r] - mu[r]) * is[r];
-        float g = va[r];
+      for (int r = 0; r < V; r += 2) {
+        const f2_t z2 = {vb[r], vb[r + 1]}, d2 = {va[r], va[r + 1]};
+        const f2_t mu2 = {mu[r], mu[r + 1]}, is2 = {is[r], is[r + 1]};
+        const f2_t zh = (z2 - mu2) * is2;
+        f2_t g = d2;
         if (act) {
-          const float u = fmaf(ga[r], zh, be[r]);
-          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
-          g *= sg * (1.0f + u * (1.0f - sg));
+          const f2_t ga2 = {ga[r], ga[r + 1]}, be2 = {be[r], be[r + 1]};
+          const f2_t u = ga2 * zh + be2;
+          const f2_t t = u * -1.44269504088896f;
+          const f2_t den = (f2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+          const f2_t sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+          g = d2 * (sg * (u * (1.0f - sg) + 1.0f));
         }
-        s1[r] += g;
-        s2[r] = fmaf(g, zh, s2[r]);
+        s1[r] += g.x; s1[r + 1] += g.y;
+        const f2_t q = g * zh;
+        s2[r] += q.x; s2[r + 1] += q.y;
       }
     }
   };
@@ -279,15 +287,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
       const long p = p0 + (long)(k + u) * PL;
       if (p < M) {
 #pragma unroll
-        for (int r = 0; r < V; ++r) {
-          const float zh = (v[u][r] - mu[r]) * is[r];
-          float gg = g[u][r];
+        for (int r = 0; r < V; r += 2) {  // float pairs → packed fp32 ops (see chan_reduce_kernel)
+          const f2_t z2 = {v[u][r], v[u][r + 1]}, mu2 = {mu[r], mu[r + 1]}, is2 = {is[r], is[r + 1]}, ga2 = {ga[r], ga[r + 1]};
+          const f2_t zh = (z2 - mu2) * is2;
+          f2_t gg = {g[u][r], g[u][r + 1]};
           if (act) {
-            const float uu = fmaf(ga[r], zh, be[r]);
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-uu));
-            gg *= sg * (1.0f + uu * (1.0f - sg));
+            const f2_t be2 = {be[r], be[r + 1]};
+            const f2_t uu = ga2 * zh + be2;
+            const f2_t t = uu * -1.44269504088896f;
+            const f2_t den = (f2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+            const f2_t sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            gg = gg * (sg * (uu * (1.0f - sg) + 1.0f));
           }
-          v[u][r] = ga[r] * is[r] * (gg - k0[r] - zh * k2[r]);
+          const f2_t k02 = {k0[r], k0[r + 1]}, k22 = {k2[r], k2[r + 1]};
+          const f2_t o = ga2 * is2 * (gg - k02 - zh * k22);
+          v[u][r] = o.x; v[u][r + 1] = o.y;
         }
         stv<F32, V>(dz, p * dz_cs + dz_co + c, v[u]);
       }
