@@ -146,7 +146,7 @@ def predict_roofline(eng, imgs, out, args, value_per_gpu):
     ev[2].record(st_)
     torch.cuda.synchronize(imgs.device)
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-            "kernel": f"conv3x3_lds_kernel/conv_igemm_kernel<{args.dtype}> @ {d_name}", "launch_ms": round(d_ms, 4),
+            "kernel": f"conv3x3_pers_kernel/conv3x3_lds_kernel/conv_igemm_kernel<{args.dtype}> @ {d_name}", "launch_ms": round(d_ms, 4),
             "algorithmic_gflop_per_launch": round(d_flops / 1e9, 3), "algorithmic_hbm_gbs": round(d_bytes / (d_ms * 1e-3) / 1e9, 1),
             "hbm_frac": round(d_bytes / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "all_conv": {"tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4), "ms": round(conv_ms, 3),
@@ -239,6 +239,11 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             cv_ms, cv_fl = cv_ms + ms, cv_fl + fl
             one = I[7] == 1 and I[8] == 1 and I[20] == 0 and args.dtype == "bf16" and I[3] % 8 == 0 and I[6] % 8 == 0 and I[6] <= 256
             kn = "conv3x3_lds_kernel" if I[25] else ("conv1x1_kernel" if one else "conv_igemm_kernel")
+            if I[25]:  # same rule as msl_launch_conv3x3_lds: persistent weights-resident form for full 64-channel blocks over <= 2 whole chunks
+                chunk = 32 if args.dtype == "bf16" else 16
+                tiles = I[0] * ((I[5] + 31) // 32) * ((I[4] + 7) // 8)
+                if I[8] == 1 and I[24] == 4 and I[3] % chunk == 0 and I[3] // chunk <= 2 and tiles >= 1024 and I[23] not in (-8, -4):
+                    kn = "conv3x3_pers_kernel"
             mode = "input gradient, transposed-conv gather" if I[22] else ("input gradient" if tag == "bwd" else "forward")
             cands.append((ms, fl, f"{kn}<{args.dtype}> ({mode})", args.dtype, tag, it))
     cands.sort(key=lambda c: -c[0])

@@ -61,8 +61,10 @@ enum {
    *       divisible, (H,W) = gradient read, (Ho,Wo) = tensor produced, weights packed [Cin][(ky,kx,co)]), k may also be 2,
    *    25 weight layout: 0 = GEMM rows above (generic kernel); 1 = LDS image for the tiled 3x3 kernel (k=3, pad=1, stride 1|2,
    *       Cin % chunk == 0 with chunk = 32 bf16 / 16 fp32, Cout % 16 == 0):
-   *       w[cout_blk][chunk][tap=ky*3+kx][g 0..3][COB][16 bytes], element e of (.., g, col, .) = W[cout_blk*COB+col][chunk*CH*4+g*CH+e][ky][kx],
-   *       CH = 8 bf16 / 4 fp32, COB = 16*COT, and 24 = COT (4 if Cout%64==0, else 2 if Cout%32==0, else 1) */
+   *       w[cout_blk][chunk][tap=ky*3+kx][g 0..3][COB][16 bytes], element e of (.., g, col, .) = W[cout_blk*COB+ch(col)][chunk*CH*4+g*CH+e][ky][kx],
+   *       CH = 8 bf16 / 4 fp32, COB = 16*COT, and 24 = COT (4 if Cout%64==0, else 2 if Cout%32==0, else 1).  Row col = c*16 + 4*q + r
+   *       (MFMA tile c, accumulator lane group q, register r) carries channel ch(col) = q*4*COT + c*4 + r, so that a lane's 4*COT
+   *       outputs of one pixel are consecutive channels (16-byte stores; a pixel's four lanes write one whole line) */
   MSL_OP_CONV = 1,
   /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
    * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y

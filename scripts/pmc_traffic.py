@@ -35,15 +35,16 @@ def one_pass(counter, outdir):
 
 def main():
     out = Path("/tmp/pmc_traffic")
-    per_counter, replay = {}, None
+    per_counter, order = {}, None
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         bench, rows = one_pass(counter, out / counter)
         replay = bench["roofline"]["replay"]
         mine = [r for r in rows if r["Counter_Name"] == counter]
         mine.sort(key=lambda r: int(r["Dispatch_Id"]))
         # the replayed ops are the last dispatches of the process; an op may launch helper kernels (e.g. the partial-sum reduction after a
-        # weight-gradient kernel), so walk backwards and pick K dispatches of each record's own kernel
-        pos, found = len(mine), []
+        # weight-gradient kernel), so walk backwards and pick K dispatches of each record's own kernel.  The replay ORDER is by measured
+        # launch time and can differ between the two passes: results are keyed by (kernel label, launch shape), not by position.
+        pos, found = len(mine), {}
         for rp in reversed(replay):
             base = rp["kernel"].split("<")[0].split(" ")[0]
             g = []
@@ -53,12 +54,18 @@ def main():
                     g.append(mine[pos])
             if len(g) < K or len({(r["Kernel_Name"], r["Grid_Size"]) for r in g}) != 1:
                 sys.exit(f"{counter}: could not isolate {K} launches of {base}: {[(r['Dispatch_Id'], r['Kernel_Name'][:40], r['Grid_Size']) for r in g]}")
-            found.append((sum(float(r["Counter_Value"]) for r in g) / K * 1024.0, g[0]["Kernel_Name"], g[0]["Grid_Size"]))
-        per_counter[counter] = found[::-1]
+            key = (rp["kernel"], json.dumps(rp["launch_shape"], sort_keys=True))
+            found[key] = (sum(float(r["Counter_Value"]) for r in g) / K * 1024.0, g[0]["Kernel_Name"], g[0]["Grid_Size"], rp)
+        per_counter[counter] = found
+        order = order or list(found)[::-1]
     records = []
-    for i, rp in enumerate(replay):
-        fetch, name, grid = per_counter["FETCH_SIZE"][i]
-        write = per_counter["WRITE_SIZE"][i][0]
+    for key in order:
+        if key not in per_counter["WRITE_SIZE"]:
+            continue  # replayed in one pass only (family representatives can differ): no complete figure
+        fetch, name, grid, rp = per_counter["FETCH_SIZE"][key]
+        write, name_w, _, _ = per_counter["WRITE_SIZE"][key]
+        if name != name_w:
+            sys.exit(f"passes disagree on the kernel of {key}: {name} vs {name_w}")
         records.append({"kernel": rp["kernel"], "launch_shape": rp["launch_shape"], "traffic_bytes_per_launch": round(2.0 * fetch + write),
                         "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write), "dispatch_kernel_name": name, "grid_size": grid,
                         "note": "rocprofv3 --pmc, two passes, mean of 5 replayed launches; FETCH_SIZE doubled (gfx950), both counters KiB -> bytes"})

@@ -115,9 +115,12 @@ LDS3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pers", [0, 1])
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 @pytest.mark.parametrize("case", LDS3_CASES)
-def test_conv3x3_lds(case, dtype):
+def test_conv3x3_lds(case, dtype, pers):
+    """pers=1 asks for the persistent weights-resident kernel (i[23] = -9; taken when stride 1 and the weight block fits LDS, else the
+    tile-per-workgroup kernel runs as with pers=0 / i[23] = -8)."""
     N, H, W, Cin, Cout, s, x_cs, x_co, y_cs, y_co, act, res, out_f32 = case
     g = torch.Generator().manual_seed(hash(case) % (2**31))
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
@@ -137,7 +140,8 @@ def test_conv3x3_lds(case, dtype):
     xd, rd, yd = xbuf.to(DEV), rbuf.to(DEV), ybuf.to(DEV)
     op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), rd.data_ptr() if res else 0, yd.data_ptr()),
                         i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co,
-                           14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"], 24: m["cot"], 25: 1})
+                           14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"], 23: -9 if pers else -8,
+                           24: m["cot"], 25: 1})
     hiplib.launch(op, _stream())
     torch.cuda.synchronize()
     out = yd.cpu()
@@ -540,7 +544,8 @@ def test_attention_backward_bf16(hw):
 
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
-@pytest.mark.parametrize("case", [(2, 16, 40, 64, 64, 1), (1, 21, 35, 32, 32, 2), (3, 9, 33, 32, 16, 1), (1, 20, 20, 128, 128, 1)])
+@pytest.mark.parametrize("case", [(2, 16, 40, 64, 64, 1), (1, 21, 35, 32, 32, 2), (3, 9, 33, 32, 16, 1), (1, 20, 20, 128, 128, 1),
+                                  (11, 160, 150, 64, 64, 1), (36, 80, 90, 32, 16, 1)])  # the last two: >= 1024 tiles → persistent kernel
 def test_conv3x3_lds_batchnorm_statistics_epilogue(case, dtype):
     """LDS-tiled 3x3 conv with p[5]: (sum z, sum z^2) per channel of the values it stores, in slot-replicated fp64 accumulators."""
     N, H, W, Cin, Cout, s = case

@@ -160,8 +160,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float t1 = s1[c][m][r], t2 = s2[c][m][r];
-#pragma unroll
-          for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
+          t1 = row16_sum(t1); t2 = row16_sum(t2);
           if (li == 0) {
             const int ch = c * 32 + 8 * g + 4 * m + r;
             red[(wave * 2 + 0) * NCP * 32 + ch] = t1;

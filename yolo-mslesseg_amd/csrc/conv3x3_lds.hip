@@ -9,12 +9,17 @@
 //   * stages that chunk's weight slab (9 taps x COB output channels) with contiguous LDS-DMA copies of a host-packed
 //     LDS image;
 //   * runs 9 taps x (PT pixel tiles x COT channel tiles) MFMAs per wave from ds_read_b128 fragment reads.
-// LDS image: [k-group g (4)][slot][16 B] planes, every plane a multiple of 256 B.  The 16 lanes of each ds_read_b128
-// lane group then read 16 consecutive 16-byte slots of one plane (B: 16 consecutive pixels of a row; A: 16 consecutive
-// output channels) or two such half-runs in different planes that land on disjoint bank quarters: conflict-free for any
-// tile alignment.  Stride 2 splits the halo columns by parity so that 16 consecutive OUTPUT pixels are again contiguous.
+// LDS images.  Weights: [tap][k-group g (4)][COB][16 B] — the 16 lanes of a ds_read_b128 lane group read 16 consecutive 16-byte slots.
+// Input halo: pixel-major rows of 4 halo pixels x 4 k-groups (256 B), pixel s's k-group g at 16-byte position
+// (s&3)*4 + ((g + (s>>2)) & 3) of row s>>2.  The rotation by the row index makes any 16 consecutive pixels of one k-group land on 16
+// different 16-byte bank columns (conflict-free for every tap shift), while the LDS-DMA that fills a row reads each pixel's four
+// k-groups — 64 contiguous bytes in HBM — with four neighbouring lanes: one gather instruction touches 16 pixels' lines, where the
+// earlier plane-per-k-group image touched 64 lines for 16 useful bytes each (the texture-address path was the bound).
+// Stride 2 splits the halo columns by parity so that 16 consecutive OUTPUT pixels are again consecutive halo slots.
 //
 // GEMM orientation, fragment k-permutation (fp32) and epilogue are those of conv_igemm.hip.
+#include <type_traits>
+
 #include "msl_common.h"
 
 __device__ __attribute__((aligned(16))) unsigned msl_zero_page[4];  // source of padding for LDS-DMA gathers
@@ -38,8 +43,57 @@ struct Tile3 {
   static constexpr int ROWP = 34;                                  // slots per halo row (s1) / per parity row (s2)
   static constexpr int ROWS = S == 1 ? TH + 2 : 2 * TH + 1;        // halo rows
   static constexpr int SLOTS = S == 1 ? ROWS * ROWP : ROWS * 2 * ROWP;
-  static constexpr int PS = (SLOTS + 63) / 64 * 64;                // slots per plane (multiple of 64: whole LDS-DMA pieces)
+  static constexpr int PIECES = (SLOTS + 15) / 16;                 // LDS-DMA pieces of 16 halo pixels x 64 B (1 KiB)
 };
+
+// byte address of halo slot s, k-group g in the rotated pixel-major image (see the header)
+__device__ __forceinline__ int halo_byte(int s, int g) { return ((s >> 2) << 8) + ((((s & 3) << 2) + ((g + (s >> 2)) & 3)) << 4); }
+
+// Epilogue of one pixel for a lane: the lane's 4*COT accumulator values are CONSECUTIVE output channels starting at co0 (weight rows are
+// packed in that order, include/mslesseg_hip.h op.i[25]): bias, optional statistics of the stored values, SiLU, residual, 16-byte stores.
+template <bool F32, int COT>
+__device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co0, const f32x4 (&accp)[COT], float (&s1)[COT][4], float (&s2)[COT][4]) {
+  float v[COT * 4];
+#pragma unroll
+  for (int c = 0; c < COT; ++c) {
+    const float4 b4 = *(const float4*)(a.bias + co0 + c * 4);
+    v[c * 4 + 0] = accp[c][0] + b4.x; v[c * 4 + 1] = accp[c][1] + b4.y; v[c * 4 + 2] = accp[c][2] + b4.z; v[c * 4 + 3] = accp[c][3] + b4.w;
+  }
+  if (a.acc) {
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float vr = F32 ? v[c * 4 + r] : bf16_bits_to_f32(f32_to_bf16_bits(v[c * 4 + r]));  // statistics of the values actually stored
+        s1[c][r] += vr;
+        s2[c][r] = fmaf(vr, vr, s2[c][r]);
+      }
+  }
+  if (a.act == 1) {
+#pragma unroll
+    for (int i = 0; i < COT * 4; ++i) v[i] = silu_f(v[i]);
+  }
+  const long ri = pix * a.res_cs + a.res_co + co0, oi = pix * a.y_cs + a.y_co + co0;
+  if constexpr (COT == 1) {
+    float (&v4)[4] = v;
+    if (a.res) { float rv[4]; ld4<F32>(a.res, ri, rv); for (int r = 0; r < 4; ++r) v4[r] += rv[r]; }
+    if (a.out_f32) st4<true>(a.y, oi, v4); else st4<F32>(a.y, oi, v4);
+  } else {
+#pragma unroll
+    for (int h = 0; h < COT / 2; ++h) {  // runs of 8 channels
+      float v8[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v8[r] = v[h * 8 + r];
+      if (a.res) {
+        float rv[8];
+        ldv<F32, 8>(a.res, ri + h * 8, rv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v8[r] += rv[r];
+      }
+      if (a.out_f32) stv<true, 8>(a.y, oi + h * 8, v8); else stv<F32, 8>(a.y, oi + h * 8, v8);
+    }
+  }
+}
 
 template <bool F32, int S, int RW, int COT>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
@@ -48,7 +102,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   constexpr int CHUNK = 64 / ES;          // channels per chunk (4 groups x 16 B)
   constexpr int COB = COT * 16;
   constexpr int PT = 2 * RW;              // pixel tiles per wave: RW rows x 2 column halves
-  constexpr int IN_BYTES = 4 * T::PS * 16;
+  constexpr int IN_BYTES = T::PIECES * 1024;
   constexpr int W_BYTES = 9 * 4 * COB * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_in = smem;
@@ -56,7 +110,13 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lp = lane & 15, g = lane >> 4;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give XCD x the x-th contiguous eighth
+  // of the tiles so that neighbouring tiles — which share halo rows and columns — hit the same L2 instead of each pulling the halo from HBM.
   int bid = blockIdx.x;
+  {
+    const int per = gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
   const int txi = bid % a.tiles_x; bid /= a.tiles_x;
   const int tyi = bid % a.tiles_y;
   const int n = bid / a.tiles_y;
@@ -74,35 +134,38 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   const int nchunks = (a.Cin + CHUNK - 1) / CHUNK;  // whole chunks, or one partial chunk whose missing k-group planes are staged as zeros
   const char* wblk = a.w + (long)cob * nchunks * W_BYTES;
 
-  // ---- per-lane staging sources, computed once: piece j of this wave covers plane gq, slots sl..sl+63
-  constexpr int IN_PIECES = 4 * T::PS / 64;
+  // ---- per-lane staging sources, computed once: piece pc covers halo slots 16*pc .. 16*pc+15; lane = (row of 4 pixels, 16-byte position)
+  constexpr int IN_PIECES = T::PIECES;
   constexpr int IN_PER_WAVE = (IN_PIECES + 3) / 4;
   constexpr int W_PIECES = W_BYTES / 1024;
   int in_off[IN_PER_WAVE];  // byte offset inside the image view of this lane's 16 bytes (chunk 0), or -1 → zero page
+  {
+    const int row4 = lane >> 4, pos = lane & 15;
+    const int gq = ((pos & 3) - row4) & 3;  // k-group stored at this position (rotation by the row index; 4*pc is a multiple of 4)
 #pragma unroll
-  for (int j = 0; j < IN_PER_WAVE; ++j) {
-    const int pc = wave + 4 * j;
-    const int gq = pc / (T::PS / 64);
-    const int sl = (pc - gq * (T::PS / 64)) * 64 + lane;
-    int r, c;
-    if constexpr (S == 1) {
-      r = sl / T::ROWP;
-      c = sl - r * T::ROWP;
-    } else {
-      const int rr = sl / T::ROWP;  // = r*2 + parity
-      const int pos = sl - rr * T::ROWP;
-      r = rr >> 1;
-      c = pos * 2 + (rr & 1);
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      const int sl = pc * 16 + row4 * 4 + (pos >> 2);
+      int r, c;
+      if constexpr (S == 1) {
+        r = sl / T::ROWP;
+        c = sl - r * T::ROWP;
+      } else {
+        const int rr = sl / T::ROWP;  // = r*2 + parity
+        const int ps = sl - rr * T::ROWP;
+        r = rr >> 1;
+        c = ps * 2 + (rr & 1);
+      }
+      const int iy = iy0 + r, ix = ix0 + c;
+      const bool ok = pc < IN_PIECES && sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && gq * (CHUNK / 4) < a.Cin;
+      in_off[j] = ok ? ((iy * a.W + ix) * a.x_cs) * ES + gq * 16 : -1;
     }
-    const int iy = iy0 + r, ix = ix0 + c;
-    const bool ok = pc < IN_PIECES && sl < T::SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && gq * (CHUNK / 4) < a.Cin;
-    in_off[j] = ok ? ((iy * a.W + ix) * a.x_cs) * ES + gq * 16 : -1;
   }
   const char* wlane = wblk + wave * 1024 + lane * 16;
 
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();  // previous chunk's fragment reads are done before the tile is overwritten
-    // ---- input halo: 4 planes x PS slots, 64 slots (1 KiB) per LDS-DMA piece, pieces dealt round-robin to the 4 waves
+    // ---- input halo: 16 pixels x 4 k-groups (1 KiB) per LDS-DMA piece, pieces dealt round-robin to the 4 waves
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
       const int pc = wave + 4 * j;
@@ -131,11 +194,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
         const int row = wave * RW + (p >> 1);     // output row inside the tile
-        const int col = (p & 1) * 16 + lp;        // output col inside the tile
+        const int col = (p & 1) * 16;             // first output col of the pixel tile (this lane: + lp)
         int slot;
         if constexpr (S == 1) slot = (row + ty) * T::ROWP + col + tx;
         else slot = ((2 * row + ty) * 2 + (tx & 1)) * T::ROWP + col + (tx >> 1);
-        B[p] = *(const uint4*)(s_in + (g * T::PS + slot) * 16);
+        B[p] = *(const uint4*)(s_in + halo_byte(slot + lp, g));
       }
     };
     fetch(0, av[0], bv[0]);
@@ -169,34 +232,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
     if (oy >= a.Ho || ox >= a.Wo) continue;
     const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+    f32x4 accp[COT];
 #pragma unroll
-    for (int c = 0; c < COT; ++c) {
-      const int co0 = cob * COB + c * 16 + g * 4;
-      if (co0 >= a.Cout) continue;
-      float v[4];
-      const float4 b4 = *(const float4*)(a.bias + co0);
-      v[0] = acc[c][p][0] + b4.x; v[1] = acc[c][p][1] + b4.y; v[2] = acc[c][p][2] + b4.z; v[3] = acc[c][p][3] + b4.w;
-      if (a.acc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float vr = F32 ? v[r] : bf16_bits_to_f32(f32_to_bf16_bits(v[r]));  // statistics of the values actually stored
-          s1[c][r] += vr;
-          s2[c][r] = fmaf(vr, vr, s2[c][r]);
-        }
-      }
-      if (a.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-      }
-      if (a.res) {
-        float rv[4];
-        ld4<F32>(a.res, pix * a.res_cs + a.res_co + co0, rv);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-      }
-      const long oi = pix * a.y_cs + a.y_co + co0;
-      if (a.out_f32) st4<true>(a.y, oi, v); else st4<F32>(a.y, oi, v);
-    }
+    for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
+    store_pixel<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2);
   }
   if (a.acc) {  // block-uniform: fold over the 16 pixel lanes, over the 4 waves (LDS), then one fp64 atomic per channel and statistic
     __syncthreads();  // every wave is done with the staged tiles
@@ -206,11 +245,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t1 = s1[c][r], t2 = s2[c][r];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
+        t1 = row16_sum(t1); t2 = row16_sum(t2);
         if (lp == 0) {
-          red[(wave * 2 + 0) * COB + c * 16 + g * 4 + r] = t1;
-          red[(wave * 2 + 1) * COB + c * 16 + g * 4 + r] = t2;
+          red[(wave * 2 + 0) * COB + g * (4 * COT) + c * 4 + r] = t1;
+          red[(wave * 2 + 1) * COB + g * (4 * COT) + c * 4 + r] = t2;
         }
       }
     __syncthreads();
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
 template <bool F32, int S, int RW, int COT>
 static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<S, RW>;
-  constexpr int LDS = 4 * T::PS * 16 + 9 * 4 * COT * 16 * 16;
+  constexpr int LDS = T::PIECES * 1024 + 9 * 4 * COT * 16 * 16;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -237,6 +275,247 @@ static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x), (unsigned)cout_blocks);
   hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT>), grid, dim3(256), LDS, s, a);
   MSL_CHECK_LAUNCH("conv3x3_lds");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent, weights-resident form for stride 1 when the whole weight block (all input-channel chunks) fits LDS beside four halo
+// buffers (Cin <= 2 chunks; e.g. 64->64: 72 KiB of weights + 4 x 22 KiB = exactly the 160 KiB of a CU).
+//
+// Why: in the kernel above a workgroup's life is a serial chain (index set-up → stage → MFMA → stage → MFMA → epilogue) that only a
+// second resident workgroup overlaps, and 60 % of every staging step is the weight slab, fetched again by each of the 12 800 tiles.
+// Here one 8-wave workgroup per CU stages the weights once and walks over tiles.  Its two 4-wave groups own different tiles and
+// separate 2-deep halo rings; the unit of work is (tile, chunk).  In each step — one workgroup barrier — a group issues the LDS-DMA of
+// its next unit, then runs the MFMAs of the current one; the second group runs one unit behind (two-chunk case), so the VALU-heavy
+// epilogue of one group (stores, SiLU, statistics: about as many issue cycles as the tile's MFMAs) overlaps the other group's MFMAs
+// on the same SIMDs.  BatchNorm statistics stay in registers over all tiles of a wave and are folded once at the end of the kernel.
+template <bool F32, int COT, int NCH>
+__global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int total_tiles, int steps) {
+  using T = Tile3<1, 2>;
+  constexpr int ES = F32 ? 4 : 2;
+  constexpr int CHUNK = 64 / ES;
+  constexpr int COB = COT * 16;
+  constexpr int PT = 4;
+  constexpr int IN_BYTES = T::PIECES * 1024;
+  constexpr int W_BYTES = 9 * 4 * COB * 16;
+  constexpr int DELAY = NCH == 2 ? 1 : 0;
+  constexpr int IN_PER_WAVE = (T::PIECES + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_w = smem;                     // [chunk][tap][g][COB][16 B]
+  unsigned char* s_ring = smem + NCH * W_BYTES;  // [group 2][buffer 2][IN_BYTES]
+
+  const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int lp = lane & 15, g = lane >> 4;
+  const int cob = blockIdx.y;
+  // tile sequence of this wave group.  With a grid that is a multiple of 8, XCD x = blockIdx.x % 8 walks the x-th contiguous eighth of the
+  // tiles (neighbouring tiles share halos: same L2); its 2 * gridDim.x / 8 groups stride through that range.
+  int G2 = gridDim.x * 2, gi = blockIdx.x * 2 + grp, tbase = 0, tcnt = total_tiles;
+  if ((gridDim.x & 7) == 0) {
+    const int per = (total_tiles + 7) >> 3;
+    tbase = (blockIdx.x & 7) * per;
+    tcnt = min(per, total_tiles - tbase);
+    G2 = gridDim.x >> 2;
+    gi = (blockIdx.x >> 3) * 2 + grp;
+  }
+  const int my_units = gi < tcnt ? ((tcnt - gi + G2 - 1) / G2) * NCH : 0;
+
+  // ---- weights of this output-channel block, all chunks: staged once
+  {
+    const char* wsrc = a.w + (long)cob * NCH * W_BYTES + lane * 16;
+    for (int pc = wave8; pc < NCH * W_BYTES / 1024; pc += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + pc * 1024),
+                                       (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
+  }
+
+  // ---- tile-independent part of the staging gather: halo (row, col) and byte offset of this lane's 16 bytes for each of its pieces
+  int rc[IN_PER_WAVE];
+  const int gq16 = ((((lane & 15) & 3) - (lane >> 4)) & 3) * 16;  // byte offset of the k-group this lane stages
+  {
+    const int row4 = lane >> 4, pos = lane & 15;
+    const int gq = gq16 >> 4;
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      const int sl = pc * 16 + row4 * 4 + (pos >> 2);
+      const int r = sl / T::ROWP, c = sl - r * T::ROWP;
+      const bool ok = pc < T::PIECES && sl < T::SLOTS && gq * (CHUNK / 4) < a.Cin;
+      rc[j] = ok ? (r << 8 | c) : -1;
+    }
+  }
+  // ---- fragment addresses (chunk- and tile-independent)
+  unsigned char* ring_g = s_ring + grp * 2 * IN_BYTES;
+  // rows wave*2 .. wave*2+3 of the halo x 3 column shifts; the second 16-pixel half of a row is +1024 B (16 slots = 4 image rows of
+  // 256 B, rotation unchanged), folded into the ds_read offset
+  int baddr[4][3];
+#pragma unroll
+  for (int hr = 0; hr < 4; ++hr)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) baddr[hr][tx] = halo_byte((wave * 2 + hr) * T::ROWP + tx + lp, g);
+  const int aoff = (g * COB + lp) * 16;
+
+  f32x4 acc[COT][PT];
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s1[COT][4], s2[COT][4];
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  // staging state: the tile whose units are being staged
+  const char* st_img = a.x;
+  int st_off[IN_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < IN_PER_WAVE; ++j) st_off[j] = -1;
+
+  auto stage = [&](int un, unsigned char* dst) __attribute__((always_inline)) {  // issue the LDS-DMA of unit `un` of this group into `dst`
+    const int cc = NCH == 2 ? (un & 1) : 0;
+    if (cc == 0) {  // first chunk of a new tile: gather offsets
+      int t = tbase + gi + (un / NCH) * G2;
+      const int n = t / tiles_per_img;
+      t -= n * tiles_per_img;
+      const int tyi = t / a.tiles_x, txi = t - tyi * a.tiles_x;
+      const int iy0 = tyi * T::TH - 1, ix0 = txi * T::TW - 1;
+      st_img = a.x + ((long)n * a.H * a.W * a.x_cs + a.x_co) * ES;
+      const int org = ((iy0 * a.W + ix0) * a.x_cs) * ES;
+#pragma unroll
+      for (int j = 0; j < IN_PER_WAVE; ++j) {
+        const int iy = iy0 + (rc[j] >> 8), ix = ix0 + (rc[j] & 255);
+        const bool ok = rc[j] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        st_off[j] = ok ? org + (((rc[j] >> 8) * a.W + (rc[j] & 255)) * a.x_cs) * ES + gq16 : -1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      if (pc < T::PIECES) {
+        const char* src = st_off[j] >= 0 ? st_img + st_off[j] + cc * (CHUNK * ES) : (const char*)msl_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  auto compute = [&](int cc, const unsigned char* buf) __attribute__((always_inline)) {  // 9 taps of one chunk; fragments of tap t+1 fetched while tap t's MFMAs issue
+    const unsigned char* wa = s_w + cc * W_BYTES + aoff;
+    uint4 av[2][COT], bv[2][PT];
+    auto fetch = [&](int t, uint4 (&A)[COT], uint4 (&B)[PT]) {
+#pragma unroll
+      for (int c = 0; c < COT; ++c) A[c] = *(const uint4*)(wa + (t * 4 * COB + c * 16) * 16);
+#pragma unroll
+      for (int p = 0; p < PT; ++p) B[p] = *(const uint4*)(buf + baddr[(p >> 1) + t / 3][t % 3] + (p & 1) * 1024);
+    };
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) fetch(t + 1, av[(t + 1) & 1], bv[(t + 1) & 1]);
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          if constexpr (F32) {
+            f32x4 af = __builtin_bit_cast(f32x4, av[t & 1][c]), bf = __builtin_bit_cast(f32x4, bv[t & 1][p]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][p], 0, 0, 0);
+          } else {
+            acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[t & 1][c]), __builtin_bit_cast(bf16x8, bv[t & 1][p]),
+                                                                acc[c][p], 0, 0, 0);
+          }
+        }
+    }
+  };
+
+  auto epilogue = [&](int k) __attribute__((always_inline)) {  // tile k of this group: bias + SiLU (+ residual) → store; statistics into registers; accumulators reset
+    int t = tbase + gi + k * G2;
+    const int n = t / tiles_per_img;
+    t -= n * tiles_per_img;
+    const int tyi = t / a.tiles_x, txi = t - tyi * a.tiles_x;
+    const int oy0 = tyi * T::TH, ox0 = txi * T::TW;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int oy = oy0 + wave * 2 + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
+      if (oy < a.Ho && ox < a.Wo) {
+        const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+        f32x4 accp[COT];
+#pragma unroll
+        for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
+        store_pixel<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2);
+      }
+#pragma unroll
+      for (int c = 0; c < COT; ++c) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  // ---- steps: at step s group 0 computes unit s, group 1 unit s - DELAY; buffer parity = s & 1 for both
+  auto step = [&](int sidx, auto par) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's pieces of the current unit have landed, and everyone is done reading the buffer refilled next
+    const int u = sidx - DELAY * grp, un = u + 1;
+    if (un >= 0 && un < my_units) stage(un, ring_g + (PAR ^ 1) * IN_BYTES);
+    if (u >= 0 && u < my_units) {
+      const int cc = NCH == 2 ? (u & 1) : 0;
+      compute(cc, ring_g + PAR * IN_BYTES);
+      if (cc == NCH - 1) epilogue(u / NCH);
+    }
+  };
+  step(-1, std::integral_constant<int, 1>{});
+  for (int sidx = 0; sidx < steps + DELAY; sidx += 2) {
+    step(sidx, std::integral_constant<int, 0>{});
+    step(sidx + 1, std::integral_constant<int, 1>{});
+  }
+
+  if (a.acc) {  // fold the statistics: 16 pixel lanes (DPP), the 8 waves (LDS), then one fp64 atomic per channel and statistic
+    __syncthreads();
+    float* red = (float*)s_ring;  // [8 waves][2][COB]
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = row16_sum(s1[c][r]), t2 = row16_sum(s2[c][r]);
+        if (lp == 0) {
+          red[(wave8 * 2 + 0) * COB + g * (4 * COT) + c * 4 + r] = t1;
+          red[(wave8 * 2 + 1) * COB + g * (4 * COT) + c * 4 + r] = t2;
+        }
+      }
+    __syncthreads();
+    double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * a.Cout;
+    for (int i = threadIdx.x; i < 2 * COB; i += 512) {
+      const int st = i / COB, ch = i - st * COB;
+      const int co = cob * COB + ch;
+      if (co < a.Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[(w * 2 + st) * COB + ch];
+        atomicAdd(dst + 2 * co + st, (double)t);
+      }
+    }
+  }
+}
+
+template <bool F32, int COT, int NCH>
+static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
+  using T = Tile3<1, 2>;
+  constexpr int LDS = NCH * 9 * 4 * COT * 16 * 16 + 4 * T::PIECES * 1024;
+  static_assert(LDS <= 160 * 1024, "conv3x3_pers: LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const long tiles = (long)a.N * a.tiles_y * a.tiles_x;
+  long wgs = (tiles + 1) / 2;
+  if (wgs > 256) wgs = 256;
+  if (wgs >= 8) wgs &= ~7L;  // multiple of 8: the XCD-aware tile order
+  long busiest = (tiles + 2 * wgs - 1) / (2 * wgs);  // tiles of the busiest wave group
+  if ((wgs & 7) == 0) { const long per = (tiles + 7) / 8, g2 = wgs / 4; busiest = (per + g2 - 1) / g2; }
+  const int steps = (int)busiest * NCH;
+  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
+  MSL_CHECK_LAUNCH("conv3x3_pers");
   return MSL_OK;
 }
 
@@ -257,16 +536,38 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho == (a.H + 2 - 3) / stride + 1 && a.Wo == (a.W + 2 - 3) / stride + 1, "conv3x3_lds: bad dims");
   MSL_REQUIRE(a.Cin > 0 && a.Cin % v == 0 && (a.Cin % chunk == 0 || a.Cin < chunk) && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs,
               "conv3x3_lds: Cin must be a multiple of %d, or a multiple of %d below it", chunk, v);
-  MSL_REQUIRE(a.Cout % 16 == 0 && a.y_cs % 4 == 0 && a.y_co % 4 == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: Cout must be a multiple of 16");
-  if (a.res) MSL_REQUIRE(a.res_cs % 4 == 0 && a.res_co % 4 == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
   const int cot = op.i[24];  // channel tiles per workgroup = how the host packed the weight image (4 for Cout % 64 == 0, else 2 or 1)
   MSL_REQUIRE((cot == 4 || cot == 2 || cot == 1) && a.Cout % (16 * cot) == 0, "conv3x3_lds: weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
+  const int oal = cot == 1 ? 4 : 8;  // a lane stores runs of 4*COT consecutive channels with 8- / 16-byte accesses
+  MSL_REQUIRE(a.Cout % 16 == 0 && a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: output view must be %d-channel aligned", oal);
+  if (a.res) MSL_REQUIRE(a.res_cs % oal == 0 && a.res_co % oal == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
   const int cout_blocks = a.Cout / (16 * cot);
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
   const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : 1;  // i[23]=-4 opts into the 16x32 tile (measured slower: kept for experiments)
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;
+  // persistent weights-resident form: stride 1, at most two input-channel chunks, weight block + 4 halo buffers within 160 KiB, and
+  // enough tiles for every CU's two wave groups (i[23] == -8 forces the tile-per-workgroup kernel, -9 the persistent one: A/B measurements and tests)
+  {
+    const int nch = (a.Cin + chunk - 1) / chunk;
+    const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
+    const bool fits = nch * 9 * 4 * cot * 256 + 4 * Tile3<1, 2>::PIECES * 1024 <= 160 * 1024;
+    // measured per layer (batch 128): ahead for full 64-channel blocks over whole chunks (64->64 @160²: 0.31 vs 0.35 ms with the statistics
+    // epilogue), behind for narrow blocks / partial chunks, where a unit holds too few MFMAs to pay for its barrier
+    const bool pays = cot == 4 && a.Cin % chunk == 0 && tiles >= 1024;
+    if (stride == 1 && rw == 2 && nch <= 2 && fits && (pays || op.i[23] == -9) && op.i[23] != -8) {
+#define L3P(F, NCH_)                                                       \
+  do {                                                                     \
+    if (cot == 4) return launch3p<F, 4, NCH_>(a, cout_blocks, s);          \
+    if (cot == 2) return launch3p<F, 2, NCH_>(a, cout_blocks, s);          \
+    return launch3p<F, 1, NCH_>(a, cout_blocks, s);                        \
+  } while (0)
+      if (f32) { if (nch == 2) L3P(true, 2); else L3P(true, 1); }
+      else     { if (nch == 2) L3P(false, 2); else L3P(false, 1); }
+#undef L3P
+    }
+  }
 #define L3(F, S_, RW_)                                                   \
   do {                                                                   \
     if (cot == 4) return launch3<F, S_, RW_, 4>(a, cout_blocks, s);      \

@@ -114,6 +114,18 @@ __device__ __forceinline__ void stv(void* p, long i, const float (&v)[V]) {
 }
 
 
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: xor-1 / xor-2 quad permutes, then half-row and row mirrors
+// — the same pairing, hence the same bits, as a __shfl_xor butterfly with offsets 1,2,4,8, but 4 VALU DPP adds instead of 4 ds_bpermute trips.
+__device__ __forceinline__ float row16_sum(float v) {
+#define MSL_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  MSL_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+  MSL_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+  MSL_DPP_ADD(0x141);  // row_half_mirror
+  MSL_DPP_ADD(0x140);  // row_mirror
+#undef MSL_DPP_ADD
+  return v;
+}
+
 // SiLU = x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each): 5 VALU instead of the ~15 of an IEEE division.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 

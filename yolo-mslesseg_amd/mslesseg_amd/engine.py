@@ -65,8 +65,17 @@ def lds3x3_eligible(cin: int, cout: int, k: int, dtype: int) -> bool:
     return k == 3 and cout % 16 == 0 and (cin % chunk == 0 or (cin < chunk and cin % (chunk // 4) == 0))
 
 
+def lds_col_perm(cot: int) -> torch.Tensor:
+    """Output channel (inside its block of 16*cot) held by row `col` of the LDS weight image.  Row col = c*16 + 4*g + r of MFMA tile c
+    lands in lane group g, register r of the accumulator; giving it channel g*4*cot + c*4 + r makes the 4*cot values a lane holds for
+    one pixel CONSECUTIVE channels, so the epilogue stores them with 16-byte accesses and a pixel's four lanes write one full line."""
+    col = torch.arange(16 * cot)
+    c, g, r = col // 16, (col % 16) // 4, col % 4
+    return g * (4 * cot) + c * 4 + r
+
+
 def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
-    """[Cout,Cin,3,3] → the LDS image of conv3x3_lds.hip: [cout_blk][chunk][tap][g][COB][CH] (include/mslesseg_hip.h)."""
+    """[Cout,Cin,3,3] → the LDS image of conv3x3_lds.hip: [cout_blk][chunk][tap][g][COB rows, lds_col_perm order][CH] (include/mslesseg_hip.h)."""
     cout, cin, _, _ = w.shape
     ch = 4 if dtype == MSL_F32 else 8
     chunk = 4 * ch
@@ -78,7 +87,7 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
         wp = torch.zeros(cout, (cin + chunk - 1) // chunk * chunk, 3, 3, dtype=w.dtype)
         wp[:, :cin] = w
         w = wp
-    wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)   # [blk, col, cc, g, e, ky, kx]
+    wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot)]   # [blk, col, cc, g, e, ky, kx]
     img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
     return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
 

@@ -192,7 +192,8 @@ def _lds_image_idx(idx4: torch.Tensor, dtype: int):
         padded = torch.full((cout, (cin + chunk - 1) // chunk * chunk, 3, 3), -1, dtype=idx4.dtype)
         padded[:, :cin] = idx4
         idx4 = padded
-    v = idx4.reshape(cout // cob, cob, idx4.shape[1] // chunk, 4, ch, 3, 3).permute(0, 2, 5, 6, 3, 1, 4).contiguous()
+    from .engine import lds_col_perm
+    v = idx4.reshape(cout // cob, cob, idx4.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot)].permute(0, 2, 5, 6, 3, 1, 4).contiguous()
     return v.reshape(-1).to(torch.int32), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
 
 
