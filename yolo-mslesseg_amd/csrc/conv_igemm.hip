@@ -29,6 +29,7 @@ struct ConvArgs {
   int N, H, W, Cin, Ho, Wo, Cout, k, stride, pad;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int K, Kpad, act, out_f32, store_mode, Cout_pad, dgrad;
+  int perm;  // 1: weight row (c*16 + 4q + r) of a block carries channel q*4*COT + c*4 + r → a lane's outputs of one pixel are consecutive channels
   int kw, lat_a, lat_b, full_h, full_w;  // kernel width (taps per row); store_mode 2: output pixel (Y,X) → (2Y+lat_a, 2X+lat_b) of a full_h x full_w image
 };
 
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lp = lane & 15, g = lane >> 4;
   const long M = (long)a.N * a.Ho * a.Wo;
-  const long pbase = ((long)blockIdx.x * 4 + wave) * (PT * 16);
+  const long pbase = ((long)xcd_block(blockIdx.x, gridDim.x) * 4 + wave) * (PT * 16);  // XCD-aware: stencil taps re-read neighbouring rows
   if (pbase >= M) return;  // whole wave out of range (wave-uniform)
   const int cobase = blockIdx.y * (COT * 16);
   const int HoWo = a.Ho * a.Wo;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const char* wrow[COT];
 #pragma unroll
-  for (int c = 0; c < COT; ++c) wrow[c] = a.w + ((long)(cobase + c * 16 + lp) * a.Kpad + g * CH) * ES;
+  for (int c = 0; c < COT; ++c) wrow[c] = a.w + ((long)(cobase + (a.perm ? (lp >> 2) * (4 * COT) + c * 4 + (lp & 3) : c * 16 + lp)) * a.Kpad + g * CH) * ES;
 
   // this lane's position on the K axis: (ty,tx,ci) of its 16-byte chunk
   int kk = g * CH;
@@ -132,6 +133,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       ox = r - oy * a.Wo;
     }
     if (a.store_mode == 2) opix = ((long)n * a.full_h + (2 * oy + a.lat_a)) * a.full_w + (2 * ox + a.lat_b);  // sub-lattice of the full image
+    if constexpr (COT >= 2) {
+      if (a.perm) {  // whole blocks, 8-aligned views: this lane holds channels co0 .. co0 + 4*COT - 1 of the pixel → 16-byte accesses, full lines per pixel
+        const int co0 = cobase + g * (4 * COT);
+        float v[COT * 4];
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+          const float4 b4 = *(const float4*)(a.bias + co0 + c * 4);
+          v[c * 4 + 0] = acc[c][pt][0] + b4.x; v[c * 4 + 1] = acc[c][pt][1] + b4.y; v[c * 4 + 2] = acc[c][pt][2] + b4.z; v[c * 4 + 3] = acc[c][pt][3] + b4.w;
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int i = 0; i < COT * 4; ++i) v[i] = silu_f(v[i]);
+        }
+        int cst = co0;
+        if (a.store_mode == 1) {
+          const int q = co0 / C4;
+          cst = co0 - q * C4;
+          opix = ((long)n * (2 * a.Ho) + (2 * oy + (q >> 1))) * (2 * a.Wo) + (2 * ox + (q & 1));
+        }
+#pragma unroll
+        for (int h = 0; h < COT / 2; ++h) {
+          float v8[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v8[r] = v[h * 8 + r];
+          if (a.res) {
+            float rv[8];
+            ldv<F32, 8>(a.res, opix * a.res_cs + a.res_co + co0 + h * 8, rv);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v8[r] += rv[r];
+          }
+          const long oi = opix * a.y_cs + a.y_co + cst + h * 8;
+          if (a.out_f32) stv<true, 8>(a.y, oi, v8); else stv<F32, 8>(a.y, oi, v8);
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
       int co0 = cobase + c * 16 + g * 4;
@@ -227,6 +264,8 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
                          "conv: bad residual view");
   const int tiles = a.Cout_pad / 16;
   const int cot = tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1);
+  a.perm = cot >= 2 && a.Cout == a.Cout_pad && a.y_cs % 8 == 0 && a.y_co % 8 == 0 && (!a.res || (a.res_cs % 8 == 0 && a.res_co % 8 == 0)) &&
+           (a.store_mode != 1 || (a.Cout / 4) % (4 * cot) == 0);
   if (f32) {
     if (cot == 4) return launch_t<true, 4, 4>(a, s);
     if (cot == 2) return launch_t<true, 2, 4>(a, s);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ x
   lut[threadIdx.x] = (float)threadIdx.x / 255.0f;  // exact IEEE division, as torch `im / 255`
   __syncthreads();
   const long M = (long)N * Ho * Wo;
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const long p = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (p >= M) return;
   const int n = (int)(p / ((long)Ho * Wo));
   const int r_ = (int)(p - (long)n * Ho * Wo);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   }
   __syncthreads();
   const int CV = C / V, Wp = (W + 1) >> 1;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   const long total = (long)N * H * Wp * CV;
   if (t >= total) return;
   const int c = (int)(t % CV) * V;

@@ -114,6 +114,13 @@ __device__ __forceinline__ void stv(void* p, long i, const float (&v)[V]) {
 }
 
 
+// XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Handing XCD x the x-th contiguous eighth
+// of the blocks keeps neighbouring blocks — which share halo rows of a 3x3 stencil — on one L2 instead of every XCD fetching them from HBM.
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblocks) {
+  const unsigned per = nblocks >> 3;
+  return bid < per * 8 ? (bid & 7) * per + (bid >> 3) : bid;
+}
+
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: xor-1 / xor-2 quad permutes, then half-row and row mirrors
 // — the same pairing, hence the same bits, as a __shfl_xor butterfly with offsets 1,2,4,8, but 4 VALU DPP adds instead of 4 ds_bpermute trips.
 __device__ __forceinline__ float row16_sum(float v) {
