@@ -426,7 +426,7 @@ def test_stem_wgrad(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
-@pytest.mark.parametrize("shape", [(2, 20, 20, 64, False), (2, 17, 23, 128, True), (1, 40, 40, 256, True)])
+@pytest.mark.parametrize("shape", [(2, 20, 20, 64, False), (2, 17, 23, 128, True), (1, 40, 40, 256, True), (3, 80, 33, 64, True), (1, 9, 50, 48, True)])
 def test_dw_wgrad(shape, dtype):
     N, H, W, C, use_scratch = shape
     g = torch.Generator().manual_seed(C + H)

@@ -704,6 +704,87 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const void* __restrict__ 
     else atomicAdd(dw + o, acc);
   }
 }
+// Sliding-window form (bf16/fp32, 8-channel groups): a thread owns (channel octet, row segment) work items and walks along the segment keeping
+// the 3x3 window of x in registers — per pixel 3 new 16-byte x loads + 1 dz load feed 72 FMAs (the per-pixel form above issues 10 loads for
+// 36).  72 fp32 partials per thread; the 4 waves fold into one [72][64] LDS image in turn, the lanes of one channel octet are then summed and
+// the workgroup writes its partial matrix (msl_reduce_partials adds them up: no contended atomics).
+#define DWR_SEG 16
+template <bool F32>
+__global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const void* __restrict__ x, const void* __restrict__ dz, int N, int H, int W, int C, int x_cs, int x_co,
+                                                            int z_cs, int z_co, int gsz, int gstride, int goff, int items_per_thread, float* __restrict__ scratch) {
+  __shared__ float red[72][64];
+  const int C8 = C >> 3;
+  const int cq = threadIdx.x % C8, rl = threadIdx.x / C8, RL = 256 / C8;
+  const int c = cq * 8;
+  const int cin = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
+  float s[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s[t][r] = 0.f;
+  const int nseg = (W + DWR_SEG - 1) / DWR_SEG;
+  const long items = (long)N * H * nseg;
+  const long i0 = ((long)xcd_block(blockIdx.x, gridDim.x) * RL + rl) * items_per_thread;
+  for (long it = i0; it < i0 + items_per_thread && it < items; ++it) {
+    const long row = it / nseg;
+    const int sg = (int)(it - row * nseg);
+    const int iy = (int)(row % H);
+    const bool up = iy > 0, dn = iy + 1 < H;
+    const long xrow = row * W;  // pixel index of (n, iy, 0); rows of one image are contiguous
+    const int x0 = sg * DWR_SEG, x1 = min(W, x0 + DWR_SEG);
+    float wl[3][8], wc[3][8], wr[3][8];  // window columns ix-1, ix, ix+1 (rows iy-1, iy, iy+1)
+    auto load_col = [&](int ix, float (&col)[3][8]) __attribute__((always_inline)) {
+      const bool in = (unsigned)ix < (unsigned)W;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const bool ok = in && (k == 1 || (k == 0 ? up : dn));
+        if (ok) ldv<F32, 8>(x, (xrow + (long)(k - 1) * W + ix) * x_cs + x_co + cin, col[k]);
+        else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) col[k][r] = 0.f;
+        }
+      }
+    };
+    load_col(x0 - 1, wl);
+    load_col(x0, wc);
+    for (int ix = x0; ix < x1; ++ix) {
+      load_col(ix + 1, wr);
+      float g[8];
+      ldv<F32, 8>(dz, (xrow + ix) * z_cs + z_co + c, g);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          s[k * 3 + 0][r] = fmaf(g[r], wl[k][r], s[k * 3 + 0][r]);
+          s[k * 3 + 1][r] = fmaf(g[r], wc[k][r], s[k * 3 + 1][r]);
+          s[k * 3 + 2][r] = fmaf(g[r], wr[k][r], s[k * 3 + 2][r]);
+        }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { wl[k][r] = wc[k][r]; wc[k][r] = wr[k][r]; }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = 0; w < 4; ++w) {  // waves fold in turn (C8 divides 64: lane l of every wave holds channel octet l % C8)
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if (w == 0) red[t * 8 + r][lane] = s[t][r]; else red[t * 8 + r][lane] += s[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  const int LPO = 64 / C8;  // lanes per channel octet
+  for (int v = threadIdx.x; v < 72 * C8; v += 256) {
+    const int k = v / C8, q = v - k * C8;
+    float acc = 0.f;
+    for (int j = 0; j < LPO; ++j) acc += red[k][j * C8 + q];
+    scratch[(long)blockIdx.x * 9 * C + (k >> 3) * C + q * 8 + (k & 7)] = acc;
+  }
+}
 // p 0 x, 1 dz, 4 dW f32 [9][C], 5 scratch for per-workgroup partials (optional; i 21 = capacity in floats) ; i 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 z_cs,13 z_co,22 gsz,23 gstride,24 goff
 int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
@@ -712,8 +793,21 @@ int msl_launch_dw_wgrad(const msl_op& op, hipStream_t s) {
               "dw_wgrad: views / channel map must be 4-aligned");
   const long M = (long)N * H * W;
   MSL_REQUIRE(M < (1L << 31), "dw_wgrad: too many pixels");
-  const int PL = 256 / (C / 4);
   float* scratch = (float*)op.p[5];
+  const bool al8 = C % 8 == 0 && C <= 512 && ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) == 0 && (op.i[22] == 0 || ((op.i[22] | op.i[23] | op.i[24]) & 7) == 0);
+  if (scratch && al8 && 64 % (C / 8) == 0) {  // sliding-window rows kernel (needs the partial-matrix scratch)
+    const int RL = 256 / (C / 8);
+    const long items = (long)N * H * ((W + DWR_SEG - 1) / DWR_SEG);
+    int ipt = 1;  // items per thread: keep >= ~2048 workgroups in flight (latency hiding), then lengthen the walks
+    while (ipt < 16 && items / ((long)RL * ipt * 2) >= 2048) ipt *= 2;
+    long bx = (items + (long)RL * ipt - 1) / ((long)RL * ipt);
+    while (bx * 9 * C > (long)op.i[21] && ipt < (1 << 20)) { ipt *= 2; bx = (items + (long)RL * ipt - 1) / ((long)RL * ipt); }
+    if (op.dtype == MSL_F32) hipLaunchKernelGGL(dw_wgrad_rows_kernel<true>, dim3((unsigned)bx), dim3(256), 0, s, op.p[0], op.p[1], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24], ipt, scratch);
+    else hipLaunchKernelGGL(dw_wgrad_rows_kernel<false>, dim3((unsigned)bx), dim3(256), 0, s, op.p[0], op.p[1], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[22], op.i[23], op.i[24], ipt, scratch);
+    MSL_CHECK_LAUNCH("dw_wgrad_rows");
+    return msl_reduce_partials(scratch, (float*)op.p[4], 9L * C, (int)bx, s);
+  }
+  const int PL = 256 / (C / 4);
   // each thread walks its pixels one dependent load round-trip at a time: with a scratch buffer (no contended atomics) the
   // work is spread over many short workgroups instead of few long ones
   const int ppt = scratch ? 4 : 32;
