@@ -328,6 +328,35 @@ def cpu_baseline_train(state, batch, seconds_budget=20.0):
             "sample": f"{steps} oracle train steps of {bs} synthetic 640x640 slices (fp32 forward + loss + autograd backward, no optimizer) in {dt:.1f}s"}
 
 
+def slice_extract_bench(dev, host_sample=True):
+    """The step before the path: cutting, enhancing and rendering the 182 axial slices of a 182x218x182 volume on the device
+    (MSL_OP_SLICE_EXTRACT, one launch) per variant, with the NumPy restatement timed on a few slices beside it."""
+    from mslesseg_amd import volume as V
+    from mslesseg_amd.enhance import aplicar_mejora
+
+    rng = np.random.default_rng(0)
+    vol = np.clip(rng.normal(300.0, 120.0, size=(182, 218, 182)), 0, None)
+    src = V.upload_volume(vol, dev)
+    idx = list(range(182))
+    out = {}
+    for mejora in (None, "HE", "CLAHE", "GC", "LT"):
+        V.extract_slices(src, vol.shape, "axial", idx, mejora)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            V.extract_slices(src, vol.shape, "axial", idx, mejora)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 10
+        rec = {"device_ms_per_182_slices": round(dt * 1e3, 3), "device_slices_per_s": round(182 / dt, 1)}
+        if host_sample:
+            t0 = time.perf_counter()
+            for i in range(60, 76):
+                V.slice_as_png_array(aplicar_mejora(V.take_slice(vol, "axial", i), mejora))
+            rec["host_numpy_slices_per_s"] = round(16 / (time.perf_counter() - t0), 1)
+        out[str(mejora)] = rec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +434,7 @@ def main():
         if rank == 0:
             line["roofline"] = None if args.no_roofline else predict_roofline(eng, imgs, out, args, value / world)
             line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_predict(pstate, host[: min(B, 64)])
+            line["slice_extract"] = None if args.no_roofline else slice_extract_bench(dev, host_sample=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -152,6 +152,12 @@ enum {
   MSL_OP_EMA = 32,                /* e = d*e + (1-d)*p over a flat fp32 range */
   MSL_OP_ATTENTION_BWD = 34,      /* PSA attention core backward (bf16): dq, dk written, dv added into the qkv gradient view; p 0 qkv, 1 y, 2 dy,
                                      3 statistics scratch f32 [N][heads][ceil16(HW)+16][4], 4 gqkv ; i as ATTENTION + 14,15 gradient view cs/co */
+  MSL_OP_SLICE_EXTRACT = 35,      /* FLAIR volume → batch of rendered slices, with the reference's enhancement variants, on the device
+                                     [replaces Paciente.aplicar_mejora + plt.imsave + cv2.imread, REF utils/Paciente.py:195-249,
+                                     utils/mejora_imagen.py:43-184, utils/utils.py:394-406].  p 0 volume f64 [Z][Y][X] (NIfTI order),
+                                     1 slice indices i32 [B], 2 tables u8 (grey[256], GC[256], sRGB->L8[256], L8->sRGB[256], LT[256][256]),
+                                     4 out u8 [B][H][W][3] (corte.T, rows flipped; H,W = slice cols,rows); i 0 X,1 Y,2 Z,
+                                     3 axis (0 sagital,1 coronal,2 axial), 4 B, 5 variant (0 none,1 HE,2 CLAHE,3 GC,4 LT) */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

@@ -61,3 +61,19 @@ def test_enhanced_slice_renders_like_matplotlib(tmp_path, mejora):
     assert E.aplicar_mejora(corte, None) is corte
     with pytest.raises(ValueError):
         E.aplicar_mejora(corte, "XX")
+
+
+def test_device_tables_match_the_numpy_variants():
+    """The tables handed to MSL_OP_SLICE_EXTRACT reproduce `gc`, `lt` and the L* round trip of `clahe` on every uint8 input."""
+    from mslesseg_amd import enhance as E, volume as V
+
+    t = V.enhancement_tables()
+    assert t.dtype == np.uint8 and t.shape == (1024 + 65536,)
+    v = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    assert np.array_equal(t[256:512][v], E.gc(v))
+    assert np.array_equal(t[512:768], E._srgb_to_L8(np.arange(256, dtype=np.uint8)))
+    assert np.array_equal(t[768:1024], E._L8_to_srgb(np.arange(256, dtype=np.uint8)))
+    lt = t[1024:].reshape(256, 256)
+    for m in (1, 17, 128, 255):
+        img = np.arange(m + 1, dtype=np.uint8).reshape(1, -1)  # uint8 input: normalizar_a_uint8 passes it through, max == m
+        assert np.array_equal(lt[m][img], E.lt(img))

@@ -570,3 +570,27 @@ def test_conv3x3_lds_batchnorm_statistics_epilogue(case, dtype):
     got = acc.cpu().view(slots, Cout, 2).sum(0)
     assert torch.allclose(got[:, 0], z.sum(0), rtol=1e-5, atol=1e-3)
     assert torch.allclose(got[:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("mejora", [None, "HE", "CLAHE", "GC", "LT"])
+@pytest.mark.parametrize("plano", ["axial", "coronal", "sagital"])
+def test_slice_extract_device_matches_host_restatement(plano, mejora, demo_volumes):
+    """MSL_OP_SLICE_EXTRACT (cut + normalizar_a_uint8 + enhancement variant + plt.imsave/cv2.imread rendering on the device) is bit-exact
+    against the NumPy restatement `slice_as_png_array(aplicar_mejora(take_slice(...)))` on real FLAIR slices (demo P39, incl. empty border
+    slices) and on a small non-cubic float volume with negative values."""
+    from mslesseg_amd import volume as V
+    from mslesseg_amd.enhance import aplicar_mejora
+
+    rng = np.random.default_rng(7)
+    small = rng.normal(size=(24, 40, 17)) * 300.0
+    small[:, :, 3] = 5.0  # a constant slice (axial 3): vmax == vmin branch
+    for vol, idx in ((demo_volumes["P39_flair"], {"axial": [0, 37, 90, 181], "coronal": [1, 100, 217], "sagital": [0, 64, 120]}[plano]),
+                     (small, {"axial": [0, 3, 16], "coronal": [0, 21, 39], "sagital": [5, 23]}[plano])):
+        src = V.upload_volume(vol, DEV)
+        got = V.extract_slices(src, vol.shape, plano, idx, mejora).cpu().numpy()
+        torch.cuda.synchronize()
+        for j, i in enumerate(idx):
+            want = V.slice_as_png_array(aplicar_mejora(V.take_slice(vol, plano, i), mejora))
+            assert got[j].shape == want.shape, (got[j].shape, want.shape)
+            nd = int((got[j] != want).sum())
+            assert nd == 0, f"{plano} slice {i} {mejora}: {nd} differing bytes, max |d| {int(np.abs(got[j].astype(int) - want.astype(int)).max())}"

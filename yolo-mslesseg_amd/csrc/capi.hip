@@ -49,6 +49,7 @@ static int dispatch(const msl_op& op, hipStream_t s) {
     case MSL_OP_EMA: return msl_launch_ema(op, s);
     case MSL_OP_SEG_LOSS: return msl_launch_seg_loss(op, s);
     case MSL_OP_ATTENTION_BWD: return msl_launch_attention_bwd(op, s);
+    case MSL_OP_SLICE_EXTRACT: return msl_launch_slice_extract(op, s);
     default:
       msl_set_error("unknown op kind %d", op.kind);
       return MSL_ENOSYS;

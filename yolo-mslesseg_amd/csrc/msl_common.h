@@ -173,6 +173,7 @@ int msl_launch_adamw(const msl_op& op, hipStream_t s);
 int msl_launch_ema(const msl_op& op, hipStream_t s);
 int msl_launch_seg_loss(const msl_op& op, hipStream_t s);
 int msl_launch_attention_bwd(const msl_op& op, hipStream_t s);
+int msl_launch_slice_extract(const msl_op& op, hipStream_t s);
 int msl_launch_conv1x1(const msl_op& op, hipStream_t s);
 bool msl_conv1x1_eligible(const msl_op& op);
 int msl_reduce_partials(const float* scratch, float* dst, long size, int nb, hipStream_t s);  // dst[i] += sum_b scratch[b][i]

@@ -143,20 +143,64 @@ def dice(gt: torch.Tensor, pred: torch.Tensor) -> Tuple[float, float]:
     return d, float(np.round(d, 3))
 
 
+_VARIANT_CODE = {None: 0, "HE": 1, "CLAHE": 2, "GC": 3, "LT": 4}
+_tables_cache: Dict[str, torch.Tensor] = {}
+
+
+def enhancement_tables() -> np.ndarray:
+    """The lookup tables MSL_OP_SLICE_EXTRACT takes (include/mslesseg_hip.h), built with the NumPy expressions of `enhance.py` so that the
+    device never evaluates a float64 `pow` / `log` itself: grey colormap, GC table, sRGB→L8, L8→sRGB, and the LT table for every possible
+    slice maximum (row m = `lt` applied to 0..255 with g.max() == m; entries above m are never read)."""
+    from . import enhance
+
+    v = np.arange(256, dtype=np.uint8)
+    lt = np.zeros((256, 256), np.uint8)
+    g = np.arange(256, dtype=np.uint16)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for m in range(256):
+            c = 255 / np.log(1 + np.array([m], dtype=np.uint16).max())
+            lt[m] = np.clip(c * np.log(1 + g), 0, 255).astype(np.uint8)
+    return np.concatenate([_GRAY_LUT, enhance.gc(v.reshape(1, -1)).reshape(-1), enhance._srgb_to_L8(v), enhance._L8_to_srgb(v), lt.reshape(-1)])
+
+
+def upload_volume(flair: np.ndarray, device) -> torch.Tensor:
+    """float64 [X,Y,Z] (as `read_nifti` / `get_fdata` give it) → device tensor in NIfTI order (x fastest), what MSL_OP_SLICE_EXTRACT reads."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(flair, dtype=np.float64).transpose(2, 1, 0))).to(device)
+
+
+def extract_slices(vol_dev: torch.Tensor, shape, plano: str, indices, mejora: Optional[str] = None) -> torch.Tensor:
+    """Device slice extraction + enhancement + rendering: uint8 [B,H,W,3] on the device = what `cv2.imread` returns for the PNG the reference
+    writes for each slice (`slice_as_png_array(aplicar_mejora(take_slice(...)))` is the host restatement the tests compare with)."""
+    if mejora not in _VARIANT_CODE:
+        raise ValueError(f"Mejora no reconocida: {mejora}.")
+    dev = vol_dev.device
+    key = str(dev)
+    if key not in _tables_cache:
+        _tables_cache[key] = torch.from_numpy(enhancement_tables()).to(dev)
+    X, Y, Z = (int(d) for d in shape)
+    axis = PLANE_AXIS[plano]
+    idx = torch.tensor([int(i) for i in indices], dtype=torch.int32, device=dev)
+    d0, d1 = expected_slice_shape(shape, plano)
+    out = torch.empty((idx.numel(), d1, d0, 3), dtype=torch.uint8, device=dev)
+    op = hiplib.make_op(hiplib.OP_SLICE_EXTRACT, MSL_F32, p=(vol_dev.data_ptr(), idx.data_ptr(), _tables_cache[key].data_ptr(), 0, out.data_ptr()),
+                        i={0: X, 1: Y, 2: Z, 3: axis, 4: idx.numel(), 5: _VARIANT_CODE[mejora]})
+    hiplib.launch(op, _stream(dev))
+    return out
+
+
 def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Iterable[int]] = None, batch: int = 128, mejora: Optional[str] = None) -> torch.Tensor:
     """FLAIR volume → float32 {0,1} volume of `plano` predictions on device (slices never predicted stay 0).
     Whole-volume batched replacement of generar_predicciones + reconstruir_volumen for one plane.  `mejora` ∈ {None, "HE", "CLAHE", "GC",
     "LT"} applies the reference's enhancement variant to every slice before it is rendered [REF Paciente.py:195-222]."""
-    from .enhance import aplicar_mejora
-
     eng = model._get_engine()
     dev = eng.device
     idx = list(range(flair.shape[PLANE_AXIS[plano]])) if indices is None else [int(i) for i in indices]
     vol = torch.zeros(flair.shape, dtype=torch.float32, device=dev)
+    src = upload_volume(flair, dev)  # the slices are cut, enhanced and rendered on the device (MSL_OP_SLICE_EXTRACT): no per-slice host work
     for b0 in range(0, len(idx), batch):
         chunk = idx[b0 : b0 + batch]
-        imgs = np.stack([slice_as_png_array(aplicar_mejora(take_slice(flair, plano, i), mejora)) for i in chunk])
-        out = eng.predict_slices(torch.from_numpy(imgs))  # uint8 [S, W, H] = the array the reference would save per slice
+        imgs = extract_slices(src, flair.shape, plano, chunk, mejora)
+        out = eng.predict_slices(imgs)  # uint8 [S, W, H] = the array the reference would save per slice
         insert_slices(vol, out, chunk, plano)
     return vol
 
