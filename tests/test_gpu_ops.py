@@ -112,6 +112,8 @@ LDS3_CASES = [
     (2, 40, 56, 16, 32, 2, 16, 0, 32, 0, 1, 0, 0),       # model.1-like: ONE partial channel chunk (missing k-group planes staged as zeros)
     (1, 33, 47, 8, 16, 1, 24, 8, 16, 0, 1, 1, 0),        # 8 → 16 out of a concat slice, residual
     (1, 20, 20, 8, 32, 2, 8, 0, 32, 0, 0, 0, 1),         # stride 2, fp32 output
+    (2, 30, 45, 16, 8, 1, 16, 0, 8, 0, 1, 0, 0),         # Cout = 8: one 16-row block, upper half zero (C3k2 bottleneck of the 160² level)
+    (1, 17, 33, 32, 8, 1, 32, 0, 24, 8, 1, 1, 0),        # Cout = 8 into a concat slice with residual
 ]
 
 
@@ -545,7 +547,7 @@ def test_attention_backward_bf16(hw):
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 @pytest.mark.parametrize("case", [(2, 16, 40, 64, 64, 1), (1, 21, 35, 32, 32, 2), (3, 9, 33, 32, 16, 1), (1, 20, 20, 128, 128, 1),
-                                  (11, 160, 150, 64, 64, 1), (36, 80, 90, 32, 16, 1)])  # the last two: >= 1024 tiles → persistent kernel
+                                  (11, 160, 150, 64, 64, 1), (36, 80, 90, 32, 16, 1), (2, 40, 40, 16, 8, 1)])  # >= 1024 tiles → persistent kernel; Cout = 8
 def test_conv3x3_lds_batchnorm_statistics_epilogue(case, dtype):
     """LDS-tiled 3x3 conv with p[5]: (sum z, sum z^2) per channel of the values it stores, in slot-replicated fp64 accumulators."""
     N, H, W, Cin, Cout, s = case

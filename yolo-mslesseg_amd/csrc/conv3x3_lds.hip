@@ -53,6 +53,7 @@ __device__ __forceinline__ int halo_byte(int s, int g) { return ((s >> 2) << 8) 
 // packed in that order, include/mslesseg_hip.h op.i[25]): bias, optional statistics of the stored values, SiLU, residual, 16-byte stores.
 template <bool F32, int COT>
 __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co0, const f32x4 (&accp)[COT], float (&s1)[COT][4], float (&s2)[COT][4]) {
+  if (co0 >= a.Cout) return;  // Cout = 8: the upper half of the single 16-row block is zero padding
   float v[COT * 4];
 #pragma unroll
   for (int c = 0; c < COT; ++c) {
@@ -537,11 +538,11 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(a.Cin > 0 && a.Cin % v == 0 && (a.Cin % chunk == 0 || a.Cin < chunk) && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs,
               "conv3x3_lds: Cin must be a multiple of %d, or a multiple of %d below it", chunk, v);
   const int cot = op.i[24];  // channel tiles per workgroup = how the host packed the weight image (4 for Cout % 64 == 0, else 2 or 1)
-  MSL_REQUIRE((cot == 4 || cot == 2 || cot == 1) && a.Cout % (16 * cot) == 0, "conv3x3_lds: weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
+  MSL_REQUIRE((cot == 4 || cot == 2 || cot == 1) && (a.Cout % (16 * cot) == 0 || (a.Cout == 8 && cot == 1)), "conv3x3_lds: weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
   const int oal = cot == 1 ? 4 : 8;  // a lane stores runs of 4*COT consecutive channels with 8- / 16-byte accesses
-  MSL_REQUIRE(a.Cout % 16 == 0 && a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: output view must be %d-channel aligned", oal);
+  MSL_REQUIRE((a.Cout % 16 == 0 || a.Cout == 8) && a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: output view must be %d-channel aligned", oal);
   if (a.res) MSL_REQUIRE(a.res_cs % oal == 0 && a.res_co % oal == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
-  const int cout_blocks = a.Cout / (16 * cot);
+  const int cout_blocks = (a.Cout + 16 * cot - 1) / (16 * cot);  // Cout = 8: one block of 16 rows, the upper 8 zero
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
   const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : 1;  // i[23]=-4 opts into the 16x32 tile (measured slower: kept for experiments)
   const int TH = 4 * rw;

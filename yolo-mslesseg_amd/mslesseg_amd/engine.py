@@ -62,7 +62,8 @@ def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
 def lds3x3_eligible(cin: int, cout: int, k: int, dtype: int) -> bool:
     chunk = 16 if dtype == MSL_F32 else 32
     # whole channel chunks, or ONE partial chunk (narrow layers: the missing k-group planes are staged as zeros)
-    return k == 3 and cout % 16 == 0 and (cin % chunk == 0 or (cin < chunk and cin % (chunk // 4) == 0))
+    # Cout = 8 (the C3k2 bottlenecks of the 160² level) runs as one 16-row block whose upper half is zero weights
+    return k == 3 and (cout % 16 == 0 or cout == 8) and (cin % chunk == 0 or (cin < chunk and cin % (chunk // 4) == 0))
 
 
 def lds_col_perm(cot: int) -> torch.Tensor:
@@ -79,6 +80,10 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
     cout, cin, _, _ = w.shape
     ch = 4 if dtype == MSL_F32 else 8
     chunk = 4 * ch
+    cout_real = cout
+    if cout == 8:  # pad to one 16-row block
+        w = torch.cat([w, torch.zeros_like(w)], 0)
+        cout = 16
     cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
     # (measured: narrower channel blocks — smaller LDS slab, 3 workgroups per CU instead of 2 — are slower: 0.29 vs 0.25 ms on 64→64 @160²,
     # the halo is then staged once per block of 32 output channels)
@@ -89,7 +94,7 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
         w = wp
     wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot)]   # [blk, col, cc, g, e, ky, kx]
     img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
-    return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
+    return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
 
 
 class PackedWeights:

@@ -186,6 +186,10 @@ def _lds_image_idx(idx4: torch.Tensor, dtype: int):
     cout, cin = idx4.shape[:2]
     ch = 4 if dtype == MSL_F32 else 8
     chunk = 4 * ch
+    cout_real = cout
+    if cout == 8:  # one 16-row block, upper half zero weights (index -1)
+        idx4 = torch.cat([idx4, torch.full_like(idx4, -1)], 0)
+        cout = 16
     cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
     cob = 16 * cot
     if cin % chunk:  # one partial chunk: index -1 = zero weight (GATHER_CAST)
@@ -194,7 +198,7 @@ def _lds_image_idx(idx4: torch.Tensor, dtype: int):
         idx4 = padded
     from .engine import lds_col_perm
     v = idx4.reshape(cout // cob, cob, idx4.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot)].permute(0, 2, 5, 6, 3, 1, 4).contiguous()
-    return v.reshape(-1).to(torch.int32), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout, lds=1, cot=cot)
+    return v.reshape(-1).to(torch.int32), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
 
 
 def _lds_ok(cin, cout, k, dtype):
