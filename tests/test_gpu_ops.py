@@ -483,6 +483,41 @@ def test_conv_statistics_epilogue_is_refused_outside_the_1x1_kernel():
         hiplib.launch(op, _stream())
 
 
+@pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1), (2, 70, 41, 64, 64, 1), (1, 33, 66, 8, 32, 0)])
+def test_stride2_input_gradient_parity_classes_lds_kernel(case):
+    """The same four parity-class passes through the LDS-tiled kernel (weights as the LDS image with a 1|2 x 1|2 kernel, i[25] = 1): bf16."""
+    from mslesseg_amd import trainprog as TP
+
+    dtype = MSL_BF16
+    N, H, W, Cin, Cout, accumulate = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cout * 9) ** 0.5).to(_tdt(dtype)).float()
+    dz = _rand_act((N, Ho, Wo, Cout), dtype, g)
+    prev = _rand_act((N, H, W, Cin), dtype, g)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dz.float().permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    if accumulate:
+        ref = ref + prev.float()
+    dzd, gx = dz.to(DEV), prev.clone().to(DEV)
+    zeros = torch.zeros(Cin, device=DEV)
+    flat = w.reshape(-1)
+    idx4 = torch.arange(flat.numel()).view(Cout, Cin, 3, 3)
+    for a in (0, 1):
+        for b in (0, 1):
+            kys, kxs = ([1] if a == 0 else [2, 0]), ([1] if b == 0 else [2, 0])
+            rows = idx4.permute(1, 2, 3, 0)[:, kys][:, :, kxs]  # [ci][kh][kw][co]
+            cidx, m = TP._lds_image_idx(rows.permute(0, 3, 1, 2), dtype)
+            img = torch.where(cidx >= 0, flat[cidx.clamp(min=0).long()], torch.zeros(())).to(_tdt(dtype)).to(DEV)
+            kh, kw = len(kys), len(kxs)
+            op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(dzd.data_ptr(), img.data_ptr(), zeros.data_ptr(), gx.data_ptr() if accumulate else 0, gx.data_ptr()),
+                                i={0: N, 1: Ho, 2: Wo, 3: Cout, 4: (H - a + 1) // 2, 5: (W - b + 1) // 2, 6: Cin, 7: kh if kh == kw else kh * 16 + kw, 8: 1, 9: 0,
+                                   10: Cout, 11: 0, 12: Cin, 13: 0, 14: Cin, 15: 0, 16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 2, 21: m["Cout_pad"],
+                                   23: a | (b << 1) | ((H & 1) << 2) | ((W & 1) << 3), 24: m["cot"], 25: 1})
+            hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(gx.cpu(), ref, dtype, f"s2 dgrad (LDS kernel) {case}")
+
+
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 @pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1)])
 def test_stride2_input_gradient_as_parity_classes(case, dtype):

@@ -33,15 +33,16 @@ struct Conv3Args {
   int N, H, W, Cin, Ho, Wo, Cout;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int act, out_f32, tiles_x, tiles_y;
+  int lat, full_h, full_w;  // lat >= 0: output pixel (Y,X) is stored at (2Y + (lat&1), 2X + (lat>>1)) of a full_h x full_w image (parity class of a stride-2 input gradient)
   double* acc;  // optional BatchNorm accumulator f64[slots][2*Cout]: per-channel (sum, sum of squares) of the stored outputs
   int slots;
 };
 
-template <int S, int RW>
+template <int S, int RW, int KH = 3>
 struct Tile3 {
   static constexpr int TW = 32, TH = 4 * RW;
-  static constexpr int ROWP = 34;                                  // slots per halo row (s1) / per parity row (s2)
-  static constexpr int ROWS = S == 1 ? TH + 2 : 2 * TH + 1;        // halo rows
+  static constexpr int ROWP = 34;                                  // slots per halo row (s1; 32 + KW - 1 <= 34) / per parity row (s2)
+  static constexpr int ROWS = S == 1 ? TH + KH - 1 : 2 * TH + 1;   // halo rows
   static constexpr int SLOTS = S == 1 ? ROWS * ROWP : ROWS * 2 * ROWP;
   static constexpr int PIECES = (SLOTS + 15) / 16;                 // LDS-DMA pieces of 16 halo pixels x 64 B (1 KiB)
 };
@@ -96,15 +97,17 @@ __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co
   }
 }
 
-template <bool F32, int S, int RW, int COT>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
-  using T = Tile3<S, RW>;
+  using T = Tile3<S, RW, KH>;
+  constexpr int NT = KH * KW;            // taps: 3x3 (pad 1), or the 1x1 / 1x2 / 2x1 / 2x2 kernels (pad 0) of the stride-2 input gradient's parity classes
+  constexpr int PAD = KH == 3 ? 1 : 0;
   constexpr int ES = F32 ? 4 : 2;
   constexpr int CHUNK = 64 / ES;          // channels per chunk (4 groups x 16 B)
   constexpr int COB = COT * 16;
   constexpr int PT = 2 * RW;              // pixel tiles per wave: RW rows x 2 column halves
   constexpr int IN_BYTES = T::PIECES * 1024;
-  constexpr int W_BYTES = 9 * 4 * COB * 16;
+  constexpr int W_BYTES = NT * 4 * COB * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_in = smem;
   unsigned char* s_w = smem + IN_BYTES;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   const int tyi = bid % a.tiles_y;
   const int n = bid / a.tiles_y;
   const int oy0 = tyi * T::TH, ox0 = txi * T::TW;
-  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;  // halo origin (pad 1)
+  const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;  // halo origin
   const int cob = blockIdx.y;
 
   f32x4 acc[COT][PT];
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     // of row r+1 / tap row ky-1 for row r / tap row ky from a register cache — 24 instead of 36 LDS reads per chunk, no faster.)
     uint4 av[2][COT], bv[2][PT];
     auto fetch = [&](int t, uint4 (&A)[COT], uint4 (&B)[PT]) {
-      const int ty = t / 3, tx = t - ty * 3;
+      const int ty = t / KW, tx = t - ty * KW;
 #pragma unroll
       for (int c = 0; c < COT; ++c) A[c] = *(const uint4*)(s_w + (((t * 4 + g) * COB) + c * 16 + lp) * 16);
 #pragma unroll
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     };
     fetch(0, av[0], bv[0]);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (t + 1 < 9) fetch(t + 1, av[(t + 1) & 1], bv[(t + 1) & 1]);
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) fetch(t + 1, av[(t + 1) & 1], bv[(t + 1) & 1]);
 #pragma unroll
       for (int c = 0; c < COT; ++c)
 #pragma unroll
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   for (int p = 0; p < PT; ++p) {
     const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
     if (oy >= a.Ho || ox >= a.Wo) continue;
-    const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+    const long pix = a.lat < 0 ? ((long)n * a.Ho + oy) * a.Wo + ox : ((long)n * a.full_h + 2 * oy + (a.lat & 1)) * a.full_w + 2 * ox + (a.lat >> 1);
     f32x4 accp[COT];
 #pragma unroll
     for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
@@ -264,17 +267,17 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 }
 
-template <bool F32, int S, int RW, int COT>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3>
 static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
-  using T = Tile3<S, RW>;
-  constexpr int LDS = T::PIECES * 1024 + 9 * 4 * COT * 16 * 16;
+  using T = Tile3<S, RW, KH>;
+  constexpr int LDS = T::PIECES * 1024 + KH * KW * 4 * COT * 16 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x), (unsigned)cout_blocks);
-  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT>), grid, dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>), grid, dim3(256), LDS, s, a);
   MSL_CHECK_LAUNCH("conv3x3_lds");
   return MSL_OK;
 }
@@ -528,6 +531,40 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const int k = op.i[7], stride = op.i[8], pad = op.i[9];
   a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
   a.act = op.i[18]; a.out_f32 = op.i[19];
+  a.lat = -1; a.full_h = a.full_w = 0;
+  if (op.i[20] == 2) {
+    // One parity class of a stride-2 3x3 input gradient: stride-1, pad-0 pass over the gradient (H, W) with a 1x1 / 1x2 / 2x1 / 2x2 kernel
+    // (zero beyond the bottom / right edge), outputs on the sub-lattice (2Y + a, 2X + b) of the full image — same op contract as the generic
+    // kernel (conv_igemm.hip, store_mode 2): i[7] = kh (square) or kh*16 + kw, i[23] = a | b<<1 | Hodd<<2 | Wodd<<3.
+    const int kh = k >= 16 ? k >> 4 : k, kw = k >= 16 ? k & 15 : k;
+    a.lat = op.i[23] & 3;
+    a.full_h = 2 * a.H - ((op.i[23] >> 2) & 1); a.full_w = 2 * a.W - ((op.i[23] >> 3) & 1);
+    a.acc = nullptr; a.slots = 1;
+    MSL_REQUIRE(op.dtype == MSL_BF16 && !op.p[5] && !a.out_f32, "conv lattice pass (LDS): bf16 only, no statistics / fp32 output");
+    MSL_REQUIRE(a.x && a.w && a.bias && a.y && kh >= 1 && kh <= 2 && kw >= 1 && kw <= 2 && stride == 1 && pad == 0, "conv lattice pass (LDS): needs a 1|2 x 1|2 kernel, stride 1, pad 0");
+    MSL_REQUIRE(a.N > 0 && a.Ho > 0 && a.Wo > 0 && a.Ho <= a.H && a.Wo <= a.W && a.Ho >= a.H - 1 && a.Wo >= a.W - 1 && 2 * (a.Ho - 1) + (a.lat & 1) < a.full_h &&
+                    2 * (a.Wo - 1) + (a.lat >> 1) < a.full_w, "conv lattice pass (LDS): class grid %dx%d inconsistent with source %dx%d", a.Ho, a.Wo, a.H, a.W);
+    MSL_REQUIRE(a.Cin > 0 && a.Cin % 8 == 0 && (a.Cin % 32 == 0 || a.Cin < 32) && a.x_cs % 8 == 0 && a.x_co % 8 == 0 && a.x_co + a.Cin <= a.x_cs, "conv lattice pass (LDS): bad input view");
+    const int cot = op.i[24];
+    MSL_REQUIRE((cot == 4 || cot == 2 || cot == 1) && (a.Cout % (16 * cot) == 0 || (a.Cout == 8 && cot == 1)), "conv lattice pass (LDS): weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
+    const int oal = cot == 1 ? 4 : 8;
+    MSL_REQUIRE(a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + a.Cout <= a.y_cs && (!a.res || (a.res_cs % oal == 0 && a.res_co % oal == 0 && a.res_co + a.Cout <= a.res_cs)),
+                "conv lattice pass (LDS): output / residual view must be %d-channel aligned", oal);
+    const int cout_blocks = (a.Cout + 16 * cot - 1) / (16 * cot);
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.tiles_y = (a.Ho + 7) / 8;
+#define L3K(KH_, KW_)                                                              \
+  do {                                                                             \
+    if (cot == 4) return launch3<false, 1, 2, 4, KH_, KW_>(a, cout_blocks, s);     \
+    if (cot == 2) return launch3<false, 1, 2, 2, KH_, KW_>(a, cout_blocks, s);     \
+    return launch3<false, 1, 2, 1, KH_, KW_>(a, cout_blocks, s);                   \
+  } while (0)
+    if (kh == 1 && kw == 1) L3K(1, 1);
+    if (kh == 1 && kw == 2) L3K(1, 2);
+    if (kh == 2 && kw == 1) L3K(2, 1);
+    L3K(2, 2);
+#undef L3K
+  }
   a.acc = (double*)op.p[5]; a.slots = op.i[23] > 0 ? op.i[23] : 1;  // BatchNorm-statistics epilogue (train-mode raw convs)
   if (a.acc) MSL_REQUIRE(a.slots <= 16 && !a.out_f32 && !a.res && a.act == 0, "conv3x3_lds: the statistics epilogue is for raw convs (no activation / residual / fp32 output)");
   const bool f32 = op.dtype == MSL_F32;

@@ -182,7 +182,9 @@ def _gemm_rows_idx(idx2d: torch.Tensor, dtype: int):
 
 
 def _lds_image_idx(idx4: torch.Tensor, dtype: int):
-    """idx4 [Cout,Cin,3,3] → LDS image [blk][cc][ky][kx][g][col][e] (engine.pack_conv3x3_lds)."""
+    """idx4 [Cout,Cin,kh,kw] → LDS image [blk][cc][ky][kx][g][col][e] (engine.pack_conv3x3_lds; kh x kw = 3x3, or the 1|2 x 1|2 kernels of the
+    stride-2 input gradient's parity classes)."""
+    kh, kw = int(idx4.shape[2]), int(idx4.shape[3])
     cout, cin = idx4.shape[:2]
     ch = 4 if dtype == MSL_F32 else 8
     chunk = 4 * ch
@@ -193,12 +195,12 @@ def _lds_image_idx(idx4: torch.Tensor, dtype: int):
     cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
     cob = 16 * cot
     if cin % chunk:  # one partial chunk: index -1 = zero weight (GATHER_CAST)
-        padded = torch.full((cout, (cin + chunk - 1) // chunk * chunk, 3, 3), -1, dtype=idx4.dtype)
+        padded = torch.full((cout, (cin + chunk - 1) // chunk * chunk, kh, kw), -1, dtype=idx4.dtype)
         padded[:, :cin] = idx4
         idx4 = padded
     from .engine import lds_col_perm
-    v = idx4.reshape(cout // cob, cob, idx4.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot)].permute(0, 2, 5, 6, 3, 1, 4).contiguous()
-    return v.reshape(-1).to(torch.int32), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
+    v = idx4.reshape(cout // cob, cob, idx4.shape[1] // chunk, 4, ch, kh, kw)[:, lds_col_perm(cot)].permute(0, 2, 5, 6, 3, 1, 4).contiguous()
+    return v.reshape(-1).to(torch.int32), dict(K=kh * kw * cin, Kpad=kh * kw * cin, Cout_pad=cout_real, lds=1, cot=cot)
 
 
 def _lds_ok(cin, cout, k, dtype):
@@ -461,7 +463,11 @@ class TrainPlan(graph.Visitor):
                         padded = torch.full((cin, len(kys), len(kxs), cpad), -1, dtype=torch.int64)
                         padded[..., :cout] = rows
                         rows = padded
-                    cidx, cm = _gemm_rows_idx(rows.reshape(cin, -1), self.dtype)
+                    if self.dtype != MSL_F32 and cpad == cout and _lds_ok(cout, cin, 3, self.dtype):
+                        # LDS-tiled pass (conv3x3_lds.hip with a 1|2 x 1|2 kernel): the class conv reads the cout gradient channels, writes cin
+                        cidx, cm = _lds_image_idx(rows.permute(0, 3, 1, 2), self.dtype)  # [ci][co][kh][kw]
+                    else:
+                        cidx, cm = _gemm_rows_idx(rows.reshape(cin, -1), self.dtype)
                     dcls.append((pa, pb, len(kys), len(kxs), self._packed(cidx), cm))
             didx, dm = dcls[0][4], dcls[0][5]
         else:
