@@ -90,14 +90,33 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
       accumulate(va, vb);
     }
   }
+  int nrows = PL;  // partial rows per channel group left in `red`
+  if ((CV & (CV - 1)) == 0 && CV <= 64) {
+    // CV is a power of two: the lanes of one channel group sit CV apart inside a wave → butterfly over them first (no serial LDS walk),
+    // then only one row per wave is left to fold
+    for (int off = CV; off < 64; off <<= 1) {
 #pragma unroll
-  for (int r = 0; r < V; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
+      for (int r = 0; r < V; ++r) {
+        s1[r] += __shfl_xor(s1[r], off);
+        if (MODE != 2) s2[r] += __shfl_xor(s2[r], off);
+      }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < CV) {
+#pragma unroll
+      for (int r = 0; r < V; ++r) { red[0][wave * CV + lane][r] = s1[r]; red[1][wave * CV + lane][r] = s2[r]; }
+    }
+    nrows = 4;
+  } else {
+#pragma unroll
+    for (int r = 0; r < V; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
+  }
   __syncthreads();
   if (threadIdx.x < CV) {
     float t1[V], t2[V];
 #pragma unroll
     for (int r = 0; r < V; ++r) { t1[r] = 0.f; t2[r] = 0.f; }
-    for (int j = 0; j < PL; ++j)
+    for (int j = 0; j < nrows; ++j)
 #pragma unroll
       for (int r = 0; r < V; ++r) { t1[r] += red[0][j * CV + threadIdx.x][r]; t2[r] += red[1][j * CV + threadIdx.x][r]; }
     double* dst = acc + (long)(blockIdx.x % slots) * (MODE == 2 ? C : 2 * C);
@@ -109,10 +128,12 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
   }
 }
 
-static int reduce_grid(long M, int C, int slots, int V) {
+static int reduce_grid(long M, int C, int slots, int V, long wide_cap = 512) {
   const int PL = 256 / (C / V);
   long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);  // >= 16 pixels per thread before another block (and its atomics) pays off
-  const long cap = slots > 1 ? 1024 : 256;                  // un-replicated accumulator: keep the same-address atomic chain short
+  // measured (batch 128): for the two-stream BatchNorm reductions 256-512 workgroups beat 768 / 1024 / 2048 / 4096 — each one ends in a fold +
+  // fp64 atomics; the single-stream column sum (fp32 head gradients, 4 channels per thread) prefers 1024
+  const long cap = slots > 1 ? wide_cap : 256;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -336,7 +357,7 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.p[0] && op.p[4] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[11] + C <= op.i[10], "colsum: bad args");
   const int slots = slots_of(op, 21);  // acc = f64[slots][C]; F64_DRAIN (i 2 = slots, i 3 = C) folds them
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "colsum: too many accumulator slots");
-  dim3 grid(reduce_grid(M, C, slots, 4));
+  dim3 grid(reduce_grid(M, C, slots, 4, 1024));
   if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots);
   else hipLaunchKernelGGL((chan_reduce_kernel<false, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots);
   MSL_CHECK_LAUNCH("colsum");
