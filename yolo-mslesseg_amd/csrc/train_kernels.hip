@@ -357,9 +357,11 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.p[0] && op.p[4] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[11] + C <= op.i[10], "colsum: bad args");
   const int slots = slots_of(op, 21);  // acc = f64[slots][C]; F64_DRAIN (i 2 = slots, i 3 = C) folds them
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "colsum: too many accumulator slots");
-  dim3 grid(reduce_grid(M, C, slots, 4, 1024));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL((chan_reduce_kernel<true, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots);
-  else hipLaunchKernelGGL((chan_reduce_kernel<false, 2, 4>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots);
+  const bool v8 = !op.i[19] && vec8(C, op.i[10], op.i[11]);  // compute-dtype input, 8-aligned view: 16-byte loads
+  dim3 grid(reduce_grid(M, C, slots, v8 ? 8 : 4, 1024));
+#define CS(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 2, V>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots)
+  if (op.dtype == MSL_F32) { if (v8) CS(true, 8); else CS(true, 4); } else { if (v8) CS(false, 8); else CS(false, 4); }
+#undef CS
   MSL_CHECK_LAUNCH("colsum");
   return MSL_OK;
 }
