@@ -64,7 +64,10 @@ enum {
    *       w[cout_blk][chunk][tap=ky*3+kx][g 0..3][COB][16 bytes], element e of (.., g, col, .) = W[cout_blk*COB+ch(col)][chunk*CH*4+g*CH+e][ky][kx],
    *       CH = 8 bf16 / 4 fp32, COB = 16*COT, and 24 = COT (4 if Cout%64==0, else 2 if Cout%32==0, else 1).  Row col = c*16 + 4*q + r
    *       (MFMA tile c, accumulator lane group q, register r) carries channel ch(col) = q*4*COT + c*4 + r, so that a lane's 4*COT
-   *       outputs of one pixel are consecutive channels (16-byte stores; a pixel's four lanes write one whole line) */
+   *       outputs of one pixel are consecutive channels (16-byte stores; a pixel's four lanes write one whole line).
+   *    p 6,7 (LDS 3x3 only, optional) fused 1x1 tail: 6 = W2 [i22 = 32][Cout = 64] row-major in the op dtype (bf16), 7 = bias2 f32[32]; the op
+   *       then writes y = act(W2 * act(conv(x) + bias) + bias2) (32 channels) and the 64-channel intermediate never reaches memory
+   *       (Proto.cv2 + Proto.cv3 at predict time); refused unless the persistent weights-resident kernel can take it */
   MSL_OP_CONV = 1,
   /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
    * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y

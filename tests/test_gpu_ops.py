@@ -631,3 +631,35 @@ def test_slice_extract_device_matches_host_restatement(plano, mejora, demo_volum
             assert got[j].shape == want.shape, (got[j].shape, want.shape)
             nd = int((got[j] != want).sum())
             assert nd == 0, f"{plano} slice {i} {mejora}: {nd} differing bytes, max |d| {int(np.abs(got[j].astype(int) - want.astype(int)).max())}"
+
+
+def test_conv3x3_with_fused_1x1_tail():
+    """MSL_OP_CONV p[6]/p[7]: y = SiLU(W2 · SiLU(conv3x3(x) + b) + b2) in one launch of the persistent 3x3 kernel (Proto.cv2 + Proto.cv3 at
+    predict time; bf16, 64 -> 64 -> 32) against the two-step fp32 reference with the intermediate rounded to bf16 as the unfused layers store it."""
+    dtype = MSL_BF16
+    N, H, W, C, C2 = 11, 160, 152, 64, 32  # 11 * 20 * 5 = 1100 tiles: the persistent kernel's domain
+    g = torch.Generator().manual_seed(77)
+    xbuf = _rand_act((N, H, W, C), dtype, g)
+    w1 = ((torch.rand((C, C, 3, 3), generator=g) * 2 - 1) / (C * 9) ** 0.5).to(_tdt(dtype)).float()
+    b1 = torch.rand(C, generator=g) - 0.5
+    w2 = ((torch.rand((C2, C), generator=g) * 2 - 1) / C**0.5).to(_tdt(dtype)).float()
+    b2 = torch.rand(C2, generator=g) - 0.5
+    mid = F.silu(F.conv2d(xbuf.float().permute(0, 3, 1, 2), w1, b1, padding=1)).to(_tdt(dtype)).float()
+    ref = F.silu(F.conv2d(mid, w2[:, :, None, None], b2)).permute(0, 2, 3, 1)
+    wt, bt, m = E.pack_conv3x3_lds(w1, b1, dtype, DEV)
+    w2t, b2t, m2 = E.pack_gemm(w2, b2, dtype, DEV)
+    assert m2["Kpad"] == 64 and m2["Cout_pad"] == 32
+    xd = xbuf.to(DEV)
+    yd = torch.full((N, H, W, 48), 7.0, dtype=_tdt(dtype), device=DEV)  # 32 channels at offset 8 of a wider buffer
+    op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr(), 0, w2t.data_ptr(), b2t.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: C, 4: H, 5: W, 6: C, 7: 3, 8: 1, 9: 1, 10: C, 11: 0, 12: 48, 13: 8, 16: m["K"], 17: m["Kpad"], 18: 1, 19: 0, 20: 0,
+                           21: m["Cout_pad"], 22: C2, 24: m["cot"], 25: 1})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    out = yd.float().cpu()
+    _close(out[..., 8:40], ref, dtype, "conv3x3 + fused 1x1 tail")
+    assert (out[..., :8] == 7.0).all() and (out[..., 40:] == 7.0).all(), "fused tail wrote outside its channel slice"
+    # a tail the persistent kernel does not implement must be refused, not silently run unfused
+    op.i[22] = 16
+    with pytest.raises(hiplib.MslError):
+        hiplib.launch(op, _stream())

@@ -33,6 +33,8 @@ struct Conv3Args {
   int N, H, W, Cin, Ho, Wo, Cout;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int act, out_f32, tiles_x, tiles_y;
+  const char* w2;       // fused 1x1 tail (persistent kernel, bf16): weights [C2 = 32][Cout = 64] row-major, y = act(W2 * act(conv(x) + bias) + bias2)
+  const float* bias2;
   int lat, full_h, full_w;  // lat >= 0: output pixel (Y,X) is stored at (2Y + (lat&1), 2X + (lat>>1)) of a full_h x full_w image (parity class of a stride-2 input gradient)
   double* acc;  // optional BatchNorm accumulator f64[slots][2*Cout]: per-channel (sum, sum of squares) of the stored outputs
   int slots;
@@ -293,7 +295,7 @@ static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
 // its next unit, then runs the MFMAs of the current one; the second group runs one unit behind (two-chunk case), so the VALU-heavy
 // epilogue of one group (stores, SiLU, statistics: about as many issue cycles as the tile's MFMAs) overlaps the other group's MFMAs
 // on the same SIMDs.  BatchNorm statistics stay in registers over all tiles of a wave and are folded once at the end of the kernel.
-template <bool F32, int COT, int NCH>
+template <bool F32, int COT, int NCH, bool FUSE = false>
 __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int total_tiles, int steps) {
   using T = Tile3<1, 2>;
   constexpr int ES = F32 ? 4 : 2;
@@ -369,6 +371,20 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
 
+  // fused 1x1 tail (FUSE): the 3x3 result of a pixel never leaves the registers.  After bias + SiLU a lane holds the pixel's channels
+  // 16g .. 16g+15 — rounded to bf16 they ARE the B operand of a second MFMA whose K-step s uses, for k-group g, the channels 16g + 8s .. +7
+  // (any contraction order is fine as long as the weight operand uses the same one): W2 fragments are read straight from the row-major
+  // [32][64] matrix, rows permuted so that the lane ends up with 8 consecutive output channels (one 16-byte store).
+  uint4 a2[2][2];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch2 = (lp >> 2) * 8 + t2 * 4 + (lp & 3);
+        a2[t2][ks] = *(const uint4*)(a.w2 + ((long)ch2 * 64 + 16 * g + 8 * ks) * 2);
+      }
+  }
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   // staging state: the tile whose units are being staged
   const char* st_img = a.x;
@@ -442,8 +458,44 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
       const int oy = oy0 + wave * 2 + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
-      if (oy < a.Ho && ox < a.Wo) {
-        const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+      const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+      if constexpr (FUSE) {
+        static_assert(!FUSE || (COT == 4 && !F32), "fused tail: 64 bf16 channels");
+        uint4 bq[2];  // K-steps 0, 1: channels 16g + 0..7, 16g + 8..15 of this pixel as bf16 (what the unfused layer would have stored)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = ks * 2 + h;
+            const float4 b4 = *(const float4*)(a.bias + g * 16 + c * 4);
+            v[h * 4 + 0] = acc[c][p][0] + b4.x; v[h * 4 + 1] = acc[c][p][1] + b4.y; v[h * 4 + 2] = acc[c][p][2] + b4.z; v[h * 4 + 3] = acc[c][p][3] + b4.w;
+          }
+          if (a.act == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+          }
+          bq[ks].x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+          bq[ks].y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+          bq[ks].z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
+          bq[ks].w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+        }
+        float o[8];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2[t2][ks]), __builtin_bit_cast(bf16x8, bq[ks]), d, 0, 0, 0);
+          const float4 b4 = *(const float4*)(a.bias2 + g * 8 + t2 * 4);
+          o[t2 * 4 + 0] = d[0] + b4.x; o[t2 * 4 + 1] = d[1] + b4.y; o[t2 * 4 + 2] = d[2] + b4.z; o[t2 * 4 + 3] = d[3] + b4.w;
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = silu_f(o[i]);
+        }
+        if (oy < a.Ho && ox < a.Wo) stv<false, 8>(a.y, pix * a.y_cs + a.y_co + g * 8, o);
+      } else if (oy < a.Ho && ox < a.Wo) {
         f32x4 accp[COT];
 #pragma unroll
         for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
@@ -501,14 +553,14 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   }
 }
 
-template <bool F32, int COT, int NCH>
+template <bool F32, int COT, int NCH, bool FUSE = false>
 static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<1, 2>;
   constexpr int LDS = NCH * 9 * 4 * COT * 16 * 16 + 4 * T::PIECES * 1024;
   static_assert(LDS <= 160 * 1024, "conv3x3_pers: LDS");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   const long tiles = (long)a.N * a.tiles_y * a.tiles_x;
@@ -518,7 +570,7 @@ static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   long busiest = (tiles + 2 * wgs - 1) / (2 * wgs);  // tiles of the busiest wave group
   if ((wgs & 7) == 0) { const long per = (tiles + 7) / 8, g2 = wgs / 4; busiest = (per + g2 - 1) / g2; }
   const int steps = (int)busiest * NCH;
-  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
+  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH, FUSE>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
   MSL_CHECK_LAUNCH("conv3x3_pers");
   return MSL_OK;
 }
@@ -532,6 +584,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
   a.act = op.i[18]; a.out_f32 = op.i[19];
   a.lat = -1; a.full_h = a.full_w = 0;
+  a.w2 = (const char*)op.p[6]; a.bias2 = (const float*)op.p[7];
   if (op.i[20] == 2) {
     // One parity class of a stride-2 3x3 input gradient: stride-1, pad-0 pass over the gradient (H, W) with a 1x1 / 1x2 / 2x1 / 2x2 kernel
     // (zero beyond the bottom / right edge), outputs on the sub-lattice (2Y + a, 2X + b) of the full image — same op contract as the generic
@@ -577,7 +630,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const int cot = op.i[24];  // channel tiles per workgroup = how the host packed the weight image (4 for Cout % 64 == 0, else 2 or 1)
   MSL_REQUIRE((cot == 4 || cot == 2 || cot == 1) && (a.Cout % (16 * cot) == 0 || (a.Cout == 8 && cot == 1)), "conv3x3_lds: weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
   const int oal = cot == 1 ? 4 : 8;  // a lane stores runs of 4*COT consecutive channels with 8- / 16-byte accesses
-  MSL_REQUIRE((a.Cout % 16 == 0 || a.Cout == 8) && a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + a.Cout <= a.y_cs, "conv3x3_lds: output view must be %d-channel aligned", oal);
+  MSL_REQUIRE((a.Cout % 16 == 0 || a.Cout == 8) && a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + (a.w2 ? op.i[22] : a.Cout) <= a.y_cs, "conv3x3_lds: output view must be %d-channel aligned", oal);
   if (a.res) MSL_REQUIRE(a.res_cs % oal == 0 && a.res_co % oal == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
   const int cout_blocks = (a.Cout + 16 * cot - 1) / (16 * cot);  // Cout = 8: one block of 16 rows, the upper 8 zero
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
@@ -594,6 +647,12 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     // measured per layer (batch 128): ahead for full 64-channel blocks over whole chunks (64->64 @160²: 0.31 vs 0.35 ms with the statistics
     // epilogue), behind for narrow blocks / partial chunks, where a unit holds too few MFMAs to pay for its barrier
     const bool pays = cot == 4 && a.Cin % chunk == 0 && tiles >= 1024;
+    if (a.w2) {  // fused 1x1 tail: only the persistent bf16 64 -> 64 (two chunks) -> 32 form exists; anything else is refused, never run unfused
+      MSL_REQUIRE(!f32 && stride == 1 && rw == 2 && nch == 2 && fits && cot == 4 && a.Cout == 64 && cout_blocks == 1 && op.i[22] == 32 && a.bias2 && !a.res && !a.acc &&
+                      !a.out_f32 && a.y_cs % 8 == 0 && a.y_co % 8 == 0 && a.y_co + 32 <= a.y_cs,
+                  "conv3x3 + fused 1x1 tail: needs bf16, stride 1, Cin = Cout = 64, 32 tail channels, plain bf16 output view");
+      return launch3p<false, 4, 2, true>(a, cout_blocks, s);
+    }
     if (stride == 1 && rw == 2 && nch <= 2 && fits && (pays || op.i[23] == -9) && op.i[23] != -8) {
 #define L3P(F, NCH_)                                                       \
   do {                                                                     \

@@ -192,6 +192,8 @@ class ProgramBuilder(graph.Visitor):
         y = out if out is not None else self._new(Ho, Wo, cout, f32=f32_out)
         assert (y.H, y.W, y.C) == (Ho, Wo, cout), (name, (y.H, y.W, y.C), (Ho, Wo, cout))
         wt, bt, m = self.w.t[name]
+        if self._fuse_into_previous_3x3(name, x, y, cout, k, s, act, res, f32_out, wt, bt, m):
+            return y
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
              16: m["K"], 17: m["Kpad"], 18: 1 if act else 0, 19: 1 if f32_out else 0, 20: 0, 21: m["Cout_pad"],
              24: m.get("cot", 0), 25: m.get("lds", 0)}
@@ -202,6 +204,27 @@ class ProgramBuilder(graph.Visitor):
         self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), rp, y.t.data_ptr()), i=i))
         self.taps[name] = y
         return y
+
+    def _fuse_into_previous_3x3(self, name, x, y, cout, k, s, act, res, f32_out, wt, bt, m) -> bool:
+        """Proto.cv3 (1x1, 64 -> 32) rides in the epilogue of Proto.cv2 (3x3, 64 -> 64) when that layer runs in the persistent weights-resident
+        kernel (include/mslesseg_hip.h, MSL_OP_CONV p 6/7): the 160x160x64 intermediate — 6.6 MB per slice written and read back — never
+        reaches HBM.  Same conditions as the kernel's own dispatch rule (msl_launch_conv3x3_lds); anything else stays two ops."""
+        if not (name.endswith(".proto.cv3") and self.ops and self.names[-1].endswith(".proto.cv2") and self.dtype == MSL_BF16):
+            return False
+        prev = self.ops[-1]
+        tiles = self.N * ((x.W + 31) // 32) * ((x.H + 7) // 8)
+        ok = (k == 1 and s == 1 and act and res is None and not f32_out and cout == 32 and x.C == 64 and x.cs == 64 and x.co == 0
+              and prev.kind == hiplib.OP_CONV and prev.i[25] == 1 and prev.i[24] == 4 and prev.i[3] == 64 and prev.i[6] == 64 and prev.i[7] == 3 and prev.i[8] == 1
+              and prev.i[18] == 1 and not prev.p[3] and prev.p[4] == x.t.data_ptr() and tiles >= 1024 and m.get("Kpad") == 64 and m.get("Cout_pad") == 32
+              and y.cs % 8 == 0 and y.co % 8 == 0)
+        if not ok:
+            return False
+        prev.p[6], prev.p[7], prev.p[4] = wt.data_ptr(), bt.data_ptr(), y.t.data_ptr()
+        prev.i[12], prev.i[13], prev.i[22] = y.cs, y.co, 32
+        self.taps.pop(self.names[-1], None)  # the 64-channel intermediate is never written
+        self.names[-1] = self.names[-1] + "+cv3"
+        self.taps[name] = y
+        return True
 
     def convT2x2(self, name, x, cout):
         y = self._new(2 * x.H, 2 * x.W, cout)
