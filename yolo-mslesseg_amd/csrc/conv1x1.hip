@@ -27,6 +27,8 @@ struct C1Args {
   double* acc;        // [slots][2*Cout] or NULL
   long M;
   int Cin, Cout, Kpad, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, slots, w_rows;
+  int shuffle, H, W;  // shuffle = 1: pixel-shuffle store of a ConvTranspose2d k2 s2 run as a 1x1 GEMM — channel q*C + c (C = Cout/4, q = dy*2 + dx) of
+                      // pixel (y, x) goes to channel c of pixel (2y + dy, 2x + dx) of the 2H x 2W output (same contract as conv_igemm's store mode 1)
 };
 
 template <int NCP, bool STATS, int PT>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
@@ -142,8 +144,15 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] += rv[r];
         }
-        if (a.out_f32) stv<true, 8>(a.y, p * a.y_cs + a.y_co + c0, v);
-        else stv<false, 8>(a.y, p * a.y_cs + a.y_co + c0, v);
+        long oi = p * a.y_cs + a.y_co + c0;
+        if (a.shuffle) {  // an 8-channel run never straddles a quadrant (Cout/4 is a multiple of 8)
+          const int C4 = a.Cout >> 2, q = c0 / C4;
+          const long n = p / ((long)a.H * a.W);
+          const int r = (int)(p - n * a.H * a.W), oy = r / a.W, ox = r - oy * a.W;
+          oi = ((n * (2 * a.H) + 2 * oy + (q >> 1)) * (2 * a.W) + 2 * ox + (q & 1)) * a.y_cs + a.y_co + (c0 - q * C4);
+        }
+        if (a.out_f32) stv<true, 8>(a.y, oi, v);
+        else stv<false, 8>(a.y, oi, v);
       }
     }
     buf ^= 1;
@@ -188,7 +197,8 @@ static const size_t C1_LDS_MAX = 150 * 1024;
 // Eligibility test used by msl_launch_conv (bf16, 1x1, stride 1, pad 0, plain store, everything a multiple of 8, weights + rings fit in LDS)
 bool msl_conv1x1_eligible(const msl_op& op) {
   const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
-  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0) return false;
+  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || (op.i[20] != 0 && op.i[20] != 1)) return false;
+  if (op.i[20] == 1 && (Cout % 32 || op.p[3] || op.p[5])) return false;  // pixel-shuffle store: whole 8-channel runs per quadrant, no residual / statistics
   if (Cin % 8 || Cout % 8 || Kpad % 32 || Kpad < Cin || Cout > 256) return false;
   if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) return false;
   if (op.p[3] && ((op.i[14] | op.i[15]) & 7)) return false;
@@ -233,7 +243,8 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   a.act = op.i[18]; a.out_f32 = op.i[19]; a.slots = op.i[23] > 0 ? op.i[23] : 1;
   a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
   MSL_REQUIRE(a.x && a.w && a.y && a.M > 0 && msl_conv1x1_eligible(op), "conv1x1: bad args");
-  MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs, "conv1x1: bad dims / views");
+  a.shuffle = op.i[20] == 1; a.H = op.i[1]; a.W = op.i[2];
+  MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + (a.shuffle ? a.Cout / 4 : a.Cout) <= a.y_cs, "conv1x1: bad dims / views");
   MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
 #define C1(N) case N: return a.acc ? c1_launch_pt<N, true>(a, s) : c1_launch_pt<N, false>(a, s)
