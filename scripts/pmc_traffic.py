@@ -41,31 +41,38 @@ def main():
         replay = bench["roofline"]["replay"]
         mine = [r for r in rows if r["Counter_Name"] == counter]
         mine.sort(key=lambda r: int(r["Dispatch_Id"]))
-        # the replayed ops are the last dispatches of the process; an op may launch helper kernels (e.g. the partial-sum reduction after a
-        # weight-gradient kernel), so walk backwards and pick K dispatches of each record's own kernel.  The replay ORDER is by measured
-        # launch time and can differ between the two passes: results are keyed by (kernel label, launch shape), not by position.
-        pos, found = len(mine), {}
-        for rp in reversed(replay):
-            base = rp["kernel"].split("<")[0].split(" ")[0]
-            g = []
-            while pos > 0 and len(g) < K:
-                pos -= 1
-                if base in mine[pos]["Kernel_Name"]:
-                    g.append(mine[pos])
-            if len(g) < K or len({(r["Kernel_Name"], r["Grid_Size"]) for r in g}) != 1:
-                sys.exit(f"{counter}: could not isolate {K} launches of {base}: {[(r['Dispatch_Id'], r['Kernel_Name'][:40], r['Grid_Size']) for r in g]}")
+        # the replayed records are the last dispatches of the process, each preceded by a sentinel launch (`ema_kernel`, bench.py): cut the tail
+        # of the dispatch list at the last len(replay) sentinels → one segment per record.  Inside a segment the op's own kernel is the
+        # (name, grid) group with exactly K dispatches and the largest counter total (an op may launch helpers, e.g. the partial-sum
+        # reduction after a weight-gradient kernel).  The replay ORDER is by measured time and can differ between the two passes: results are
+        # keyed by (kernel label, launch shape), not by position.
+        sent = [i for i, r in enumerate(mine) if "ema_kernel" in r["Kernel_Name"]]
+        if len(sent) < len(replay):
+            sys.exit(f"{counter}: {len(sent)} sentinel dispatches for {len(replay)} replayed records")
+        cuts = sent[-len(replay):] + [len(mine)]
+        found = {}
+        for j, rp in enumerate(replay):
+            seg = mine[cuts[j] + 1 : cuts[j + 1]]
+            groups = {}
+            for r in seg:
+                groups.setdefault((r["Kernel_Name"], r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+            full = {k: v for k, v in groups.items() if len(v) == K}
+            if not full:
+                sys.exit(f"{counter}: no kernel with {K} dispatches in the segment of {rp['kernel']}: {[(k[0][:40], k[1], len(v)) for k, v in groups.items()]}")
+            (name, grid), vals = max(full.items(), key=lambda kv: sum(kv[1]))
             key = (rp["kernel"], json.dumps(rp["launch_shape"], sort_keys=True))
-            found[key] = (sum(float(r["Counter_Value"]) for r in g) / K * 1024.0, g[0]["Kernel_Name"], g[0]["Grid_Size"], rp)
+            found[key] = (sum(vals) / K * 1024.0, name, grid, rp, {k: sum(v) / K * 1024.0 for k, v in full.items()})
         per_counter[counter] = found
-        order = order or list(found)[::-1]
+        order = order or list(found)
     records = []
     for key in order:
         if key not in per_counter["WRITE_SIZE"]:
             continue  # replayed in one pass only (family representatives can differ): no complete figure
-        fetch, name, grid, rp = per_counter["FETCH_SIZE"][key]
-        write, name_w, _, _ = per_counter["WRITE_SIZE"][key]
-        if name != name_w:
-            sys.exit(f"passes disagree on the kernel of {key}: {name} vs {name_w}")
+        fetch, name, grid, rp, _ = per_counter["FETCH_SIZE"][key]
+        wgroups = per_counter["WRITE_SIZE"][key][4]
+        if (name, grid) not in wgroups:  # the kernel that fetched the most must also be in the other pass's segment
+            sys.exit(f"passes disagree on the kernel of {key}: {name} / {grid} not among {[(k[0][:40], k[1]) for k in wgroups]}")
+        write = wgroups[(name, grid)]
         records.append({"kernel": rp["kernel"], "launch_shape": rp["launch_shape"], "traffic_bytes_per_launch": round(2.0 * fetch + write),
                         "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write), "dispatch_kernel_name": name, "grid_size": grid,
                         "note": "rocprofv3 --pmc, two passes, mean of 5 replayed launches; FETCH_SIZE doubled (gfx950), both counters KiB -> bytes"})
