@@ -182,20 +182,25 @@ def test_conv_rejects_bad_descriptor():
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 @pytest.mark.parametrize("cout", [16, 32])
 def test_stem(dtype, cout):
-    g = torch.Generator().manual_seed(7)
-    N, H, W = 2, 64, 96
-    img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
-    w = (torch.rand((cout, 3, 3, 3), generator=g) * 2 - 1) / 27**0.5
-    b = torch.rand(cout, generator=g) - 0.5
-    ref = F.silu(F.conv2d(img.float().permute(0, 3, 1, 2) / 255, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
-    wd = w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV)
-    bd, xd = b.to(DEV), img.to(DEV)
-    yd = torch.zeros((N, H // 2, W // 2, cout), dtype=_tdt(dtype), device=DEV)
-    op = hiplib.make_op(hiplib.OP_STEM, dtype, p=(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 0, yd.data_ptr()),
-                        i={0: N, 1: H, 2: W, 4: H // 2, 5: W // 2, 6: cout, 12: cout, 13: 0, 18: 1})
-    hiplib.launch(op, _stream())
-    torch.cuda.synchronize()
-    _close(yd, ref, dtype, "stem")
+    for N, H, W in ((2, 64, 96), (3, 45, 71), (1, 17, 130)):  # even; odd sizes with rows that are not dword multiples; one wide tile row
+        g = torch.Generator().manual_seed(7 + H)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+        w = (torch.rand((cout, 3, 3, 3), generator=g) * 2 - 1) / 27**0.5
+        b = torch.rand(cout, generator=g) - 0.5
+        ref = F.silu(F.conv2d(img.float().permute(0, 3, 1, 2) / 255, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
+        wd = w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV)
+        bd, xd = b.to(DEV), img.to(DEV)
+        outs = []
+        for form in (0, 9):  # LDS-tile kernel, thread-per-pixel kernel (i[19] = 9)
+            yd = torch.zeros((N, Ho, Wo, cout), dtype=_tdt(dtype), device=DEV)
+            op = hiplib.make_op(hiplib.OP_STEM, dtype, p=(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 0, yd.data_ptr()),
+                                i={0: N, 1: H, 2: W, 4: Ho, 5: Wo, 6: cout, 12: cout, 13: 0, 18: 1, 19: form})
+            hiplib.launch(op, _stream())
+            torch.cuda.synchronize()
+            _close(yd, ref, dtype, f"stem {(N, H, W)} form {form}")
+            outs.append(yd.float().cpu())
+        assert torch.equal(outs[0], outs[1]), "the two stem kernels must agree bit for bit (same taps, same fma order)"
 
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])

@@ -45,12 +45,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ x
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci) {
         const float v = lut[px[ci]];
-        const float* wr = sw + ((ky * 3 + kx) * 3 + ci) * COUT;
+        const float* wr = w + ((ky * 3 + kx) * 3 + ci) * COUT;  // wave-uniform address: scalar loads, the weight is an SGPR operand of the fma
 #pragma unroll
-        for (int c = 0; c < COUT; c += 4) {
-          const float4 w4 = *(const float4*)(wr + c);
-          acc[c] = fmaf(v, w4.x, acc[c]); acc[c + 1] = fmaf(v, w4.y, acc[c + 1]); acc[c + 2] = fmaf(v, w4.z, acc[c + 2]); acc[c + 3] = fmaf(v, w4.w, acc[c + 3]);
-        }
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
       }
     }
   }
@@ -66,6 +63,87 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ x
   }
 }
 
+// Tile form: a workgroup owns 8 x 32 output pixels and first copies its 17 x 65-pixel input patch into LDS with aligned dword loads
+// (coalesced: 200 contiguous bytes per image row) — the thread-per-pixel form above issues 27 single-byte global loads per pixel, one
+// address per lane, and is bound by them.  Bytes are then picked from LDS (per row and pixel: 9 consecutive bytes), the weights come in as
+// scalar loads (SGPR operands of packed fmas).  Same taps skipped at the border, same fma order per channel: bit-identical results.
+template <bool F32, int COUT>
+__global__ __launch_bounds__(256) void stem_tile_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        void* __restrict__ y, int N, int H, int W, int Ho, int Wo, int y_cs, int y_co, int act,
+                                                        int tiles_x, int tiles_y) {
+  constexpr int TH = 8, TW = 32, ROWS = 2 * TH + 1, RD = 52;  // 52 dwords per LDS row: 65 pixels x 3 bytes + up to 3 bytes of alignment slack
+  __shared__ uint32_t tile[ROWS * RD];
+  __shared__ float lut[256];
+  lut[threadIdx.x] = (float)threadIdx.x / 255.0f;  // exact IEEE division, as torch `im / 255`
+  int bid = (int)xcd_block(blockIdx.x, gridDim.x);
+  const int txi = bid % tiles_x; bid /= tiles_x;
+  const int tyi = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const long img0 = (long)n * H * W * 3, total = (long)N * H * W * 3;
+  for (int i = threadIdx.x; i < ROWS * 50; i += 256) {
+    const int r = i / 50, d = i - r * 50;
+    const int iy = 2 * oy0 - 1 + r;
+    uint32_t v = 0;
+    if ((unsigned)iy < (unsigned)H) {
+      const long b0 = img0 + ((long)iy * W + (2 * ox0 - 1)) * 3;  // first byte of the patch row (may point one pixel left of the image)
+      const long off = (b0 & ~3L) + 4 * d;
+      if (off >= 0 && off + 4 <= total) v = *(const uint32_t*)(x + off);
+      else {
+        for (int j = 0; j < 4; ++j)
+          if (off + j >= 0 && off + j < total) v |= (uint32_t)x[off + j] << (8 * j);
+      }
+    }
+    tile[r * RD + d] = v;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+  const int oy = oy0 + ly, ox = ox0 + lx;
+  if (oy >= Ho || ox >= Wo) return;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    const long b0 = img0 + ((long)iy * W + (2 * ox0 - 1)) * 3;
+    const uint8_t* rowp = (const uint8_t*)tile + (2 * ly + ky) * (RD * 4) + (int)(b0 & 3) + 6 * lx;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float v = lut[rowp[kx * 3 + ci]];
+        const float* wr = w + ((ky * 3 + kx) * 3 + ci) * COUT;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+      }
+    }
+  }
+  const long oi = (((long)n * Ho + oy) * Wo + ox) * y_cs + y_co;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = silu_f(acc[c]);
+  }
+  if (((y_cs | y_co) & 7) == 0) {  // 16-byte stores (fp32: 2 x 16)
+#pragma unroll
+    for (int c = 0; c < COUT; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = acc[c + q];
+      stv<F32, 8>(y, oi + c, v);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) {
+      float v[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+      st4<F32>(y, oi + c, v);
+    }
+  }
+}
+
 int msl_launch_stem(const msl_op& op, hipStream_t s) {
   const uint8_t* x = (const uint8_t*)op.p[0];
   const float* w = (const float*)op.p[1];
@@ -76,9 +154,19 @@ int msl_launch_stem(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(N > 0 && H > 0 && W > 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "stem: bad dims");
   MSL_REQUIRE(Cout == 16 || Cout == 32, "stem: Cout=%d unsupported (16|32)", Cout);
   MSL_REQUIRE(y_cs % 4 == 0 && y_co % 4 == 0 && y_co + Cout <= y_cs, "stem: bad output view");
+  const bool f32 = op.dtype == MSL_F32;
+  if (op.i[19] != 9 && ((uintptr_t)x & 3) == 0) {  // tile kernel (i[19] = 9 keeps the thread-per-pixel form: A/B tests)
+    const int tiles_x = (Wo + 31) / 32, tiles_y = (Ho + 7) / 8;
+    const unsigned tgrid = (unsigned)((long)N * tiles_x * tiles_y);
+#define STEMT(F, C) hipLaunchKernelGGL((stem_tile_kernel<F, C>), dim3(tgrid), dim3(256), 0, s, x, w, b, y, N, H, W, Ho, Wo, y_cs, y_co, act, tiles_x, tiles_y)
+    if (f32) { if (Cout == 16) STEMT(true, 16); else STEMT(true, 32); }
+    else     { if (Cout == 16) STEMT(false, 16); else STEMT(false, 32); }
+#undef STEMT
+    MSL_CHECK_LAUNCH("stem_tile");
+    return MSL_OK;
+  }
   long M = (long)N * Ho * Wo;
   unsigned grid = (unsigned)((M + 255) / 256);
-  const bool f32 = op.dtype == MSL_F32;
 #define STEM(F, C) hipLaunchKernelGGL((stem_kernel<F, C>), dim3(grid), dim3(256), 0, s, x, w, b, y, N, H, W, Ho, Wo, y_cs, y_co, act)
   if (f32) { if (Cout == 16) STEM(true, 16); else STEM(true, 32); }
   else     { if (Cout == 16) STEM(false, 16); else STEM(false, 32); }
