@@ -936,32 +936,66 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const uint8_t* __r
     for (int j = 0; j < NT; ++j) acc[tt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int segs = (Wo + 31) / 32;
   const long total = (long)N * Ho * segs;
+  // Per segment a wave first copies its inputs into a private LDS patch with wide coalesced loads — 3 image rows of 65 pixels as aligned dwords and
+  // the 32 x COUT gradient tile as 16-byte pieces — and then picks the operand bytes / halfwords from LDS: the direct form issued 16 single-byte and
+  // 8*NT two-byte global loads per lane and segment, one address per lane, and was bound by them.  Same values, same accumulation order.
+  __shared__ uint32_t s_img[4][3 * 52];
+  __shared__ uint4 s_dz[4][32 * COUT / 8];
+  const long xbytes = (long)N * H * W * 3;
   for (long seg = (long)blockIdx.x * 4 + wave; seg < total; seg += (long)gridDim.x * 4) {  // wave-uniform
-    const int row = (int)(seg / segs), ox0 = (int)(seg - (long)row * segs) * 32 + 8 * g;
+    const int row = (int)(seg / segs), xs = (int)(seg - (long)row * segs) * 32, ox0 = xs + 8 * g;
     const int n = row / Ho, oy = row - n * Ho;
+    __builtin_amdgcn_wave_barrier();  // the previous segment's operand reads are done (LDS executes a wave's instructions in order)
+    for (int i = lane; i < 150; i += 64) {
+      const int r = i / 50, d = i - r * 50;
+      const int iy = oy * 2 - 1 + r;
+      uint32_t v = 0;
+      if ((unsigned)iy < (unsigned)H) {
+        const long b0 = (((long)n * H + iy) * W + (2 * xs - 1)) * 3;
+        const long off = (b0 & ~3L) + 4 * d;
+        if (off >= 0 && off + 4 <= xbytes) v = *(const uint32_t*)(x + off);
+        else {
+          for (int j = 0; j < 4; ++j)
+            if (off + j >= 0 && off + j < xbytes) v |= (uint32_t)x[off + j] << (8 * j);
+        }
+      }
+      s_img[wave][r * 52 + d] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int idx = lane + 64 * k, px = idx / (COUT / 8), ch = (idx - px * (COUT / 8)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (xs + px < Wo) v = *(const uint4*)(dz + ((long)row * Wo + xs + px) * z_cs + z_co + ch);
+      s_dz[wave][idx] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 a[2], b[NT];
+    const uint8_t* pimg = (const uint8_t*)s_img[wave];
+    const unsigned short* pdz = (const unsigned short*)s_dz[wave];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int iy = oy * 2 - 1 + ky[tt];
       const bool rowok = tv[tt] && (unsigned)iy < (unsigned)H;
-      const uint8_t* xr = x + ((long)n * H + (rowok ? iy : 0)) * W * 3 + ci[tt];
+      const long b0 = (((long)n * H + iy) * W + (2 * xs - 1)) * 3;
+      const uint8_t* xr = pimg + ky[tt] * 208 + (int)(b0 & 3) + ci[tt];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ix = (ox0 + j) * 2 - 1 + kx[tt];
-        const float v = (rowok && ox0 + j < Wo && (unsigned)ix < (unsigned)W) ? (float)xr[ix * 3] : 0.f;
+        const float v = (rowok && ox0 + j < Wo && (unsigned)ix < (unsigned)W) ? (float)xr[((8 * g + j) * 2 + kx[tt]) * 3] : 0.f;
         a[tt][j] = (short)f32_to_bf16_bits(v);
       }
     }
 #pragma unroll
     for (int c = 0; c < NT; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[c][j] = (ox0 + j < Wo) ? (short)dz[((long)row * Wo + ox0 + j) * z_cs + z_co + c * 16 + li] : (short)0;
+      for (int j = 0; j < 8; ++j) b[c][j] = (short)pdz[(8 * g + j) * COUT + c * 16 + li];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int c = 0; c < NT; ++c) acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tt]), __builtin_bit_cast(bf16x8, b[c]), acc[tt][c], 0, 0, 0);
   }
+  __syncthreads();
   // fold the 4 waves, then D[row = tap 4g+r (+16 tt)][col = co li]
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -1001,7 +1035,9 @@ int msl_launch_stem_wgrad(const msl_op& op, hipStream_t s) {
   if (scratch && bx * 27 * Cout > (long)op.i[21]) bx = (long)op.i[21] / (27L * Cout);
   MSL_REQUIRE(bx >= 1, "stem_wgrad: scratch too small");
 #define SW(F, CO) hipLaunchKernelGGL((stem_wgrad_kernel<F, CO>), dim3((unsigned)bx), dim3(256), 0, s, (const uint8_t*)op.p[0], op.p[1], (float*)op.p[4], N, H, W, Ho, Wo, op.i[12], op.i[13], scratch)
+  const bool wide_ok = ((op.i[12] | op.i[13]) & 7) == 0 && ((uintptr_t)op.p[0] & 3) == 0 && ((uintptr_t)op.p[1] & 15) == 0;  // 16-byte gradient pieces, dword image loads
   if (op.dtype == MSL_F32) { if (Cout == 16) SW(true, 16); else SW(true, 32); }
+  else if (!wide_ok) { if (Cout == 16) SW(false, 16); else SW(false, 32); }
   else {
     bx = (M / 32 + 4 * 16 - 1) / (4 * 16);  // >= 16 segments of 32 pixels per wave
     if (bx > 2048) bx = 2048;
