@@ -523,6 +523,36 @@ def test_stride2_input_gradient_parity_classes_lds_kernel(case):
     _close(gx.cpu(), ref, dtype, f"s2 dgrad (LDS kernel) {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1), (2, 70, 41, 64, 64, 1), (1, 33, 66, 8, 32, 0), (3, 40, 40, 16, 32, 1)])
+def test_stride2_input_gradient_all_classes_one_pass(case):
+    """MSL_OP_CONV store mode 3: the whole 3x3 / stride-2 / pad-1 input gradient (four parity classes) in one launch of the LDS-tiled kernel
+    (weights = 3x3 LDS image of the transposed weight, at most two channel tiles), with and without accumulation into the gradient view."""
+    from mslesseg_amd import trainprog as TP
+
+    dtype = MSL_BF16
+    N, H, W, Cin, Cout, accumulate = case
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cout * 9) ** 0.5).to(_tdt(dtype)).float()
+    dz = _rand_act((N, Ho, Wo, Cout), dtype, g)
+    prev = _rand_act((N, H, W, Cin), dtype, g)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dz.float().permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    if accumulate:
+        ref = ref + prev.float()
+    dzd, gx = dz.to(DEV), prev.clone().to(DEV)
+    zeros = torch.zeros(Cin, device=DEV)
+    flat = w.reshape(-1)
+    idx4 = torch.arange(flat.numel()).view(Cout, Cin, 3, 3)
+    cidx, m = TP._lds_image_idx(idx4.permute(1, 0, 2, 3), dtype, max_cot=2)
+    img = torch.where(cidx >= 0, flat[cidx.clamp(min=0).long()], torch.zeros(())).to(_tdt(dtype)).to(DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(dzd.data_ptr(), img.data_ptr(), zeros.data_ptr(), gx.data_ptr() if accumulate else 0, gx.data_ptr()),
+                        i={0: N, 1: Ho, 2: Wo, 3: Cout, 4: H, 5: W, 6: Cin, 7: 3, 8: 1, 9: 1, 10: Cout, 11: 0, 12: Cin, 13: 0, 14: Cin, 15: 0, 16: m["K"], 17: m["Kpad"],
+                           18: 0, 19: 0, 20: 3, 21: m["Cout_pad"], 24: m["cot"], 25: 1})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    _close(gx.cpu(), ref, dtype, f"s2 dgrad, one pass {case}")
+
+
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 @pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1)])
 def test_stride2_input_gradient_as_parity_classes(case, dtype):

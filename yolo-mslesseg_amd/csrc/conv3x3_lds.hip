@@ -575,6 +575,143 @@ static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   return MSL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Input gradient of a 3x3 / stride 2 / pad 1 convolution, all four parity classes in ONE pass (bf16).  dx[2Y+a][2X+b] only receives the
+// taps ky = 1 (a = 0) or ky in {2, 0} (a = 1; sources dz[Y], dz[Y+1]), and likewise kx for b — a 1x1, 1x2, 2x1 and 2x2 kernel over dz.
+// Run as four separate passes (store mode 2 above) the gradient tile is staged four times and every 128-byte line of dx is written
+// in quarters by different launches.  Here a workgroup stages a (8+1) x (32+1) tile of dz once per 64-byte channel chunk together
+// with all nine taps of the weight block, keeps one accumulator set per class (4 x COT x 4 pixel tiles), and writes the 2 x 2 output
+// pixels of every gradient pixel back to back.  Weights: the 3x3 LDS image of the transposed weight [ci][co][ky][kx] (no tap flip),
+// output channels = the forward input channels.  Op contract: MSL_OP_CONV, i[20] = 3, i[7] = 3, i[8] = 1; (H, W) = dz, (Ho, Wo) = dx.
+template <int COT>
+__global__ __launch_bounds__(256, 2) void conv_s2dgrad_lds_kernel(Conv3Args a) {  // <= 256 registers: two workgroups per CU overlap staging and MFMAs
+  using T = Tile3<1, 2, 2>;  // 8 x 32 gradient pixels, halo 9 rows x 33 (pitch 34) columns
+  constexpr int ES = 2, CHUNK = 32, COB = COT * 16, PT = 4;
+  constexpr int IN_BYTES = T::PIECES * 1024;
+  constexpr int W_BYTES = 9 * 4 * COB * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;
+  unsigned char* s_w = smem + IN_BYTES;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lp = lane & 15, g = lane >> 4;
+  int bid = (int)xcd_block(blockIdx.x, gridDim.x);
+  const int txi = bid % a.tiles_x; bid /= a.tiles_x;
+  const int tyi = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+  const int Y0 = tyi * T::TH, X0 = txi * T::TW;
+  const int cob = blockIdx.y;
+
+  f32x4 acc[4][COT][PT];  // [class a*2+b]
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int p = 0; p < PT; ++p) acc[k][c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const char* ximg = a.x + ((long)n * a.H * a.W * a.x_cs + a.x_co) * ES;
+  const int nchunks = (a.Cin + CHUNK - 1) / CHUNK;
+  const char* wblk = a.w + (long)cob * nchunks * W_BYTES;
+  constexpr int IN_PER_WAVE = (T::PIECES + 3) / 4;
+  constexpr int W_PIECES = W_BYTES / 1024;
+  int in_off[IN_PER_WAVE];
+  {
+    const int row4 = lane >> 4, pos = lane & 15;
+    const int gq = ((pos & 3) - row4) & 3;
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      const int sl = pc * 16 + row4 * 4 + (pos >> 2);
+      const int r = sl / T::ROWP, c = sl - r * T::ROWP;
+      const int iy = Y0 + r, ix = X0 + c;  // no padding before the tile; zero beyond the bottom / right edge
+      const bool ok = pc < T::PIECES && sl < T::SLOTS && iy < a.H && ix < a.W && gq * (CHUNK / 4) < a.Cin;
+      in_off[j] = ok ? ((iy * a.W + ix) * a.x_cs) * ES + gq * 16 : -1;
+    }
+  }
+  const char* wlane = wblk + wave * 1024 + lane * 16;
+  // fragment addresses: rows wave*2 .. wave*2+2 of the halo x column shift 0|1; the second 16-pixel half is +1024 B
+  int baddr[3][2];
+#pragma unroll
+  for (int hr = 0; hr < 3; ++hr)
+#pragma unroll
+    for (int tx = 0; tx < 2; ++tx) baddr[hr][tx] = halo_byte((wave * 2 + hr) * T::ROWP + tx + lp, g);
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      if (pc < T::PIECES) {
+        const char* src = in_off[j] >= 0 ? ximg + in_off[j] + cc * (CHUNK * ES) : (const char*)msl_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(s_in + pc * 1024), 16, 0, 0);
+      }
+    }
+    const char* wsrc = wlane + (long)cc * W_BYTES;
+    for (int pc = wave; pc < W_PIECES; pc += 4, wsrc += 4096) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
+                                       (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // source offset (ty, tx) in {0,1}^2; the taps that read it: ky = 1 or 2 for ty = 0, ky = 0 for ty = 1 (same for kx / tx)
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        uint4 bv[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) bv[p] = *(const uint4*)(s_in + baddr[(p >> 1) + ty][tx] + (p & 1) * 1024);
+#pragma unroll
+        for (int iy = 0; iy < (ty ? 1 : 2); ++iy)
+#pragma unroll
+          for (int ix = 0; ix < (tx ? 1 : 2); ++ix) {
+            const int ky = ty ? 0 : 1 + iy, kx = tx ? 0 : 1 + ix;
+            const int cls = (ky != 1 ? 1 : 0) * 2 + (kx != 1 ? 1 : 0);  // a*2 + b
+            const int t = ky * 3 + kx;
+#pragma unroll
+            for (int c = 0; c < COT; ++c) {
+              const uint4 av = *(const uint4*)(s_w + (((t * 4 + g) * COB) + c * 16 + lp) * 16);
+#pragma unroll
+              for (int p = 0; p < PT; ++p)
+                acc[cls][c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv[p]), acc[cls][c][p], 0, 0, 0);
+            }
+          }
+      }
+  }
+  // ---- epilogue: the 2 x 2 output pixels of every gradient pixel (+ what the gradient view already holds)
+  float s1[COT][4], s2[COT][4];  // unused (no statistics here): store_pixel's signature
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    const int Y = Y0 + wave * 2 + (p >> 1), X = X0 + (p & 1) * 16 + lp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oy = 2 * Y + (k >> 1), ox = 2 * X + (k & 1);
+      if (oy >= a.Ho || ox >= a.Wo) continue;
+      const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+      f32x4 accp[COT];
+#pragma unroll
+      for (int c = 0; c < COT; ++c) accp[c] = acc[k][c][p];
+      store_pixel<false, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2);
+    }
+  }
+}
+
+template <int COT>
+static int launch_s2dgrad(const Conv3Args& a, int cout_blocks, hipStream_t s) {
+  using T = Tile3<1, 2, 2>;
+  constexpr int LDS = T::PIECES * 1024 + 9 * 4 * COT * 16 * 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_s2dgrad_lds_kernel<COT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x), (unsigned)cout_blocks);
+  hipLaunchKernelGGL((conv_s2dgrad_lds_kernel<COT>), grid, dim3(256), LDS, s, a);
+  MSL_CHECK_LAUNCH("conv_s2dgrad_lds");
+  return MSL_OK;
+}
+
 // Eligibility + dispatch; called from msl_launch_conv when op.i[25] == 1 (weights packed as the LDS image).
 int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   Conv3Args a;
@@ -585,6 +722,22 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   a.act = op.i[18]; a.out_f32 = op.i[19];
   a.lat = -1; a.full_h = a.full_w = 0;
   a.w2 = (const char*)op.p[6]; a.bias2 = (const float*)op.p[7];
+  if (op.i[20] == 3) {  // all four parity classes of a 3x3 / stride-2 / pad-1 input gradient in one pass (conv_s2dgrad_lds_kernel)
+    a.acc = nullptr; a.slots = 1;
+    MSL_REQUIRE(op.dtype == MSL_BF16 && !op.p[5] && !op.p[6] && !a.out_f32 && a.act == 0, "conv s2 dgrad (LDS): bf16, no statistics / tail / activation / fp32 output");
+    MSL_REQUIRE(a.x && a.w && a.bias && a.y && k == 3 && stride == 1 && a.N > 0 && a.H > 0 && a.W > 0 && a.H == (a.Ho + 2 - 3) / 2 + 1 && a.W == (a.Wo + 2 - 3) / 2 + 1,
+                "conv s2 dgrad (LDS): (H, W) = %dx%d must be the stride-2 output of (Ho, Wo) = %dx%d", a.H, a.W, a.Ho, a.Wo);
+    MSL_REQUIRE(a.Cin > 0 && a.Cin % 8 == 0 && (a.Cin % 32 == 0 || a.Cin < 32) && a.x_cs % 8 == 0 && a.x_co % 8 == 0 && a.x_co + a.Cin <= a.x_cs, "conv s2 dgrad (LDS): bad gradient view");
+    const int cot = op.i[24];  // 2 for Cout % 32 == 0, else 1 (the four accumulator sets leave room for two channel tiles)
+    MSL_REQUIRE((cot == 2 || cot == 1) && (a.Cout % (16 * cot) == 0 || (a.Cout == 8 && cot == 1)), "conv s2 dgrad (LDS): weights packed for COT=%d do not fit Cout=%d", cot, a.Cout);
+    const int oal = cot == 1 ? 4 : 8;
+    MSL_REQUIRE(a.y_cs % oal == 0 && a.y_co % oal == 0 && a.y_co + a.Cout <= a.y_cs && (!a.res || (a.res_cs % oal == 0 && a.res_co % oal == 0 && a.res_co + a.Cout <= a.res_cs)),
+                "conv s2 dgrad (LDS): output / residual view must be %d-channel aligned", oal);
+    const int cout_blocks = (a.Cout + 16 * cot - 1) / (16 * cot);
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 7) / 8;
+    return cot == 2 ? launch_s2dgrad<2>(a, cout_blocks, s) : launch_s2dgrad<1>(a, cout_blocks, s);
+  }
   if (op.i[20] == 2) {
     // One parity class of a stride-2 3x3 input gradient: stride-1, pad-0 pass over the gradient (H, W) with a 1x1 / 1x2 / 2x1 / 2x2 kernel
     // (zero beyond the bottom / right edge), outputs on the sub-lattice (2Y + a, 2X + b) of the full image — same op contract as the generic

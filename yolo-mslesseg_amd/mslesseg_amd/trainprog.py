@@ -181,7 +181,7 @@ def _gemm_rows_idx(idx2d: torch.Tensor, dtype: int):
     return out.reshape(-1).to(torch.int32), dict(K=K, Kpad=kpad, Cout_pad=rpad)
 
 
-def _lds_image_idx(idx4: torch.Tensor, dtype: int):
+def _lds_image_idx(idx4: torch.Tensor, dtype: int, max_cot: int = 4):
     """idx4 [Cout,Cin,kh,kw] → LDS image [blk][cc][ky][kx][g][col][e] (engine.pack_conv3x3_lds; kh x kw = 3x3, or the 1|2 x 1|2 kernels of the
     stride-2 input gradient's parity classes)."""
     kh, kw = int(idx4.shape[2]), int(idx4.shape[3])
@@ -192,7 +192,7 @@ def _lds_image_idx(idx4: torch.Tensor, dtype: int):
     if cout == 8:  # one 16-row block, upper half zero weights (index -1)
         idx4 = torch.cat([idx4, torch.full_like(idx4, -1)], 0)
         cout = 16
-    cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
+    cot = min(max_cot, 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1))
     cob = 16 * cot
     if cin % chunk:  # one partial chunk: index -1 = zero weight (GATHER_CAST)
         padded = torch.full((cout, (cin + chunk - 1) // chunk * chunk, kh, kw), -1, dtype=idx4.dtype)
@@ -454,8 +454,12 @@ class TrainPlan(graph.Visitor):
             # pass over dz with a 1x1 / 1x2 / 2x1 / 2x2 kernel (offset 0 ↔ tap 1 or 2, offset +1 ↔ tap 0) stored on that sub-lattice.
             # The all-taps gather form does 9 tap-GEMMs per output pixel of which 2.25 are non-zero.
             d_mode = 2
+            if self.dtype != MSL_F32 and cpad == cout and _lds_ok(cout, cin, 3, self.dtype) and os.environ.get("MSL_S2DGRAD_SPLIT") is None:
+                # all four classes in one launch (conv_s2dgrad_lds_kernel): 3x3 LDS image of the transposed weight, at most two channel tiles
+                d_mode = 3
+                didx, dm = _lds_image_idx(idx4.permute(1, 0, 2, 3), self.dtype, max_cot=2)
             base = idx4.permute(1, 2, 3, 0)  # [ci][ky][kx][co]
-            for pa in (0, 1):
+            for pa in ((0, 1) if d_mode == 2 else ()):
                 for pb in (0, 1):
                     kys, kxs = ([1] if pa == 0 else [2, 0]), ([1] if pb == 0 else [2, 0])
                     rows = base[:, kys][:, :, kxs]
@@ -469,7 +473,8 @@ class TrainPlan(graph.Visitor):
                     else:
                         cidx, cm = _gemm_rows_idx(rows.reshape(cin, -1), self.dtype)
                     dcls.append((pa, pb, len(kys), len(kxs), self._packed(cidx), cm))
-            didx, dm = dcls[0][4], dcls[0][5]
+            if d_mode == 2:
+                didx, dm = dcls[0][4], dcls[0][5]
         else:
             drows = idx4.permute(1, 2, 3, 0)  # [ci][ky][kx][co]
             if cpad != cout:
@@ -517,6 +522,10 @@ class TrainPlan(graph.Visitor):
             gres = None if first else gx
             if d_mode == 0:
                 ops.append(self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, 3, 1, 1, res=gres, cout=cin))
+            elif d_mode == 3:
+                op = self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, 3, 1, 1, res=gres, cout=cin, store_mode=3)
+                op.i[4], op.i[5] = x.H, x.W  # (Ho, Wo) = the gradient image produced
+                ops.append(op)
             elif d_mode == 2:
                 for pa, pb, kh, kw, wcls, cm in dcls:
                     op = self._conv_op(dz, gx, wcls, self.zeros.data_ptr(), cm, kh, 1, 0, res=gres, cout=cin, store_mode=2)
