@@ -220,6 +220,8 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
         I = op.i
         if wgrad:
             return 2.0 * I[0] * I[4] * I[5] * I[6] * I[7] * I[7] * I[3]
+        if I[20] == 3:  # all parity classes of a stride-2 input gradient in one launch: 9 tap-GEMMs per GRADIENT pixel (H, W), not per output pixel
+            return 2.0 * I[0] * I[1] * I[2] * I[6] * 9 * I[3]
         return 2.0 * I[0] * I[4] * I[5] * I[6] * I[16]
 
     wg_ms, wg_fl, cv_ms, cv_fl = 0.0, 0.0, 0.0, 0.0
@@ -239,7 +241,9 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             cv_ms, cv_fl = cv_ms + ms, cv_fl + fl
             one = I[7] == 1 and I[8] == 1 and (I[20] == 0 or (I[20] == 1 and I[6] % 32 == 0)) and args.dtype == "bf16" and I[3] % 8 == 0 and I[6] % 8 == 0 and I[6] <= 256
             kn = "conv3x3_lds_kernel" if I[25] else ("conv1x1_kernel" if one else "conv_igemm_kernel")
-            if I[25]:  # same rule as msl_launch_conv3x3_lds: persistent weights-resident form for full 64-channel blocks over <= 2 whole chunks
+            if I[25] and I[20] == 3:
+                kn = "conv_s2dgrad_lds_kernel"
+            elif I[25]:  # same rule as msl_launch_conv3x3_lds: persistent weights-resident form for full 64-channel blocks over <= 2 whole chunks
                 chunk = 32 if args.dtype == "bf16" else 16
                 tiles = I[0] * ((I[5] + 31) // 32) * ((I[4] + 7) // 8)
                 if I[8] == 1 and I[24] == 4 and I[3] % chunk == 0 and I[3] // chunk <= 2 and tiles >= 1024 and I[23] not in (-8, -4):
