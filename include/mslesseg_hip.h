@@ -57,6 +57,11 @@ enum {
    * i: 0 N,1 H,2 W,3 Cin,4 Ho,5 Wo,6 Cout,7 k,8 stride,9 pad,10 x_cs,11 x_co,12 y_cs,13 y_co,14 res_cs,15 res_co,
    *    16 K(=k*k*Cin),17 Kpad,18 act(0 none,1 SiLU),19 out_f32(0/1),20 store_mode(0 plain, 1 pixel-shuffle 2x2:
    *    GEMM channel q*C+c with q=dy*2+dx goes to pixel (2y+dy,2x+dx) channel c, C=Cout/4 — ConvTranspose2d k2 s2),
+   *       2 = one parity class of a stride-2 3x3 input gradient: stride-1 pad-0 pass over the gradient with a 1|2 x 1|2 kernel (7 = kh, or
+   *       kh*16+kw), output pixel (Y,X) stored at (2Y+a, 2X+b) of the full image, 23 = a | b<<1 | Hodd<<2 | Wodd<<3 (generic kernel, or
+   *       the LDS-tiled kernel when 25 = 1, bf16);  3 = the whole 3x3 / stride-2 / pad-1 input gradient in one pass (25 = 1, bf16:
+   *       weights = the 3x3 LDS image of the transposed weight [ci][co][ky][kx] with 24 = COT <= 2, (H,W) = gradient read,
+   *       (Ho,Wo) = gradient image produced, 3 = forward output channels, 6 = forward input channels; p[3] adds what the view already holds),
    *    21 Cout_pad (multiple of 16), 22 dgrad (0 forward gather; 1 transposed-conv gather: source = (out+pad-tap)/stride when
    *       divisible, (H,W) = gradient read, (Ho,Wo) = tensor produced, weights packed [Cin][(ky,kx,co)]), k may also be 2,
    *    25 weight layout: 0 = GEMM rows above (generic kernel); 1 = LDS image for the tiled 3x3 kernel (k=3, pad=1, stride 1|2,

@@ -88,10 +88,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       p0 = tile * (TH * TW);  // 1x1: the pixels are a flat list, a "row" is just 32 consecutive ones
       n = 0; oy0 = 0; ox0 = 0;
     } else {
-      const int txi = (int)(tile % a.tiles_x);
-      const long tq = tile / a.tiles_x;
-      const int tyi = (int)(tq % a.tiles_y);
-      n = (int)(tq / a.tiles_y);
+      // tiles of an image are walked column-major: vertical neighbours share 2 of the 6 (4-row tile) halo rows of x and are staged back to back,
+      // so the shared rows are still in L2 (row-major order revisits them tiles_x tiles later — 200 KB per workgroup, x 32 workgroups per XCD,
+      // more than its 4 MB L2)
+      const int tyi = (int)(tile % a.tiles_y);
+      const long tq = tile / a.tiles_y;
+      const int txi = (int)(tq % a.tiles_x);
+      n = (int)(tq / a.tiles_x);
       oy0 = tyi * TH; ox0 = txi * TW;
     }
     for (int pc = wave; pc < C::Z_PIECES; pc += 8) {
