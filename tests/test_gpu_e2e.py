@@ -159,6 +159,32 @@ def test_batch_equals_single(eng_f32, golden):
         assert torch.equal(p1.keep_idx.cpu()[0, :n], k2[j, :n])
 
 
+def test_large_batch_bf16_matches_small_batch(eng_bf16, golden):
+    """At batch >= 11 the 160x160 3x3 layers switch to the persistent weights-resident kernel and Proto.cv3 rides in Proto.cv2's epilogue
+    (MSL_OP_CONV p[6]/p[7]); small batches take the tile-per-workgroup kernel and two ops.  Both paths compute the same bf16 network: the
+    prototypes and head tensors of a slice must agree between a 16-slice batch and a single-slice run up to bf16 rounding of a different
+    (but equally valid) fp32 summation order, and the kept detections must be the same."""
+    a, b = _img(golden, 0), _img(golden, 1)
+    imgs = np.stack([a, b] * 8)
+    p16 = eng_bf16.predict_batch(torch.from_numpy(imgs))
+    torch.cuda.synchronize()
+    assert any(n.endswith("proto.cv2+cv3") for n in p16.builder.names), "the fused tail was expected at this batch size"
+    h16 = p16.head_tensor().float().cpu().clone()
+    pr16 = p16.proto.torch().float().cpu().clone()
+    c16 = p16.keep_cnt.cpu().clone()
+    for j, im in enumerate((a, b)):
+        p1 = eng_bf16.predict_batch(torch.from_numpy(im[None]))
+        torch.cuda.synchronize()
+        assert not any(n.endswith("+cv3") for n in p1.builder.names)
+        h1, pr1 = p1.head_tensor().float().cpu()[0], p1.proto.torch().float().cpu()[0]
+        for k in (j, j + 2, j + 14):  # every copy of the slice inside the batch
+            perr = float((pr16[k] - pr1).abs().max() / (1 + pr1.abs().max()))
+            herr = float((h16[k, 4] - h1[4]).abs().max())
+            assert perr < 0.05 and herr < 0.05, (k, perr, herr)
+            assert abs(int(c16[k]) - int(p1.keep_cnt.cpu()[0])) <= 1
+        assert torch.equal(h16[j], h16[j + 2]) and torch.equal(pr16[j], pr16[j + 14]), "copies of one slice inside a batch must agree bit for bit"
+
+
 # --------------------------------------------------------------------------------------------- NMS, bit-exact
 def _run_nms(pred, conf=0.25, iou=0.7, max_det=300):
     N, A, _ = pred.shape
