@@ -57,6 +57,8 @@ CONV_CASES = [
     # 1x1 streaming kernel (bf16): LDS-resident weights, per-wave LDS-DMA rings, 16-byte stores
     (2, 40, 40, 64, 256, 1, 1, 64, 0, 256, 0, 1, 0, 0),    # 8 output groups → 16-pixel slices
     (2, 33, 47, 256, 64, 1, 1, 384, 128, 192, 64, 1, 1, 0),  # K = 256 from a concat slice, residual, ragged pixel count
+    (2, 21, 40, 128, 384, 1, 1, 128, 0, 448, 32, 1, 1, 0),   # Cout = 384 > 256: two launches of the streaming kernel over channel halves, residual, slice
+    (1, 20, 20, 256, 512, 1, 1, 256, 0, 512, 0, 0, 0, 0),    # Cout = 512: 2 x 256
     (4, 80, 80, 48, 64, 1, 1, 48, 0, 64, 0, 1, 0, 0),      # K padded 48 → 64; several slices per wave
     (1, 50, 50, 64, 48, 1, 1, 64, 0, 48, 0, 0, 1, 0),      # Cout = 48: half-filled output group; dgrad-like (no act, accumulate)
     (1, 30, 30, 32, 64, 1, 1, 32, 0, 64, 0, 0, 0, 1),      # fp32 output (box head)

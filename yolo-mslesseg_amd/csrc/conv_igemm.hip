@@ -223,6 +223,29 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 int msl_launch_conv(const msl_op& op, hipStream_t s) {
   if (op.i[25] == 1) return msl_launch_conv3x3_lds(op, s);  // weights packed as the LDS image: tiled 3x3 kernel
   if (msl_conv1x1_eligible(op)) return msl_launch_conv1x1(op, s);  // bf16 1x1: streaming kernel with LDS-resident weights (conv1x1.hip)
+  if (op.dtype == MSL_BF16 && op.i[7] == 1 && op.i[8] == 1 && op.i[9] == 0 && op.i[20] == 0 && op.i[6] > 256 && op.i[6] % 32 == 0 && !op.p[5] && op.p[1]) {
+    // wide 1x1 (input gradients of the layers that read a 384- / 512-channel concat): the streaming kernel keeps at most 256 output channels'
+    // weights in LDS — run it over equal channel parts (x is read once per part; still well ahead of the generic kernel)
+    const int parts = (op.i[6] + 255) / 256, step = (op.i[6] / parts + 31) / 32 * 32;
+    msl_op sub[4];
+    bool ok = parts <= 4;
+    for (int j = 0, c0 = 0; ok && j < parts; ++j, c0 += step) {
+      sub[j] = op;
+      const int n = op.i[6] - c0 < step ? op.i[6] - c0 : step;
+      sub[j].i[6] = n; sub[j].i[21] = n;
+      sub[j].p[1] = (char*)op.p[1] + (long)c0 * op.i[17] * 2;
+      sub[j].p[2] = op.p[2] ? (void*)((float*)op.p[2] + c0) : nullptr;
+      sub[j].i[13] = op.i[13] + c0; sub[j].i[15] = op.i[15] + c0;
+      ok = n > 0 && msl_conv1x1_eligible(sub[j]);
+    }
+    if (ok) {
+      for (int j = 0; j < parts; ++j) {
+        const int rc = msl_launch_conv1x1(sub[j], s);
+        if (rc != MSL_OK) return rc;
+      }
+      return MSL_OK;
+    }
+  }
   MSL_REQUIRE(!op.p[5], "conv: the BatchNorm-statistics epilogue (p[5]) exists only in the 1x1 streaming kernel and this op is not eligible for it");
   ConvArgs a;
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2];
