@@ -33,6 +33,8 @@ struct Conv3Args {
   int N, H, W, Cin, Ho, Wo, Cout;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int act, out_f32, tiles_x, tiles_y;
+  int cout_blocks;  // output-channel blocks per tile: the fastest-varying part of the workgroup index, so that the blocks of one tile run
+                    // back to back and re-read its halo from L2 (as the slow grid dimension every block pulled it from HBM again)
   const char* w2;       // fused 1x1 tail (persistent kernel, bf16): weights [C2 = 32][Cout = 64] row-major, y = act(W2 * act(conv(x) + bias) + bias2)
   const float* bias2;
   int lat, full_h, full_w;  // lat >= 0: output pixel (Y,X) is stored at (2Y + (lat&1), 2X + (lat>>1)) of a full_h x full_w image (parity class of a stride-2 input gradient)
@@ -123,12 +125,12 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     const int per = gridDim.x >> 3;
     if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
   }
+  const int cob = bid % a.cout_blocks; bid /= a.cout_blocks;
   const int txi = bid % a.tiles_x; bid /= a.tiles_x;
   const int tyi = bid % a.tiles_y;
   const int n = bid / a.tiles_y;
   const int oy0 = tyi * T::TH, ox0 = txi * T::TW;
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;  // halo origin
-  const int cob = blockIdx.y;
 
   f32x4 acc[COT][PT];
 #pragma unroll
@@ -278,8 +280,10 @@ static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x), (unsigned)cout_blocks);
-  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>), grid, dim3(256), LDS, s, a);
+  Conv3Args b = a;
+  b.cout_blocks = cout_blocks;
+  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * cout_blocks));
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>), grid, dim3(256), LDS, s, b);
   MSL_CHECK_LAUNCH("conv3x3_lds");
   return MSL_OK;
 }
@@ -595,11 +599,11 @@ __global__ __launch_bounds__(256, 2) void conv_s2dgrad_lds_kernel(Conv3Args a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lp = lane & 15, g = lane >> 4;
   int bid = (int)xcd_block(blockIdx.x, gridDim.x);
+  const int cob = bid % a.cout_blocks; bid /= a.cout_blocks;
   const int txi = bid % a.tiles_x; bid /= a.tiles_x;
   const int tyi = bid % a.tiles_y;
   const int n = bid / a.tiles_y;
   const int Y0 = tyi * T::TH, X0 = txi * T::TW;
-  const int cob = blockIdx.y;
 
   f32x4 acc[4][COT][PT];  // [class a*2+b]
 #pragma unroll
@@ -706,8 +710,10 @@ static int launch_s2dgrad(const Conv3Args& a, int cout_blocks, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_s2dgrad_lds_kernel<COT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x), (unsigned)cout_blocks);
-  hipLaunchKernelGGL((conv_s2dgrad_lds_kernel<COT>), grid, dim3(256), LDS, s, a);
+  Conv3Args b = a;
+  b.cout_blocks = cout_blocks;
+  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * cout_blocks));
+  hipLaunchKernelGGL((conv_s2dgrad_lds_kernel<COT>), grid, dim3(256), LDS, s, b);
   MSL_CHECK_LAUNCH("conv_s2dgrad_lds");
   return MSL_OK;
 }
