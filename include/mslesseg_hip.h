@@ -196,7 +196,10 @@ const char* msl_last_error(void);
 int msl_launch(const msl_op* op, void* stream);
 /* Enqueue ops[0..n) in order on `stream` (one host call per forward pass). */
 int msl_run_program(const msl_op* ops, int32_t n, void* stream);
-/* Same, with a lane per op (0 = `stream`, 1..3 = library-owned side streams): independent chains overlap; see capi.hip for the ordering rules. */
+/* Same, with a lane per op (0 = `stream`; 1..3 = fork/join side streams: a lane starts after what `stream` holds so far, the next lane-0 op
+ * waits for it — independent chains overlap; 4..5 = deferred side streams: each op waits for what `stream` holds so far, nothing waits for it
+ * until the end of the program — work whose result the program itself never reads, e.g. weight gradients).  The call returns with every lane
+ * joined into `stream`. */
 int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream);
 
 /* hipGraph capture of a program: launch-bound inner loops (batch-1 predict, ~110 small kernels) replay as one graph. */

@@ -81,18 +81,26 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream) {
   return MSL_OK;
 }
 
-// Program with lanes: ops tagged lane 0 run on `stream`; ops tagged 1..MSL_MAX_LANES-1 run on library-owned side streams, so that
-// independent chains (the detection-head branches of different pyramid levels) overlap their launch-latency-bound kernels.
-// Ordering: ops of one lane keep program order; a side lane starts after everything issued to `stream` so far (fork event); a lane-0
-// op that follows side-lane ops waits for all of them (join), and so does the end of the program.
-#define MSL_MAX_LANES 4
+// Program with lanes: ops tagged lane 0 run on `stream`; ops tagged 1..MSL_MAX_LANES-1 run on library-owned side streams.
+//   fork/join lanes (1 .. MSL_FIRST_DEFERRED-1): independent chains (the detection-head branches of different pyramid levels) overlap their
+//     launch-latency-bound kernels.  Ops of one lane keep program order; a lane starts after everything issued to `stream` so far (fork
+//     event); a lane-0 op that follows such ops waits for all of them (join).
+//   deferred lanes (MSL_FIRST_DEFERRED ..): work whose result nothing in the program reads (weight gradients — only the optimizer step after
+//     the program needs them).  Every such op waits for everything issued to `stream` so far, lane-0 ops do NOT wait for it: the chain of
+//     input-gradient / BatchNorm kernels continues while the weight-gradient kernels fill the tails of those launches.
+//   The end of the program joins every lane.
+#define MSL_MAX_LANES 6
+#define MSL_FIRST_DEFERRED 4
 static hipStream_t g_side[16][MSL_MAX_LANES];
-static hipEvent_t g_fork[16], g_join[16][MSL_MAX_LANES];
+static hipEvent_t g_fork[16], g_fork_def[16], g_join[16][MSL_MAX_LANES];
 static bool g_lanes_ready[16];
 
 static int lanes_init(int dev) {
   if (g_lanes_ready[dev]) return MSL_OK;
-  if (hipEventCreateWithFlags(&g_fork[dev], hipEventDisableTiming) != hipSuccess) { msl_set_error("lanes: hipEventCreate failed"); return MSL_ELAUNCH; }
+  if (hipEventCreateWithFlags(&g_fork[dev], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_fork_def[dev], hipEventDisableTiming) != hipSuccess) {
+    msl_set_error("lanes: hipEventCreate failed");
+    return MSL_ELAUNCH;
+  }
   for (int k = 1; k < MSL_MAX_LANES; ++k) {
     if (hipStreamCreateWithFlags(&g_side[dev][k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_join[dev][k], hipEventDisableTiming) != hipSuccess) {
       msl_set_error("lanes: cannot create side stream %d", k);
@@ -110,9 +118,9 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
   int rc = lanes_init(dev);
   if (rc != MSL_OK) return rc;
   hipStream_t main_s = (hipStream_t)stream;
-  bool active[MSL_MAX_LANES] = {false, false, false, false};
-  auto join_all = [&]() {
-    for (int k = 1; k < MSL_MAX_LANES; ++k)
+  bool active[MSL_MAX_LANES] = {false, false, false, false, false, false};
+  auto join = [&](int from, int to) {
+    for (int k = from; k < to; ++k)
       if (active[k]) {
         (void)hipEventRecord(g_join[dev][k], g_side[dev][k]);
         (void)hipStreamWaitEvent(main_s, g_join[dev][k], 0);
@@ -121,16 +129,21 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
   };
   for (int32_t i = 0; i < n; ++i) {
     const int L = lanes[i];
-    if (L < 0 || L >= MSL_MAX_LANES) { msl_set_error("op %d: lane %d out of range", i, L); join_all(); return MSL_EINVAL; }
+    if (L < 0 || L >= MSL_MAX_LANES) { msl_set_error("op %d: lane %d out of range", i, L); join(1, MSL_MAX_LANES); return MSL_EINVAL; }
     hipStream_t s = main_s;
     if (L == 0) {
-      join_all();
-    } else {
+      join(1, MSL_FIRST_DEFERRED);
+    } else if (L < MSL_FIRST_DEFERRED) {
       if (!active[L]) {  // fork: the side lane sees everything issued to the main stream so far
         (void)hipEventRecord(g_fork[dev], main_s);
         (void)hipStreamWaitEvent(g_side[dev][L], g_fork[dev], 0);
         active[L] = true;
       }
+      s = g_side[dev][L];
+    } else {  // deferred: ordered after the main stream as of now, joined only at the end
+      (void)hipEventRecord(g_fork_def[dev], main_s);
+      (void)hipStreamWaitEvent(g_side[dev][L], g_fork_def[dev], 0);
+      active[L] = true;
       s = g_side[dev][L];
     }
     rc = dispatch(ops[i], s);
@@ -139,11 +152,11 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
       strncpy(tmp, g_err, sizeof(tmp) - 1);
       tmp[sizeof(tmp) - 1] = 0;
       msl_set_error("op %d (kind %d, lane %d): %s", i, ops[i].kind, L, tmp);
-      join_all();
+      join(1, MSL_MAX_LANES);
       return rc;
     }
   }
-  join_all();
+  join(1, MSL_MAX_LANES);
   return MSL_OK;
 }
 

@@ -300,6 +300,18 @@ class TrainPlan(graph.Visitor):
         self._lane = lane
         return lane
 
+    WGRAD_LANE = 4  # deferred lane (capi.hip): weight gradients of the trunk run beside the input-gradient / BatchNorm chain
+
+    def _wgrad_lane(self, lane: int) -> int:
+        """Lane of a layer's weight-gradient op: trunk layers (lane 0) hand it to the deferred lane — nothing in the backward program reads a
+        weight gradient, the program end joins it — while head layers keep it inside their own fork/join lane."""
+        return self.WGRAD_LANE if (lane == 0 and self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None) else lane
+
+    def _defer(self, op, lane: int):
+        if self._wgrad_lane(lane) != lane:
+            op._force_lane = self._wgrad_lane(lane)
+        return op
+
     def _scratch(self, lane: int) -> int:
         if lane not in self._wg_scratch:
             self._wg_scratch[lane] = torch.empty(WG_SCRATCH_FLOATS, dtype=torch.float32, device=self.device)
@@ -416,8 +428,8 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             self._bn_backward(ops, name, z, y, cout, True, stats, None)
-            ops.append(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
-                                      i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS}))
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+                                                  i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS}), lane))
             return ops
 
         self._add_bw(bw)
@@ -515,8 +527,8 @@ class TrainPlan(graph.Visitor):
                 ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dzc.t.data_ptr(), dz.t.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
                 dz, dz_f32 = dzc, 0
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
-                                      i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}))
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+                                                  i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}), lane))
             gx = self.G(x)
             first = self._init.first_write(gx)
             gres = None if first else gx
@@ -593,8 +605,8 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             self._bn_backward(ops, name, z, y, C, act, stats, res, res_inplace=inplace)
-            ops.append(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
-                                      i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS, **gm}))
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+                                                  i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS, **gm}), lane))
             gx = self.G(x)
             if gmap is None:
                 first = self._init.first_write(gx)
@@ -744,7 +756,7 @@ class TrainPlan(graph.Visitor):
                     bwd_segments.append(op)
                     bwd_segments.append([])
                 else:
-                    op._lane = lane
+                    op._lane = getattr(op, "_force_lane", lane)
                     bwd_segments[-1].append(op)
 
         def prog(ops):
