@@ -305,11 +305,17 @@ class TrainPlan(graph.Visitor):
     def _wgrad_lane(self, lane: int) -> int:
         """Lane of a layer's weight-gradient op: trunk layers (lane 0) hand it to the deferred lane — nothing in the backward program reads a
         weight gradient, the program end joins it — while head layers keep it inside their own fork/join lane."""
-        return self.WGRAD_LANE if (lane == 0 and self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None) else lane
+        if not (lane == 0 and self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None):
+            return lane
+        if os.environ.get("MSL_WGRAD_ONE_LANE") is not None:
+            return self.WGRAD_LANE
+        self._wg_rr = getattr(self, "_wg_rr", 0)
+        return self.WGRAD_LANE + (self._wg_rr & 1)  # two deferred lanes, taken in turn by _defer (each with its own partial-matrix scratch)
 
     def _defer(self, op, lane: int):
         if self._wgrad_lane(lane) != lane:
             op._force_lane = self._wgrad_lane(lane)
+            self._wg_rr = getattr(self, "_wg_rr", 0) + 1  # next weight gradient → the other deferred lane
         return op
 
     def _scratch(self, lane: int) -> int:
@@ -520,6 +526,8 @@ class TrainPlan(graph.Visitor):
                 ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gyw.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0, 21: ACC_SLOTS}))
                 ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cpad}))
+                if lane == 0 and self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None:  # bias gradient: nothing in the program reads it either
+                    ops[-2]._force_lane = ops[-1]._force_lane = self.WGRAD_LANE
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
             if dz_f32 and self.dtype != MSL_F32:  # the MFMA operands must be the compute dtype (as autocast feeds these convs upstream)
                 dzc = self._new(Ho, Wo, dz.C)
