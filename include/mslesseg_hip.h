@@ -196,9 +196,10 @@ const char* msl_last_error(void);
 int msl_launch(const msl_op* op, void* stream);
 /* Enqueue ops[0..n) in order on `stream` (one host call per forward pass). */
 int msl_run_program(const msl_op* ops, int32_t n, void* stream);
-/* Same, with a lane per op (0 = `stream`; 1..3 = fork/join side streams: a lane starts after what `stream` holds so far, the next lane-0 op
- * waits for it — independent chains overlap; 4..5 = deferred side streams: each op waits for what `stream` holds so far, nothing waits for it
- * until the end of the program — work whose result the program itself never reads, e.g. weight gradients).  The call returns with every lane
+/* Same, with a lane per op (0 = `stream`; 1..4 = fork/join side streams: a lane starts after what `stream` holds so far, the next lane-0 op
+ * waits for it — independent chains overlap; 5..7 = deferred side streams: each op waits for what `stream` (or the running fork/join lane in
+ * bits 8-15 of its lane word) holds so far, nothing waits for it until the end of the program — work whose result the program itself never
+ * reads, e.g. weight gradients).  The call returns with every lane
  * joined into `stream`. */
 int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream);
 

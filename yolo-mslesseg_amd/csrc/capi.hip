@@ -86,11 +86,12 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream) {
 //     launch-latency-bound kernels.  Ops of one lane keep program order; a lane starts after everything issued to `stream` so far (fork
 //     event); a lane-0 op that follows such ops waits for all of them (join).
 //   deferred lanes (MSL_FIRST_DEFERRED ..): work whose result nothing in the program reads (weight gradients — only the optimizer step after
-//     the program needs them).  Every such op waits for everything issued to `stream` so far, lane-0 ops do NOT wait for it: the chain of
+//     the program needs them).  Every such op waits for everything issued so far to `stream` (or to the fork/join lane named in bits 8-15 of
+//     its lane word, when that lane is running), lane-0 ops do NOT wait for it: the chain of
 //     input-gradient / BatchNorm kernels continues while the weight-gradient kernels fill the tails of those launches.
 //   The end of the program joins every lane.
-#define MSL_MAX_LANES 6
-#define MSL_FIRST_DEFERRED 4
+#define MSL_MAX_LANES 8
+#define MSL_FIRST_DEFERRED 5
 static hipStream_t g_side[16][MSL_MAX_LANES];
 static hipEvent_t g_fork[16], g_fork_def[16], g_join[16][MSL_MAX_LANES];
 static bool g_lanes_ready[16];
@@ -118,7 +119,7 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
   int rc = lanes_init(dev);
   if (rc != MSL_OK) return rc;
   hipStream_t main_s = (hipStream_t)stream;
-  bool active[MSL_MAX_LANES] = {false, false, false, false, false, false};
+  bool active[MSL_MAX_LANES] = {false, false, false, false, false, false, false, false};
   auto join = [&](int from, int to) {
     for (int k = from; k < to; ++k)
       if (active[k]) {
@@ -128,8 +129,8 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
       }
   };
   for (int32_t i = 0; i < n; ++i) {
-    const int L = lanes[i];
-    if (L < 0 || L >= MSL_MAX_LANES) { msl_set_error("op %d: lane %d out of range", i, L); join(1, MSL_MAX_LANES); return MSL_EINVAL; }
+    const int L = lanes[i] & 0xff, src = (lanes[i] >> 8) & 0xff;  // bits 8-15 (deferred ops): the fork/join lane whose work the op consumes (0 = `stream`)
+    if (lanes[i] < 0 || L >= MSL_MAX_LANES || src >= MSL_FIRST_DEFERRED) { msl_set_error("op %d: lane %d (source %d) out of range", i, L, src); join(1, MSL_MAX_LANES); return MSL_EINVAL; }
     hipStream_t s = main_s;
     if (L == 0) {
       join(1, MSL_FIRST_DEFERRED);
@@ -140,8 +141,8 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
         active[L] = true;
       }
       s = g_side[dev][L];
-    } else {  // deferred: ordered after the main stream as of now, joined only at the end
-      (void)hipEventRecord(g_fork_def[dev], main_s);
+    } else {  // deferred: ordered after its source stream as of now, joined only at the end
+      (void)hipEventRecord(g_fork_def[dev], src == 0 || !active[src] ? main_s : g_side[dev][src]);
       (void)hipStreamWaitEvent(g_side[dev][L], g_fork_def[dev], 0);
       active[L] = true;
       s = g_side[dev][L];

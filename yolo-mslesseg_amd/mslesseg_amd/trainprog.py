@@ -300,12 +300,13 @@ class TrainPlan(graph.Visitor):
         self._lane = lane
         return lane
 
-    WGRAD_LANE = 4  # deferred lane (capi.hip): weight gradients of the trunk run beside the input-gradient / BatchNorm chain
+    WGRAD_LANE = 5  # first deferred lane (capi.hip): weight gradients of the trunk run beside the input-gradient / BatchNorm chain
 
     def _wgrad_lane(self, lane: int) -> int:
         """Lane of a layer's weight-gradient op: trunk layers (lane 0) hand it to the deferred lane — nothing in the backward program reads a
         weight gradient, the program end joins it — while head layers keep it inside their own fork/join lane."""
-        if not (lane == 0 and self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None):
+        # (measured: deferring the head lanes' weight gradients as well is slower — 27.2 vs 26.5 ms per step: those lanes already overlap each other)
+        if not (self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None and (lane == 0 or os.environ.get("MSL_WGRAD_HEAD_DEFER") is not None)):
             return lane
         if os.environ.get("MSL_WGRAD_ONE_LANE") is not None:
             return self.WGRAD_LANE
@@ -314,7 +315,7 @@ class TrainPlan(graph.Visitor):
 
     def _defer(self, op, lane: int):
         if self._wgrad_lane(lane) != lane:
-            op._force_lane = self._wgrad_lane(lane)
+            op._force_lane = self._wgrad_lane(lane) | (lane << 8)  # bits 8-15: the lane that produced its inputs (capi.hip)
             self._wg_rr = getattr(self, "_wg_rr", 0) + 1  # next weight gradient → the other deferred lane
         return op
 
@@ -526,8 +527,8 @@ class TrainPlan(graph.Visitor):
                 ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gyw.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0, 21: ACC_SLOTS}))
                 ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cpad}))
-                if lane == 0 and self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None:  # bias gradient: nothing in the program reads it either
-                    ops[-2]._force_lane = ops[-1]._force_lane = self.WGRAD_LANE
+                if self._wgrad_lane(lane) != lane:  # bias gradient: nothing in the program reads it either
+                    ops[-2]._force_lane = ops[-1]._force_lane = self.WGRAD_LANE | (lane << 8)
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
             if dz_f32 and self.dtype != MSL_F32:  # the MFMA operands must be the compute dtype (as autocast feeds these convs upstream)
                 dzc = self._new(Ho, Wo, dz.C)
@@ -587,8 +588,8 @@ class TrainPlan(graph.Visitor):
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co, 21: ACC_SLOTS}))
             ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cout}))
             # dW[ci][(dy,dx,co)] = sum_p x[p][ci] * dy[(2y+dy,2x+dx)][co]: CONV_WGRAD with the operands swapped
-            ops.append(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(lane)),
-                                      i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co, 21: WG_SCRATCH_FLOATS}))
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+                                                  i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co, 21: WG_SCRATCH_FLOATS}), lane))
             gx = self.G(x)
             first = self._init.first_write(gx)
             ops.append(self._conv_op(gy, gx, wd, self.zeros.data_ptr(), dm, 2, 2, 0, res=None if first else gx, cout=cin))
