@@ -259,6 +259,10 @@ class TrainPlan(graph.Visitor):
         self._wg_scratch: Dict[int, torch.Tensor] = {}  # per-workgroup dW partials: one buffer per lane (one wgrad runs at a time on a lane)
         self._lane = 0
         self.use_lanes = os.environ.get("MSLESSEG_LANES", "1") != "0"
+        # the prototype branch on a lane of its own: its input gradient goes to a private buffer that is added to the P3 gradient after the join
+        # (it used to share lane 1 with the level-0 head because both accumulate into that gradient — a 5.5 ms serial chain beside two ~1.5 ms ones)
+        self._proto_own_lane = self.use_lanes and os.environ.get("MSL_PROTO_SHARED_LANE") is None
+        self._late_adds = []
         self._keep: List[torch.Tensor] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.levels, self.proto_view, self.in_view = {}, None, None
@@ -296,7 +300,7 @@ class TrainPlan(graph.Visitor):
             if m:
                 lane = 1 + min(int(m.group(1)), 2)
             elif re.match(r"model\.\d+\.proto\.", name):
-                lane = 1
+                lane = 4 if self._proto_own_lane else 1
         self._lane = lane
         return lane
 
@@ -539,7 +543,15 @@ class TrainPlan(graph.Visitor):
             ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
                                                   i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}), lane))
             gx = self.G(x)
-            first = self._init.first_write(gx)
+            if self._proto_own_lane and name.endswith(".proto.cv1"):
+                priv = torch.empty_like(x.t)
+                self._keep.append(priv)
+                gpriv = View(priv, x.N, x.H, x.W, x.C, x.cs, x.co, x.f32)
+                self._late_adds.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gx.t.data_ptr(), priv.data_ptr()),
+                                                      i={0: self.N, 1: x.H, 2: x.W, 3: x.C, 10: gx.cs, 11: gx.co, 12: gpriv.cs, 13: gpriv.co, 20: 0}))
+                gx, first = gpriv, True
+            else:
+                first = self._init.first_write(gx)
             gres = None if first else gx
             if d_mode == 0:
                 ops.append(self._conv_op(dz, gx, wd, self.zeros.data_ptr(), dm, 3, 1, 1, res=gres, cout=cin))
@@ -759,14 +771,24 @@ class TrainPlan(graph.Visitor):
                 self._init.mark(self.G(v))
         self._init.mark(self.G(self.proto_view))
         bwd_segments: List = [[]]
+        seen_side = False
         for build, lane in reversed(self._bw_builders):
-            for op in build():
+            built = build()
+            if lane != 0:
+                seen_side = True
+            elif seen_side and self._late_adds:  # first trunk layer after the head / prototype lanes: they are joined here — add the private gradients
+                for op in self._late_adds:
+                    op._lane = 0
+                    bwd_segments[-1].append(op)
+                self._late_adds = []
+            for op in built:
                 if callable(op):
                     bwd_segments.append(op)
                     bwd_segments.append([])
                 else:
                     op._lane = getattr(op, "_force_lane", lane)
                     bwd_segments[-1].append(op)
+        assert not self._late_adds, "private gradient buffers were never added back"
 
         def prog(ops):
             return hiplib.Program(ops, lanes=[getattr(o, "_lane", 0) for o in ops])
