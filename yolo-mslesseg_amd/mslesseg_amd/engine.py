@@ -143,6 +143,9 @@ def _lane_of(name: str) -> int:
         return 1 if int(m.group(1)) == 0 else 3
     if re.match(r"model\.\d+\.proto\.", name):
         return 2
+    m = re.match(r"decode\.(\d+)$", name)  # a level's box decode follows its head chain on the same lane (the levels fill disjoint anchor ranges)
+    if m and os.environ.get("MSL_DECODE_MAIN") is None:
+        return 1 if int(m.group(1)) == 0 else 3
     return 0
 
 
