@@ -145,7 +145,10 @@ enum {
    * [Cin][(ky,kx,co)]).  ConvTranspose2d(2,2) backward = CONV k=2 s=2 p=0 (dgrad) and CONV_WGRAD with the operands swapped. */
   MSL_OP_BN_STATS = 16,           /* acc f64[slots][2C] += (sum z, sum z^2) per channel over N*H*W; i[21] slots */
   MSL_OP_BN_FINALIZE = 17,        /* stats f32[2C] = (mean, 1/sqrt(var+eps)) from the slot sums; running stats update; acc = 0 */
-  MSL_OP_BN_ACT = 18,             /* y = act(gamma*zhat+beta) (+res) */
+  MSL_OP_BN_ACT = 18,             /* y = act(gamma*zhat+beta) (+res);
+                                     with p 6 = acc f64[slots][2C] the finalize is fused (small layers): every workgroup derives (mean, invstd) from the slot
+                                     sums, block 0 writes them to p 1 and updates the running statistics at p 7 | NULL (variance at p7 + i16 floats);
+                                     i 21 slots, f 0 eps, f 1 momentum; the accumulator is NOT reset (the caller zeroes it before the next pass) */
   MSL_OP_BN_ACT_BWD_REDUCE = 19,  /* acc f64[slots][2C] += (sum g, sum g*zhat), g = dy*act'(u); i[21] slots */
   MSL_OP_BN_ACT_BWD_APPLY = 20,   /* dz = gamma*invstd*(g - s1/M - zhat*s2/M); dgamma = s2, dbeta = s1 */
   MSL_OP_COLSUM = 21,             /* acc f64[C] += column sums of a view (bias gradients) */

@@ -191,17 +191,45 @@ int msl_launch_bn_finalize(const msl_op& op, hipStream_t s) {
 
 // BN_ACT forward: y = act(gamma * (z - mean) * invstd + beta) (+ res).  Thread = (channel group, pixel lane): the per-channel
 // constants sit in registers and the thread streams PPT pixels.
+// Fused finalize (small layers, where a separate 5 us BN_FINALIZE launch on the forward chain costs more than the work): fin.acc != NULL — every
+// workgroup derives (mean, invstd) of all channels from the slot sums itself (the same expressions and roundings as bn_finalize_kernel), block 0
+// also publishes them for the backward pass and updates the running statistics.  The accumulators are NOT reset here (other workgroups are
+// still reading them): the caller zeroes them before the next forward pass.
+struct BnFin { const double* acc; float* stats_out; float* rmean; float* rvar; double M; float eps, mom; int slots; };
 template <bool F32, int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y, long M, int C,
-                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT) {
+                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT, BnFin fin) {
+  __shared__ float ks[2048];
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
   const int c = cq * V;
+  if (fin.acc) {  // block-uniform
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int j = 0; j < fin.slots; ++j) { a1 += fin.acc[(long)j * 2 * C + 2 * ch]; a2 += fin.acc[(long)j * 2 * C + 2 * ch + 1]; }
+      const double mean = a1 / fin.M;
+      double var = a2 / fin.M - mean * mean;
+      if (var < 0) var = 0;
+      const float fm = (float)mean, fi = (float)(1.0 / sqrt(var + (double)fin.eps));
+      ks[2 * ch] = fm; ks[2 * ch + 1] = fi;
+      if (blockIdx.x == 0) {
+        fin.stats_out[2 * ch] = fm; fin.stats_out[2 * ch + 1] = fi;
+        if (fin.rmean) {
+          fin.rmean[ch] = (1.f - fin.mom) * fin.rmean[ch] + fin.mom * fm;
+          fin.rvar[ch] = (1.f - fin.mom) * fin.rvar[ch] + fin.mom * (float)(var * (fin.M > 1 ? fin.M / (fin.M - 1) : 1.0));
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (pl >= PL) return;
   float mu[V], is[V], ga[V], be[V];
 #pragma unroll
-  for (int r = 0; r < V; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
+  for (int r = 0; r < V; ++r) {
+    if (fin.acc) { mu[r] = ks[2 * (c + r)]; is[r] = ks[2 * (c + r) + 1]; } else { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; }
+    ga[r] = gamma[c + r]; be[r] = beta[c + r];
+  }
   const long p0 = (long)blockIdx.x * PL * PPT + pl;
   constexpr int U = V == 8 ? 2 : 4;
   for (int k = 0; k < PPT; k += U) {
@@ -242,7 +270,13 @@ int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
   const int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;
   const long per_block = (long)PL * PPT;
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
-#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT)
+  BnFin fin = {nullptr, nullptr, nullptr, nullptr, 0.0, 0.f, 0.f, 0};
+  if (op.p[6]) {  // fused finalize: p 6 acc f64[slots][2C], p 7 running mean | NULL (running var = p7 + i16 floats), i 21 slots, f 0 eps, f 1 momentum
+    MSL_REQUIRE(C <= 1024 && slots_of(op, 21) <= MSL_MAX_SLOTS && (!op.p[7] || op.i[16] != 0), "bn_act: bad fused-finalize arguments");
+    fin.acc = (const double*)op.p[6]; fin.stats_out = (float*)op.p[1]; fin.rmean = (float*)op.p[7]; fin.rvar = op.p[7] ? (float*)op.p[7] + op.i[16] : nullptr;
+    fin.M = (double)M; fin.eps = op.f[0]; fin.mom = op.f[1]; fin.slots = slots_of(op, 21);
+  }
+#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin)
   if (op.dtype == MSL_F32) { if (v8) BA(true, 8); else BA(true, 4); } else { if (v8) BA(false, 8); else BA(false, 4); }
 #undef BA
   MSL_CHECK_LAUNCH("bn_act");

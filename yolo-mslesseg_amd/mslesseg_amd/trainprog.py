@@ -256,6 +256,9 @@ class TrainPlan(graph.Visitor):
         self._arena: Dict[int, dict] = {}
         self._bwd_acc = torch.zeros(1 << 19, dtype=torch.float64, device=self.device)  # all backward reduction accumulators
         self._bwd_acc_n = 0
+        self._fwd_acc = torch.zeros(1 << 19, dtype=torch.float64, device=self.device)  # all forward BatchNorm accumulators
+        self._fwd_acc_n = 0
+        self._fuse_finalize = os.environ.get("MSL_BN_FINALIZE_SEPARATE") is None
         self._wg_scratch: Dict[int, torch.Tensor] = {}  # per-workgroup dW partials: one buffer per lane (one wgrad runs at a time on a lane)
         self._lane = 0
         self.use_lanes = os.environ.get("MSLESSEG_LANES", "1") != "0"
@@ -332,8 +335,12 @@ class TrainPlan(graph.Visitor):
         self._bw_builders.append((build, self._lane))
 
     def _acc(self, C) -> torch.Tensor:
-        t = torch.zeros(2 * C * ACC_SLOTS, dtype=torch.float64, device=self.device)
-        self._keep.append(t)
+        """Forward BatchNorm accumulator f64[slots][2C]: a slice of ONE buffer.  BN_FINALIZE resets its own slice after reading it; the layers
+        whose finalize is fused into BN_ACT cannot (forward() zeroes the whole buffer once per step instead — one memset)."""
+        n = 2 * C * ACC_SLOTS
+        assert self._fwd_acc_n + n <= self._fwd_acc.numel()
+        t = self._fwd_acc[self._fwd_acc_n : self._fwd_acc_n + n]
+        self._fwd_acc_n += n
         return t
 
     def _acc_bwd(self, C, slots=1) -> torch.Tensor:
@@ -395,13 +402,21 @@ class TrainPlan(graph.Visitor):
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C}
         if not fused:
             self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co, 21: ACC_SLOTS}))
-        self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var")),
-                               i={**dims, 21: ACC_SLOTS}, f=(BN_EPS, BN_MOM)))
+        # small layers: the finalize rides in BN_ACT (a separate 5 us launch on the forward chain costs more than recomputing it per workgroup)
+        fuse = self._fuse_finalize and self.N * z.H * z.W * C <= 20_000_000 and C <= 1024
+        if not fuse:
+            self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var")),
+                                   i={**dims, 21: ACC_SLOTS}, f=(BN_EPS, BN_MOM)))
         i = {**dims, 10: z.cs, 11: z.co, 12: y.cs, 13: y.co, 18: 1 if act else 0}
         rp = 0
         if res is not None:
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
-        self._f(hiplib.make_op(hiplib.OP_BN_ACT, self.dtype, p=(z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), rp, y.t.data_ptr(), st.ptr(name + ".beta")), i=i))
+        p = (z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), rp, y.t.data_ptr(), st.ptr(name + ".beta"))
+        f = ()
+        if fuse:
+            i[16], i[21] = (st.bptr(name + ".var") - st.bptr(name + ".mean")) // 4, ACC_SLOTS
+            p, f = p + (acc.data_ptr(), st.bptr(name + ".mean")), (BN_EPS, BN_MOM)
+        self._f(hiplib.make_op(hiplib.OP_BN_ACT, self.dtype, p=p, i=i, f=f))
         return stats
 
     def _bn_backward(self, ops, name, z: View, y: View, C, act, stats, res: Optional[View], res_inplace=False):
@@ -816,6 +831,7 @@ class TrainPlan(graph.Visitor):
         self.pack_program.run(torch.cuda.current_stream(self.device).cuda_stream)
 
     def forward(self):
+        self._fwd_acc[: self._fwd_acc_n].zero_()  # one memset: the accumulators of the layers whose finalize is fused into BN_ACT are not reset by a kernel
         self._run(self.forward_segments)
 
     def backward(self):
