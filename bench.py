@@ -366,6 +366,31 @@ def slice_extract_bench(dev, host_sample=True):
     return out
 
 
+def volume_plane_bench(eng, dev):
+    """The reference's unit of work around the path: one patient volume, one plane — 182 axial slices of 218 x 182 cut from a 182x218x182
+    volume, rendered, letterboxed to 640 x 544, predicted, merged and inserted into the plane volume (`volume.predict_volume`).  Timed from the
+    host volume (the 58 MB upload is inside) to the finished device volume."""
+    from mslesseg_amd import volume as V
+
+    class _Model:  # predict_volume only needs the engine accessor of the YOLO wrapper
+        def _get_engine(self):
+            return eng
+
+    rng = np.random.default_rng(1)
+    vol = np.asfortranarray(np.clip(rng.normal(300.0, 120.0, size=(182, 218, 182)), 0, None))  # x fastest in memory, as read_nifti / get_fdata return it
+    m = _Model()
+    V.predict_volume(m, vol, "axial")  # plans for the two batch shapes (128 + 54 slices)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        out = V.predict_volume(m, vol, "axial")
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    return {"ms_per_plane_volume": round(dt * 1e3, 2), "slices_per_s_incl_upload_extract_insert": round(182 / dt, 1), "slices": 182,
+            "note": "host float64 volume -> device plane volume; upload 58 MB + MSL_OP_SLICE_EXTRACT + LetterBox + net + NMS + masks + merge + insert"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -444,6 +469,7 @@ def main():
             line["roofline"] = None if args.no_roofline else predict_roofline(eng, imgs, out, args, value / world)
             line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_predict(pstate, host[: min(B, 64)])
             line["slice_extract"] = None if args.no_roofline else slice_extract_bench(dev, host_sample=not args.no_cpu_baseline)
+            line["volume_plane"] = None if args.no_roofline else volume_plane_bench(eng, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
