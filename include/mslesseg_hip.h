@@ -173,6 +173,8 @@ enum {
                                      1 slice indices i32 [B], 2 tables u8 (grey[256], GC[256], sRGB->L8[256], L8->sRGB[256], LT[256][256]),
                                      4 out u8 [B][H][W][3] (corte.T, rows flipped; H,W = slice cols,rows); i 0 X,1 Y,2 Z,
                                      3 axis (0 sagital,1 coronal,2 axial), 4 B, 5 variant (0 none,1 HE,2 CLAHE,3 GC,4 LT) */
+  MSL_OP_SGD = 36,                /* SGD + Nesterov momentum over a flat fp32 range (optimizer=auto beyond 10 000 iterations): p 0 params, 1 grads,
+                                     2 momentum buffer, 5 clip scale f32[1]|NULL ; i 0,1 n, 2 first step ; f 0 lr, 1 momentum, 2 weight decay */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

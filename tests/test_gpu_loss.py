@@ -34,7 +34,7 @@ def _views(B, S, nc, proto_bf16, seed, spread=1.0):
     return levels, glevels, proto, gproto
 
 
-def _labels(B, S, nc, seed, empty=()):
+def _labels(B, S, nc, seed, empty=(), count=None, size=(0.08, 0.5)):
     """Random rectangles as instances (overlap-encoded masks at S/4), some slices without any."""
     rng = np.random.default_rng(seed)
     m = S // 4
@@ -43,8 +43,8 @@ def _labels(B, S, nc, seed, empty=()):
     for b in range(B):
         if b in empty:
             continue
-        for j in range(int(rng.integers(1, 5))):
-            w, h = rng.uniform(0.08, 0.5, 2)
+        for j in range(int(rng.integers(1, 5)) if count is None else count[b]):
+            w, h = rng.uniform(size[0], size[1], 2)
             cx, cy = rng.uniform(w / 2, 1 - w / 2), rng.uniform(h / 2, 1 - h / 2)
             x1, y1, x2, y2 = (np.array([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2]) * m).astype(int)
             masks[b, y1 : y2 + 1, x1 : x2 + 1] = j + 1
@@ -98,6 +98,30 @@ def test_seg_loss_matches_torch_autograd(B, S, nc, bf16, empty, spread):
     tol = (8e-3 if bf16 else 1e-3) * float(want.abs().max()) + 1e-7  # bf16 gradient storage: 2^-9 relative rounding
     assert float((got - want).abs().max()) <= tol
     # the discrete part: same number of foreground anchors as the reference assignment
+    assert items[5] == pytest.approx(float(sum((g.abs().sum(-1) > 0).sum() for g in ref_grads[0:9:3])), abs=0.5)
+
+
+def test_seg_loss_more_than_64_instances_in_one_slice():
+    """A mosaic of four lesion-rich slices can exceed 64 instances (the demo masks already show 14 components per slice): the anchor
+    claim word counts claims instead of holding one bit per instance, so up to 255 instances (one byte of the overlap encoding) fit."""
+    from mslesseg_amd.hiplib import MSL_F32
+    from mslesseg_amd.segloss import SegLossOp, device_targets
+
+    B, S, nc = 2, 320, 1
+    levels, glevels, proto, gproto = _views(B, S, nc, False, seed=77)
+    batch = _labels(B, S, nc, seed=9, count=(97, 3), size=(0.04, 0.12))
+    op = SegLossOp(levels, glevels, proto, gproto, nc, S, S, MSL_F32, "cuda:0")
+    gt, masks = device_targets(batch, B, S, S, "cuda:0")
+    assert gt.shape[1] == 97
+    items = op(gt, masks).cpu().numpy()
+    ref_items, ref_grads = _reference(levels, proto, batch, nc, B)
+    np.testing.assert_allclose(items[:4], ref_items.cpu().numpy(), rtol=2e-4, atol=1e-6)
+    k = 0
+    for lv in glevels:
+        for gv in lv:
+            got, want = gv.torch().float().cpu(), ref_grads[k].cpu()
+            assert float((got - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-7
+            k += 1
     assert items[5] == pytest.approx(float(sum((g.abs().sum(-1) > 0).sum() for g in ref_grads[0:9:3])), abs=0.5)
 
 

@@ -59,6 +59,51 @@ def test_adamw_kernel_matches_torch_adamw():
     assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_sgd_kernel_matches_torch_sgd_nesterov():
+    """The SGD branch of optimizer='auto' (> 10 000 iterations) [UPSTREAM build_optimizer: SGD(lr 0.01, momentum, nesterov=True)]."""
+    from mslesseg_amd import hiplib
+
+    g = torch.Generator().manual_seed(1)
+    n = 4099
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, nesterov=True, weight_decay=5e-4)
+    p, buf = p0.clone().cuda(), torch.zeros(n).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    for t in range(1, 5):
+        ref.grad = gr * t
+        opt.step()
+        gd = (gr * t).cuda()
+        hiplib.launch(hiplib.make_op(hiplib.OP_SGD, hiplib.MSL_F32, p=(p.data_ptr(), gd.data_ptr(), buf.data_ptr(), 0, 0, 0), i={0: n, 1: 0, 2: 1 if t == 1 else 0},
+                                     f=(0.01, 0.9, 5e-4)), s)
+    torch.cuda.synchronize()
+    assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_optimizer_auto_takes_sgd_beyond_10k_iterations_and_feeder_errors_surface(tmp_path):
+    from mslesseg_amd.train import Trainer
+    from ultralytics import YOLO
+
+    ds = D.SyntheticSegDataset(8, 64, seed=0)
+    model = YOLO("yolo11n-seg.pt", precision="fp32")
+    tr = Trainer(model, dataset=ds, val_dataset=None, epochs=20000, batch=4, project=tmp_path, name="sgd", imgsz=64, nbs=4, augment=False, max_iters=3)
+    assert tr.optimizer == "SGD" and tr.lr0 == 0.01  # ceil(8 / max(4, 4)) * 20000 = 40 000 iterations
+    before = tr.store.p.clone()
+    tr.fit()
+    assert bool(torch.isfinite(tr.store.p).all()) and float((tr.store.p - before).abs().max()) > 0
+    assert Trainer(model, dataset=ds, val_dataset=None, epochs=10, batch=4, project=tmp_path, name="adamw", imgsz=64, nbs=4).optimizer == "AdamW"
+
+    class Broken(D.SyntheticSegDataset):
+        def get(self, i):
+            if i == 5:
+                raise OSError("unreadable label file")
+            return super().get(i)
+
+    bad = Trainer(model, dataset=Broken(8, 64, seed=0), val_dataset=None, epochs=1, batch=4, project=tmp_path, name="bad", imgsz=64, nbs=4, augment=False)
+    with pytest.raises(RuntimeError, match="data feeder failed"):
+        bad.fit()
+
+
 def test_train_through_the_reference_call_signature(tmp_path):
     """`entrenar_fold` [REF scripts/train.py:346-366]: staged `images/` + `labels/` folders (labels from the mask converter, PNG slices
     like `plt.imsave` writes them), the YAML of `generar_yaml`, then `.train(data=<yaml>, epochs=E, batch=-1, cache=True, project=…,

@@ -29,3 +29,21 @@ def test_slice_extraction_matches_oracle(demo_volumes, plano):
         b = P.slice_to_png_array(P.take_slice(fl, plano, i))
         assert np.array_equal(a, b)
     assert V.expected_slice_shape(fl.shape, plano) == {"axial": (182, 218), "coronal": (182, 182), "sagital": (218, 182)}[plano]
+
+
+def test_select_slices_restates_indices_a_usar(demo_volumes):
+    """[REF utils/Paciente.py:267-295]: every lesion-bearing slice, or the `num_cortes` central ones; P39's counts are the facts
+    tests/test_oracle_pins.py pins from the reference's demo volume (101 axial / 147 coronal / 113 sagittal)."""
+    from mslesseg_amd import volume as V
+
+    gt = demo_volumes["P39_mask"]
+    for plano, n in (("axial", 101), ("coronal", 147), ("sagital", 113)):
+        idx = V.select_slices(gt, plano)
+        assert len(idx) == n and idx == sorted(idx)
+        ax = V.PLANE_AXIS[plano]
+        assert all(np.take(gt, i, axis=ax).any() for i in idx)
+        assert V.select_slices(gt, plano, 1000) == idx
+        sub = V.select_slices(gt, plano, 50)
+        centro, start = n // 2, max(0, n // 2 - 25)
+        assert sub == idx[start : start + 50] and len(sub) == 50 and idx[centro] in sub
+    assert V.select_slices(np.zeros((4, 5, 6), np.uint8), "axial", 3) == []

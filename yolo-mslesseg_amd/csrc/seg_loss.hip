@@ -12,7 +12,8 @@
 // Stages (one launch each; B = slices, A = anchors of all levels, n = max instances per slice of this batch):
 //   1 decode    (b,a)   softmax-expectation of the 4x16 DFL logits → predicted box (grid units)
 //   2 metric    (b,a)   for every gt j: inside-gt test, CIoU overlap, align = score^0.5 * overlap^6        → [B,n,A]
-//   3 topk      (b,j)   10 best anchors per gt (ties → lowest anchor index), set bit j of posmask[b,a]
+//   3 topk      (b,j)   10 best anchors per gt (ties → lowest anchor index); posmask[b,a] += 1<<32 | j (claim count | gt index: a gt
+//                       claims an anchor at most once, so any number of instances fits — the old one-bit-per-gt word capped n at 64)
 //   4 resolve   (b,a)   anchors claimed by several gts go to the highest overlap; per-gt maxima for the normalisation
 //   5 gather    (b)     normalised target score per foreground anchor, sum of target scores, ordered foreground list
 //   6 main      (b,a)   cls BCE, CIoU, DFL and their gradients
@@ -45,7 +46,7 @@ struct SlArgs {
   float* pb;                    // [B][A][4]
   float* align;                 // [B][n][A]
   float* ov;                    // [B][n][A]   (-1 where the anchor is not a candidate of the gt)
-  unsigned long long* posmask;  // [B][A]
+  unsigned long long* posmask;  // [B][A]  claim count << 32 | sum of the claiming gt indices (= the gt index when the count is 1)
   int* tgi;                     // [B][A]
   float* norm;                  // [B][A]
   uint8_t* fg;                  // [B][A]
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void sl_topk_kernel(SlArgs s) {
     if (bi >= s.A) break;  // fewer than 10 anchors in total (block-uniform)
     if (threadIdx.x == 0) {
       sv[bi] = -2.0f;
-      if (s.ov[((long)b * s.n + j) * s.A + bi] >= 0.f) atomicOr(s.posmask + (long)b * s.A + bi, 1ull << j);
+      if (s.ov[((long)b * s.n + j) * s.A + bi] >= 0.f) atomicAdd(s.posmask + (long)b * s.A + bi, (1ull << 32) | (unsigned long long)j);
     }
     __syncthreads();
   }
@@ -224,10 +225,10 @@ __global__ __launch_bounds__(256) void sl_resolve_kernel(SlArgs s) {
   if (t >= (long)s.B * s.A) return;
   const int b = (int)(t / s.A), a = (int)(t - (long)b * s.A);
   const unsigned long long bits = s.posmask[t];
-  const int cnt = __popcll(bits);
+  const int cnt = (int)(bits >> 32);
   int j = 0;
   if (cnt == 1) {
-    j = __ffsll((long long)bits) - 1;
+    j = (int)(bits & 0xffffffffull);
   } else if (cnt > 1) {
     float best = -1.0f;
     for (int k = 0; k < s.n; ++k) {
@@ -603,7 +604,7 @@ int msl_launch_seg_loss(const msl_op& op, hipStream_t st) {
   s.p_cs = op.i[10]; s.p_co = op.i[11]; s.gp_cs = op.i[12]; s.gp_co = op.i[13];
   s.imgh = (float)op.i[14]; s.imgw = (float)op.i[15];
   MSL_REQUIRE(s.tab && s.masks && s.proto && op.p[5] && op.p[6] && (s.no_grad || s.gproto) && (s.n == 0 || s.gt), "seg_loss: null pointer");
-  MSL_REQUIRE(s.B > 0 && s.A > 0 && s.nc > 0 && s.n >= 0 && s.n <= 64 && s.mh > 0 && s.mw > 0 && s.nlev >= 1 && s.nlev <= 3, "seg_loss: bad dims (n_max <= 64, 1-3 levels)");
+  MSL_REQUIRE(s.B > 0 && s.A > 0 && s.nc > 0 && s.n >= 0 && s.n <= 255 && s.mh > 0 && s.mw > 0 && s.nlev >= 1 && s.nlev <= 3, "seg_loss: bad dims (n_max <= 255: the overlap mask encoding is one byte, 1-3 levels)");
   MSL_REQUIRE(s.p_cs % 4 == 0 && s.p_co % 4 == 0 && s.p_co + 32 <= s.p_cs && (s.no_grad || (s.gp_cs % 4 == 0 && s.gp_co % 4 == 0 && s.gp_co + 32 <= s.gp_cs)), "seg_loss: bad prototype views");
   MSL_REQUIRE(((uintptr_t)op.p[5] & 255) == 0 && (size_t)s.A * 4 <= 160 * 1024 - 1024, "seg_loss: workspace must be 256-byte aligned; A too large for the top-k stage");
   const SlCarve c = sl_carve(s.B, s.A, s.n);

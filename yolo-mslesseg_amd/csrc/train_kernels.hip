@@ -1139,6 +1139,30 @@ int msl_launch_adamw(const msl_op& op, hipStream_t s) {
   return MSL_OK;
 }
 
+// SGD with Nesterov momentum over a flat range — the branch `optimizer=auto` takes beyond 10 000 iterations [UPSTREAM engine/trainer.py
+// build_optimizer: SGD(lr 0.01, momentum, nesterov=True); torch.optim.SGD: g += wd*p; buf = mu*buf + g (buf = g on the first step);
+// p -= lr*(g + mu*buf)].  `first` = 1 on the first step of the buffer.
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, float lr, float mu, float wd,
+                                                  int first, const float* __restrict__ gscale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gs = gscale ? *gscale : 1.0f;
+  const float pi = p[i];
+  const float gi = g[i] * gs + wd * pi;
+  const float bi = first ? gi : mu * buf[i] + gi;
+  buf[i] = bi;
+  p[i] = pi - lr * (gi + mu * bi);
+}
+// p 0 params, 1 grads, 2 momentum buffer, 5 gscale f32[1]|NULL ; i 0 n_lo,1 n_hi, 2 first step (0|1) ; f 0 lr, 1 momentum, 2 weight decay
+int msl_launch_sgd(const msl_op& op, hipStream_t s) {
+  const long n = ((long)op.i[1] << 31) | (long)op.i[0];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && n > 0, "sgd: bad args");
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float*)op.p[0], (const float*)op.p[1], (float*)op.p[2], n,
+                     op.f[0], op.f[1], op.f[2], op.i[2], (const float*)op.p[5]);
+  MSL_CHECK_LAUNCH("sgd");
+  return MSL_OK;
+}
+
 // EMA: e = d*e + (1-d)*p over a flat range  [UPSTREAM ModelEMA.update]
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long n, float d) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -19,6 +19,7 @@ from . import labels as L
 
 IMGSZ = 640
 PAD = 114
+MAX_INSTANCES = 255  # per slice: pixel value of the overlap mask = 1 + instance index (uint8)
 
 
 # ------------------------------------------------------------------------------------------------- raster / warp
@@ -97,6 +98,41 @@ class SegDataset:
         img, inst = self.items[i]
         h, w = img.shape[:2]
         return img, [(c, p * np.array([w, h], dtype=np.float32)) for c, p in inst]  # polygons in pixels
+
+
+class VolumeSliceDataset:
+    """The dataset `extraer_dataset` would stage for one patient volume, built in memory: per plane the lesion-bearing slices
+    (`volume.select_slices` = Paciente.indices_a_usar), each rendered like `plt.imsave(corte.T, cmap="gray", origin="lower")` + `cv2.imread`
+    (`volume.slice_as_png_array`), its GT mask cut the same way and traced into polygons like `convert_segment_masks_to_yolo_seg` writes them
+    (normalised, 6 decimals) [REF scripts/extraer_dataset.py:174-227, utils/Paciente.py:281-295].  Items are what `SegDataset` caches."""
+
+    def __init__(self, flair: np.ndarray, mask: np.ndarray, planes=("axial", "coronal", "sagital"), num_cortes=None, mejora=None, imgsz: int = IMGSZ,
+                 keep=None):
+        from . import volume as V
+        from .enhance import aplicar_mejora
+
+        self.imgsz, self.items, self.index = imgsz, [], []
+        for plano in planes:
+            for i in V.select_slices(mask, plano, num_cortes):
+                if keep is not None and not keep(plano, i):
+                    continue
+                png = V.slice_as_png_array(aplicar_mejora(V.take_slice(flair, plano, i), mejora))
+                m = np.ascontiguousarray(V.take_slice(mask, plano, i).T[::-1] > 0)
+                h, w = m.shape
+                inst = []
+                for c in L.find_external_contours(m):
+                    if len(c) >= 3:
+                        inst.append((0, np.stack([np.round(c[:, 0] / w, 6), np.round(c[:, 1] / h, 6)], 1).astype(np.float32)))
+                self.items.append((resize_keep_ratio(np.ascontiguousarray(png[..., ::-1]), imgsz), inst))
+                self.index.append((plano, i))
+
+    def __len__(self):
+        return len(self.items)
+
+    def get(self, i):
+        img, inst = self.items[i]
+        h, w = img.shape[:2]
+        return img, [(c, p * np.array([w, h], dtype=np.float32)) for c, p in inst]
 
 
 class SyntheticSegDataset:
@@ -224,6 +260,11 @@ def collate(samples: Sequence[Tuple[np.ndarray, list]], size: int = IMGSZ, mask_
         polys = [(c, p) for c, p in inst if len(p) >= 3]
         areas = [0.5 * abs(np.dot(p[:, 0], np.roll(p[:, 1], 1)) - np.dot(p[:, 1], np.roll(p[:, 0], 1))) for _, p in polys]
         order = np.argsort(areas)[::-1]
+        if len(order) > MAX_INSTANCES:  # one byte per pixel in the overlap encoding: keep the largest instances, deterministically, and say so
+            import logging
+
+            logging.getLogger("ultralytics").warning(f"slice {b} of the batch holds {len(order)} instances: keeping the {MAX_INSTANCES} largest")
+            order = order[:MAX_INSTANCES]
         for j, k in enumerate(order):
             c, p = polys[k]
             fill_polygon(masks[b], p / mask_ratio, j + 1)

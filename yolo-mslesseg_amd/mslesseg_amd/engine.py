@@ -23,6 +23,16 @@ IOU_THRES = 0.7  # [REF trains/Base/…/args.yaml:41]
 MAX_DET = 300  # [REF …/args.yaml:42]
 
 
+def precision_code(name: str) -> int:
+    """'bf16' | 'fp32' → MSL_BF16 | MSL_F32 (the storage / arithmetic type of an engine)."""
+    n = str(name).lower()
+    if n in ("bf16", "bfloat16"):
+        return MSL_BF16
+    if n in ("fp32", "f32", "float32"):
+        return MSL_F32
+    raise ValueError(f"unknown precision {name!r} (bf16 | fp32)")
+
+
 def _dt(dtype: int) -> torch.dtype:
     return torch.float32 if dtype == MSL_F32 else torch.bfloat16
 

@@ -80,8 +80,8 @@ class SegLossOp:
         if B != self.B or gt.dtype != torch.float32 or masks.dtype != torch.uint8 or tuple(masks.shape) != (B, self.proto.H, self.proto.W):
             raise ValueError(f"seg_loss: gt {tuple(gt.shape)} {gt.dtype} / masks {tuple(masks.shape)} {masks.dtype} do not match the plan "
                              f"(B={self.B}, proto {self.proto.H}x{self.proto.W})")
-        if n > 64:
-            raise ValueError("seg_loss: more than 64 instances in one slice")
+        if n > 255:  # data.collate never produces this: the overlap mask encoding is one byte per pixel, so it keeps the 255 largest instances
+            raise ValueError("seg_loss: more than 255 instances in one slice")
         gt, masks = gt.contiguous(), masks.contiguous()
         ws = self._workspace(n)
         base = ws.data_ptr()

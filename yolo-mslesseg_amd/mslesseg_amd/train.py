@@ -21,7 +21,7 @@ import struct
 import threading
 import time
 from pathlib import Path
-from queue import Queue
+from queue import Full, Queue
 from typing import Optional
 
 import numpy as np
@@ -32,7 +32,7 @@ from . import data as D
 from . import hiplib, params
 from .hiplib import MSL_BF16, MSL_F32
 from .loss import segmentation_loss
-from .segloss import SegLossOp, pack_targets
+from .segloss import SegLossOp, device_targets, pack_targets
 from .trainprog import ParamStore, TrainPlan
 
 RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss", "metrics/precision(B)", "metrics/recall(B)",
@@ -40,7 +40,8 @@ RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cl
                   "val/box_loss", "val/seg_loss", "val/cls_loss", "val/dfl_loss", "lr/pg0", "lr/pg1", "lr/pg2"]  # [REF trains/…/results.csv:1]
 
 DEFAULTS = dict(imgsz=640, nbs=64, seed=0, lrf=0.01, warmup_epochs=3.0, warmup_bias_lr=0.0, weight_decay=0.0005, close_mosaic=10,
-                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=None, augment=True, val_max=None)
+                beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=None, augment=True, val_max=None,
+                optimizer=None, momentum=0.937, warmup_momentum=0.8)
 
 
 def _fbits(x: float) -> int:
@@ -152,14 +153,19 @@ class Trainer:
         self.nb = max(math.ceil(per_rank / self.batch), 1)
         total_batch = self.batch * self.world
         iterations = math.ceil(len(self.ds) / max(total_batch, self.hyp["nbs"])) * self.epochs
-        self.optimizer = "AdamW" if iterations <= 10000 else "AdamW"  # SGD branch of 'auto' (>10k iterations) is not built
-        self.lr0 = round(0.002 * 5 / (4 + self.nc), 6)
+        # optimizer='auto' [UPSTREAM build_optimizer]: AdamW(lr 0.002*5/(4+nc)) up to 10 000 iterations, SGD(lr 0.01, Nesterov) beyond; every run of
+        # the reference takes the AdamW branch (<= 8 700 iterations, pinned by its 25 results.csv — tests/test_oracle_pins.py)
+        self.optimizer = self.hyp.get("optimizer") or ("AdamW" if iterations <= 10000 else "SGD")
+        if self.optimizer not in ("AdamW", "SGD"):
+            raise ValueError(f"optimizer {self.optimizer!r}: only the two branches of 'auto' (AdamW, SGD) exist here")
+        self.lr0 = round(0.002 * 5 / (4 + self.nc), 6) if self.optimizer == "AdamW" else 0.01
         self.sched = Schedule(self.nb, self.epochs, self.lr0, self.hyp["lrf"], self.hyp["warmup_epochs"], total_batch, self.hyp["nbs"])
         self.wd = self.hyp["weight_decay"] * total_batch * max(round(self.hyp["nbs"] / total_batch), 1) / self.hyp["nbs"]
         self.opt_steps = 0
         self.ema_p, self.ema_b, self.ema_updates = self.store.p.clone(), self.store.b.clone(), 0
         self.gscale = torch.ones(1, dtype=torch.float32, device=self.device)
         self.best_fitness, self.t0 = None, None
+        self.ni = 0  # iterations seen (the momentum warm-up of the SGD branch reads it)
 
     # ------------------------------------------------------------------ data feeding
     def _batches(self, epoch: int):
@@ -168,23 +174,42 @@ class Trainer:
         mine = shard_indices(n, epoch, self.hyp["seed"], self.rank, self.world)
         mosaic = epoch < self.epochs - self.hyp["close_mosaic"]
         q: Queue = Queue(maxsize=4)
+        stop = threading.Event()
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except Full:
+                    continue
+            return False
 
         def work():
-            for b in range(self.nb):
-                idx = [int(mine[(b * self.batch + j) % len(mine)]) for j in range(self.batch)]
-                if self.hyp["augment"]:
-                    samples = [D.augment(self.ds, i, rng, mosaic, self.hyp["imgsz"]) for i in idx]
-                else:
-                    samples = [D.plain(self.ds, i, self.hyp["imgsz"]) for i in idx]
-                q.put(D.collate(samples, self.hyp["imgsz"]))
-            q.put(None)
+            try:
+                for b in range(self.nb):
+                    idx = [int(mine[(b * self.batch + j) % len(mine)]) for j in range(self.batch)]
+                    if self.hyp["augment"]:
+                        samples = [D.augment(self.ds, i, rng, mosaic, self.hyp["imgsz"]) for i in idx]
+                    else:
+                        samples = [D.plain(self.ds, i, self.hyp["imgsz"]) for i in idx]
+                    if not put(D.collate(samples, self.hyp["imgsz"])):
+                        return
+                put(None)
+            except BaseException as e:  # a bad label file, a shape mismatch …: hand it to the training loop instead of dying silently
+                put(e)
 
         threading.Thread(target=work, daemon=True).start()
-        while True:
-            item = q.get()
-            if item is None:
-                return
-            yield item
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise RuntimeError(f"data feeder failed: {item!r}") from item
+                yield item
+        finally:
+            stop.set()  # early exit (max_iters, an exception in the step): the feeder stops waiting on the queue
 
     # ------------------------------------------------------------------ one optimisation step
     def to_device(self, batch):
@@ -246,9 +271,14 @@ class Trainer:
             n = hi - lo
             if n <= 0:
                 continue
-            op = hiplib.make_op(hiplib.OP_ADAMW, MSL_F32, p=(st.p.data_ptr() + 4 * lo, st.g.data_ptr() + 4 * lo, st.m.data_ptr() + 4 * lo,
-                                                             st.v.data_ptr() + 4 * lo, 0, self.gscale.data_ptr()),
-                                i={0: n & 0x7FFFFFFF, 1: n >> 31, 2: _fbits(wd), 3: _fbits(bc1), 4: _fbits(bc2)}, f=(lr, h["beta1"], h["beta2"], h["eps"]))
+            if self.optimizer == "SGD":  # momentum warms up from 0.8 to 0.937 with the learning rate [UPSTREAM BaseTrainer warm-up]
+                mu = float(np.interp(min(self.ni, max(self.sched.nw, 0)), [0, max(self.sched.nw, 1)], [h["warmup_momentum"], h["momentum"]])) if self.sched.nw > 0 else h["momentum"]
+                op = hiplib.make_op(hiplib.OP_SGD, MSL_F32, p=(st.p.data_ptr() + 4 * lo, st.g.data_ptr() + 4 * lo, st.m.data_ptr() + 4 * lo, 0, 0, self.gscale.data_ptr()),
+                                    i={0: n & 0x7FFFFFFF, 1: n >> 31, 2: 1 if t == 1 else 0}, f=(lr, mu, wd))
+            else:
+                op = hiplib.make_op(hiplib.OP_ADAMW, MSL_F32, p=(st.p.data_ptr() + 4 * lo, st.g.data_ptr() + 4 * lo, st.m.data_ptr() + 4 * lo,
+                                                                 st.v.data_ptr() + 4 * lo, 0, self.gscale.data_ptr()),
+                                    i={0: n & 0x7FFFFFFF, 1: n >> 31, 2: _fbits(wd), 3: _fbits(bc1), 4: _fbits(bc2)}, f=(lr, h["beta1"], h["beta2"], h["eps"]))
             hiplib.launch(op, s)
         st.g.zero_()
         # EMA of parameters and BN running statistics
@@ -258,59 +288,47 @@ class Trainer:
             n = e.numel()
             hiplib.launch(hiplib.make_op(hiplib.OP_EMA, MSL_F32, p=(e.data_ptr(), src.data_ptr()), i={0: n & 0x7FFFFFFF, 1: n >> 31}, f=(d,)), s)
 
-    # ------------------------------------------------------------------ validation (losses on the held-out fold, EMA weights)
+    # ------------------------------------------------------------------ validation (held-out fold, EMA weights, eval-mode BatchNorm)
     @torch.no_grad()
-    def _val_losses(self) -> np.ndarray:
-        if self.val_ds is None or len(self.val_ds) == 0:
-            return np.zeros(4)
-        st = self.store
-        keep_p, keep_b = st.p.clone(), st.b.clone()
-        st.p.copy_(self.ema_p)
-        tot, cnt = np.zeros(4), 0
-        n = len(self.val_ds)
-        for b0 in range(0, min(n, 8 * self.batch), self.batch):
-            idx = [(b0 + j) % n for j in range(self.batch)]
-            batch = D.collate([D.plain(self.val_ds, i, self.hyp["imgsz"]) for i in idx], self.hyp["imgsz"])
-            self.plan.in_view.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
-            self.plan.pack()
-            self.plan.forward()
-            db = self.to_device({k: v for k, v in batch.items() if k != "img"})
-            tot += self.loss_op(db["gt"], db["masks"], no_grad=True)[:4].cpu().numpy()
-            cnt += 1
-        st.p.copy_(keep_p)
-        st.b.copy_(keep_b)  # validation must not move the running statistics
-        return tot / max(cnt, 1)
-
-    @torch.no_grad()
-    def _val_metrics(self):
-        """Box/mask P, R, mAP50, mAP50-95 on the held-out fold with the EMA weights (eval-mode BN, conf 0.001, IoU 0.7, max_det 300)
-        [UPSTREAM SegmentationValidator]; masks are compared at proto resolution like upstream's default `process_mask`."""
+    def _validate(self):
+        """One eval-mode pass over the held-out fold with the EMA weights → (val losses [4], metrics dict | None)  [UPSTREAM SegmentationValidator:
+        the validator runs the EMA model in eval mode (running BatchNorm statistics), accumulates v8SegmentationLoss on its raw head outputs for
+        the val/* columns and scores NMS(conf 0.001, IoU 0.7, max_det 300) detections for box/mask P, R, mAP50, mAP50-95].  Masks are compared at
+        prototype resolution like upstream's default `process_mask`.  `val_max` (not a reference setting) bounds the slices for quick runs and
+        is recorded in args.yaml."""
         from . import metrics as MT
         from .engine import InferEngine
 
         if self.val_ds is None or len(self.val_ds) == 0:
-            return None
+            return np.zeros(4), None
         S, n = self.hyp["imgsz"], len(self.val_ds)
-        limit = self.hyp.get("val_max") or n
+        limit = min(n, self.hyp.get("val_max") or n)
         sd = self.store.state_dict(p=self.ema_p, b=self.ema_b)
         eng = InferEngine({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, self.store.scale, self.nc, self.dtype, str(self.device),
                           conf=0.001, iou=0.7, max_det=300)
         stats = MT.SegStats()
-        vb = min(self.batch, 16)
-        for b0 in range(0, min(n, limit), vb):
-            idx = list(range(b0, min(b0 + vb, n, limit)))
-            while len(idx) < vb:
-                idx.append(idx[-1])  # pad the last batch; padded entries are not scored
+        vb = min(self.batch, 32)
+        tot, nbat = np.zeros(4), 0
+        loss_ops = {}
+        for b0 in range(0, limit, vb):
+            idx = list(range(b0, min(b0 + vb, limit)))
+            nb_ = len(idx)
             batch = D.collate([D.plain(self.val_ds, i, S) for i in idx], S)
-            plan = eng.plan(vb, S, S)  # validation slices are already letterboxed RGB at the training size: no LetterBox pass
+            plan = eng.plan(nb_, S, S)  # validation slices are already letterboxed RGB at the training size: no LetterBox pass
             plan.input.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
             plan.run()
+            if nb_ not in loss_ops:
+                lv = [plan.builder.levels[i] for i in sorted(plan.builder.levels)]
+                loss_ops[nb_] = SegLossOp(lv, lv, plan.proto, plan.proto, self.nc, S, S, self.dtype, self.device)  # no_grad: the gradient views are never written
+            gt, masks_d = device_targets(batch, nb_, S, S, self.device)
+            tot += loss_ops[nb_](gt, masks_d, no_grad=True)[:4].cpu().numpy()
+            nbat += 1
             cnt = plan.keep_cnt.cpu()
             mh, mw = plan.proto.H, plan.proto.W
             ys = torch.arange(mh, device=self.device, dtype=torch.float32)[None, :, None]
             xs = torch.arange(mw, device=self.device, dtype=torch.float32)[None, None, :]
-            gtm = torch.from_numpy(batch["masks"]).to(self.device)
-            for j in range(len(set(range(b0, min(b0 + vb, n, limit))))):
+            gtm = masks_d
+            for j in range(nb_):
                 k = int(cnt[j])
                 det = plan.det[j, :k]
                 bl = det[:, :4] * (mw / S)
@@ -322,8 +340,8 @@ class Trainer:
                 m = int(sel.sum())
                 gm = (gtm[j][None] == torch.arange(1, m + 1, device=self.device)[:, None, None]).float().reshape(m, -1)
                 stats.add_image(det[:, :4], det[:, 4], det[:, 5], pm, gxyxy, torch.from_numpy(batch["cls"][sel]).to(self.device), gm)
-        del eng
-        return stats.result()
+        del eng, loss_ops
+        return tot / max(nbat, 1), stats.result()
 
     # ------------------------------------------------------------------ files
     def _save(self, epoch: int, fitness: float) -> None:
@@ -339,7 +357,7 @@ class Trainer:
         args = dict(task="segment", mode="train", model=str(self.yolo.ckpt_path), data=self.data_path, epochs=self.epochs, batch=self.batch,
                     imgsz=self.hyp["imgsz"], cache=True, optimizer="auto", seed=self.hyp["seed"], amp="bf16" if self.dtype == MSL_BF16 else False,
                     lr0=self.lr0, lrf=self.hyp["lrf"], weight_decay=self.hyp["weight_decay"], warmup_epochs=self.hyp["warmup_epochs"], nbs=self.hyp["nbs"],
-                    close_mosaic=self.hyp["close_mosaic"], box=7.5, cls=0.5, dfl=1.5, overlap_mask=True, mask_ratio=4, world_size=self.world,
+                    close_mosaic=self.hyp["close_mosaic"], box=7.5, cls=0.5, dfl=1.5, overlap_mask=True, mask_ratio=4, world_size=self.world, val_max=self.hyp.get("val_max"),
                     save_dir=str(self.save_dir))
         (self.save_dir / "args.yaml").write_text(yaml.safe_dump(args, sort_keys=False))
 
@@ -364,12 +382,12 @@ class Trainer:
                 tl += items.cpu().numpy()
                 nb_seen += 1
                 ni += 1
+                self.ni = ni
                 if self.max_iters is not None and ni >= self.max_iters:
                     done = True
                     break
             tl /= max(nb_seen, 1)
-            vl = self._val_losses()
-            mets = self._val_metrics() if self.rank == 0 else None
+            vl, mets = self._validate() if self.rank == 0 else (np.zeros(4), None)  # rank 0 validates; the others meet it again at the next all-reduce
             fitness = mets["fitness"] if mets else -float(tl.sum())
             if self.rank == 0:
                 mcols = [round(float(mets[c]), 5) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
@@ -384,7 +402,8 @@ class Trainer:
         torch.cuda.synchronize(self.device)
         if self.world > 1:
             torch.distributed.barrier()
-        # the trained (EMA) weights become the model's weights, like ultralytics reloads best.pt
-        self.yolo.state = self.store.state_dict(p=self.ema_p, b=self.ema_b)
+        # the best checkpoint becomes the model's weights, like ultralytics' trainer reloads best.pt into the YOLO object after training
+        best = self.wdir / "best.pt"
+        self.yolo.state = params.load_checkpoint(best)["state"] if best.is_file() else self.store.state_dict(p=self.ema_p, b=self.ema_b)
         self.yolo.nc, self.yolo.names, self.yolo._engine = self.nc, self.names, None
         return self

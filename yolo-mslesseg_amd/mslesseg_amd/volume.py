@@ -87,6 +87,25 @@ def take_slice(vol: np.ndarray, plano: str, i: int) -> np.ndarray:
     raise ValueError(f"Plano no reconocido: {plano}")
 
 
+def lesion_slices(mask: np.ndarray, plano: str) -> list:
+    """Indices of the slices of `plano` whose GT mask holds a lesion voxel [REF utils/Paciente.py:267-279 indices_cortes_con_lesion]."""
+    ax = PLANE_AXIS[plano]
+    other = tuple(a for a in range(3) if a != ax)
+    return np.nonzero((np.asarray(mask) > 0).any(axis=other))[0].astype(int).tolist()
+
+
+def select_slices(mask: np.ndarray, plano: str, num_cortes: Optional[int] = None) -> list:
+    """The slice set the reference's dataset stage writes and its predict stage therefore reads (the predict loop globs the PNGs that exist
+    [REF scripts/generar_predicciones.py:205-222]): every lesion-bearing slice, or — when there are more than `num_cortes` — the
+    `num_cortes` central ones of that list [REF utils/Paciente.py:281-295 indices_a_usar]."""
+    valid = lesion_slices(mask, plano)
+    if num_cortes is None or len(valid) <= num_cortes:
+        return valid
+    centro, mitad = len(valid) // 2, num_cortes // 2
+    start = max(0, centro - mitad)
+    return valid[start : start + num_cortes]
+
+
 def slice_as_png_array(vol_slice: np.ndarray) -> np.ndarray:
     """The uint8 [H,W,3] array cv2.imread returns for a slice saved by plt.imsave(corte.T, cmap="gray", origin="lower").
     matplotlib normalises in the input's own float type and in float32 for integer input (the enhanced uint8 variants)."""
