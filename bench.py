@@ -31,6 +31,7 @@ METRIC = "FLAIR slices/sec train+infer at 1/2/4/8 GPU; Dice vs GT volumes"  # BA
 PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
 PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_SLICE_640 = 9.630  # n, nc=1, 640x640, 2*MAC over conv + attention + ConvT; training = 3x
+FWD_GFLOP = {"n": 9.630, "s": 32.90}  # SURVEY §8d, nc=1, 640x640
 
 
 def synthetic_slices(n, h, w, seed):
@@ -45,7 +46,13 @@ def synthetic_slices(n, h, w, seed):
     return np.ascontiguousarray(np.repeat(g[..., None], 3, axis=3))
 
 
-def load_weights():
+def load_weights(scale="n"):
+    """n: the calibrated-random test weights (tests/golden/synth_n_nc1.pt); s (BASELINE configs[2]): seeded random initialisation — there is no
+    checkpoint of that scale anywhere and train-mode BatchNorm uses batch statistics anyway."""
+    if scale != "n":
+        from mslesseg_amd import params
+
+        return {k: (v.float() if v.is_floating_point() else v) for k, v in params.init_state(scale, 1, seed=0).items()}
     st = torch.load(ROOT / "tests" / "golden" / "synth_n_nc1.pt", map_location="cpu", weights_only=True)
     return {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
 
@@ -108,7 +115,7 @@ def predict_setup(args, dev, rank, state, B):
             st = dict(state)
             for i in range(3):
                 st[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + mid
-            probe = E.InferEngine(st, "n", 1, dtype, str(dev))
+            probe = E.InferEngine(st, args.scale, 1, dtype, str(dev))
             kept = float(probe.predict_batch(imgs[:16]).keep_cnt.float().mean().item())
             del probe
             lo, hi = (mid, hi) if kept < args.target_kept else (lo, mid)
@@ -117,7 +124,7 @@ def predict_setup(args, dev, rank, state, B):
         for i in range(3):
             state[f"model.23.cv3.{i}.2.bias"] = state[f"model.23.cv3.{i}.2.bias"] + bias_shift
         torch.cuda.empty_cache()
-    eng = E.InferEngine(state, "n", 1, dtype, str(dev))
+    eng = E.InferEngine(state, args.scale, 1, dtype, str(dev))
     return eng, imgs, host, state, bias_shift
 
 
@@ -151,7 +158,7 @@ def predict_roofline(eng, imgs, out, args, value_per_gpu):
             "hbm_frac": round(d_bytes / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "all_conv": {"tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4), "ms": round(conv_ms, 3),
                          "share_of_program": round(conv_ms / total_ms, 3)},
-            "whole_net_frac_of_mfma_roof": round(value_per_gpu * FWD_GFLOP_PER_SLICE_640 * (S * S / 640.0 / 640.0) / 1e3 / peak, 4),
+            "whole_net_frac_of_mfma_roof": round(value_per_gpu * FWD_GFLOP[args.scale] * (S * S / 640.0 / 640.0) / 1e3 / peak, 4),
             "step_breakdown": {"letterbox_ms": round(ev[0].elapsed_ms(ev[1]), 4), "mask_merge_ms": round(ev[1].elapsed_ms(ev[2]), 4), "program_ms": round(total_ms, 3),
                                "mean_kept_instances_per_slice": round(float(plan.keep_cnt.float().mean().item()), 1),
                                "mask_on_fraction": round(float((out > 0).float().mean().item()), 3)}}
@@ -164,14 +171,14 @@ def predict_roofline(eng, imgs, out, args, value_per_gpu):
     return roof
 
 
-def cpu_baseline_predict(state, imgs_u8, seconds_budget=20.0):
+def cpu_baseline_predict(state, imgs_u8, seconds_budget=20.0, scale="n"):
     """Restated CPU path (ultralytics-on-CPU cannot run here: SURVEY §8d), batch 1 per slice like the reference's loop."""
     from oracle import prepost as P
     from oracle import synth
 
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    om = synth.model_from_state(state)
+    om = synth.model_from_state(state, scale=scale)
     P.generar_prediccion_2D(om, imgs_u8[0])
     t0, n = time.perf_counter(), 0
     while (time.perf_counter() - t0) < seconds_budget and n < 4096:  # bounded sample: ~20 s of host work, cycling over the slices
@@ -191,11 +198,11 @@ def train_setup(args, dev, rank, world, state, B):
 
     y = YOLO.__new__(YOLO)  # a model object around the benchmark weights (no checkpoint file involved)
     y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
-    y.dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
-    y.scale, y.nc, y.state, y.pretrained = "n", 1, state, True
+    y.dtype = y.train_dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
+    y.scale, y.nc, y.state, y.pretrained = args.scale, 1, state, True
     ds = D.SyntheticSegDataset(B, args.size, seed=rank)
     tr = Trainer(y, dataset=ds, val_dataset=None, epochs=1, batch=B, project=ROOT / "gpurun_out" / "bench_runs", name=f"r{rank}",
-                 imgsz=args.size, nbs=B * world, warmup_epochs=0.0)
+                 imgsz=args.size, nbs=B * world, warmup_epochs=0.0, replica=(args.mode == "replicas"))
     batch = D.collate([D.plain(ds, i, args.size) for i in range(B)], args.size)
     dbatch = tr.to_device(batch)
     return tr, dbatch, batch
@@ -263,7 +270,7 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             "all_conv_fwd_dgrad": {"tflops": round(cv_fl / (cv_ms * 1e-3) / 1e12, 2), "frac": round(cv_fl / (cv_ms * 1e-3) / 1e12 / PEAK[args.dtype], 4), "ms": round(cv_ms, 3)},
             "program_ms": {"total_fwd_bwd_pack": round(total, 3),
                            **{f"{t}:{names.get(k, 'torch-attention')}": round(v, 3) for (t, k), v in sorted(by_kind.items(), key=lambda x: -x[1])[:14]}},
-            "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP_PER_SLICE_640 * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4)}
+            "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP[args.scale] * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4)}
     def shape_of(o):
         J = o.i
         return {"N": J[0], "H": J[1], "W": J[2], "Cin": J[3], "Ho": J[4], "Wo": J[5], "Cout": J[6], "k": J[7], "stride": J[8]}
@@ -274,6 +281,7 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             if rec.get("kernel") == kname and rec.get("launch_shape") == roof["launch_shape"]:
                 roof["traffic"] = rec["traffic_bytes_per_launch"]
                 roof["traffic_note"] = rec.get("note", "")
+                roof["traffic_source"] = "profiles/pmc_latest.json: a committed rocprofv3 --pmc summary of an earlier run of this kernel and shape (scripts/pmc_traffic.py), not collected in this run"
     if args.replay_dominant > 0:  # for the PMC passes: the three longest MFMA launches, each alone and back to back, as the LAST dispatches of the process
         s_ = torch.cuda.current_stream(tr.device).cuda_stream
         torch.cuda.synchronize(tr.device)
@@ -309,14 +317,14 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
     return roof
 
 
-def cpu_baseline_train(state, batch, seconds_budget=20.0):
+def cpu_baseline_train(state, batch, seconds_budget=20.0, scale="n"):
     """Oracle train step (train-mode forward + oracle loss + autograd backward) on the host cores, bounded sample."""
     from oracle import loss as OL
     from oracle import yolo11seg as Y
 
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    m = Y.build("n", 1)
+    m = Y.build(scale, 1)
     m.load_state_dict(state)
     m.train()
     n_img, t0, steps, bs = 0, time.perf_counter(), 0, 2
@@ -391,16 +399,89 @@ def volume_plane_bench(eng, dev):
             "note": "host float64 volume -> device plane volume; upload 58 MB + MSL_OP_SLICE_EXTRACT + LetterBox + net + NMS + masks + merge + insert"}
 
 
+def train_e2e_bench(args, dev, rank, world, state, B):
+    """`model.train()`'s real loop: batches come from the data feeder (mosaic on, the reference's augmentation set) instead of one resident batch.
+    Dataset: the lesion slices of demo patient P39 rendered as the reference's dataset stage writes them (361 slices, three planes), repeated 8x
+    so that an epoch has ~22 iterations at batch 128 like the reference's folds (112-174 iterations per epoch)."""
+    from mslesseg_amd import data as D
+    from mslesseg_amd import hiplib
+    from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
+    from mslesseg_amd.train import Trainer
+    from mslesseg_amd.yolo import YOLO
+
+    z = np.load(ROOT / "tests" / "golden" / "demo_volumes.npz")
+    shape = tuple(int(v) for v in z["P39_shape"])
+    mask = np.unpackbits(z["P39_mask_bits"])[: int(np.prod(shape))].reshape(shape).astype(np.uint8)
+    t0 = time.perf_counter()
+    base = D.VolumeSliceDataset(z["P39_flair_u16"].astype(np.float64), mask)
+    t_ds = time.perf_counter() - t0
+
+    class Repeat:
+        def __init__(self, ds, k):
+            self.ds, self.k = ds, k
+
+        def __len__(self):
+            return len(self.ds) * self.k
+
+        def get(self, i):
+            return self.ds.get(i % len(self.ds))
+
+    ds = Repeat(base, 8)
+    y = YOLO.__new__(YOLO)
+    y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
+    y.dtype = y.train_dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
+    y.scale, y.nc, y.state, y.pretrained = args.scale, 1, state, True
+    tr = Trainer(y, dataset=ds, val_dataset=None, epochs=10 ** 6, batch=B, project=ROOT / "gpurun_out" / "bench_runs", name=f"e2e{rank}", imgsz=args.size,
+                 nbs=B * world, warmup_epochs=0.0, device_augment=not args.host_augment)
+
+    def stream():
+        e = 0
+        while True:
+            yield from tr._batches(e)
+            e += 1
+
+    it = stream()
+    lr = tr.lr0
+
+    def step():
+        tr.forward_backward(next(it))
+        tr.optimizer_step(lr)
+
+    split = {"dataset_build_s": round(t_ds, 1), "slices": len(ds), "iterations_per_epoch": tr.nb}
+    if tr.aug is not None:  # the two halves of the feeder on their own: host (random draws + label geometry, one thread) and device (two launches)
+        rng = np.random.default_rng(0)
+        idx = list(range(B))
+        tr.aug.prepare(idx, rng, True, True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            h = tr.aug.prepare(idx, rng, True, True)
+        split["host_prepare_ms_per_batch"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
+        st_ = torch.cuda.current_stream(dev).cuda_stream
+        tr.aug.render(h)
+        e0, e1 = hiplib.Event(), hiplib.Event()
+        e0.record(st_)
+        for _ in range(5):
+            tr.aug.render(h)
+        e1.record(st_)
+        torch.cuda.synchronize(dev)
+        split["device_render_ms_per_batch"] = round(e0.elapsed_ms(e1) / 5, 3)
+    return tr, step, split
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="train", choices=["train", "predict"])
+    ap.add_argument("--mode", default="train", choices=["train", "predict", "train-e2e", "replicas"],
+                    help="train: one resident batch per step (the headline); predict: the inference leg; train-e2e: the same step fed by the data feeder "
+                         "(mosaic on); replicas: independent trainings, one per GPU, no collective (SURVEY 8e zero-communication mode)")
     ap.add_argument("--batch", type=int, default=0, help="slices per GPU per step (default: 128 for both legs — north_star: batch >= 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--scale", default="n", choices=["n", "s"], help="n = BASELINE configs[1]; s = configs[2] (YOLO11s-seg, seeded random initialisation)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-augment", action="store_true", help="train-e2e: the NumPy augmentation path of data.py instead of the device feeder")
     ap.add_argument("--replay-dominant", type=int, default=0, help="after the roofline pass, launch the dominant op this many more times (PMC collection)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-op replay (for a clean rocprofv3 trace of the timed steps only)")
     ap.add_argument("--no-infer", action="store_true", help="train mode: skip the short predict run reported under 'infer'")
@@ -410,12 +491,15 @@ def main():
                          "calibrated-random weights as they are, which saturates max_det=300 on noise slices)")
     args = ap.parse_args()
     world, rank, dev, dist = dist_setup(args)
-    state = load_weights()
+    state = load_weights(args.scale)
     S = args.size
+    model_name = f"YOLO11{args.scale}-seg"
+    cfg_name = "BASELINE configs[1]" if args.scale == "n" else "BASELINE configs[2] model"
+    wdesc = "calibrated random weights" if args.scale == "n" else "seeded random initialisation"
     line = {"metric": METRIC, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
 
-    if args.mode == "train":
+    if args.mode in ("train", "replicas"):
         B = args.batch or 128
         tr, dbatch, batch = train_setup(args, dev, rank, world, state, B)
         lr = tr.lr0
@@ -426,30 +510,63 @@ def main():
 
         dt = timed(step, args, dev, world, dist)
         value = world * B * args.steps / dt
+        dp = args.mode == "train"
         line.update(value=round(value, 2), ms_per_step=round(dt / args.steps * 1e3, 4),
-                    config={"workload": f"train step (BASELINE configs[1]): YOLO11n-seg nc=1, {S}x{S}x3 uint8 slices, batch {B}/GPU, {args.dtype} activations+weights / "
-                                        f"fp32 master+accumulate; pack + forward(train BN) + loss + backward + {'all-reduce + ' if world > 1 else ''}clip + AdamW + EMA; "
-                                        f"calibrated random weights, 1-6 random polygons per slice",
-                            "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}: slices sharded, one flat-gradient all-reduce per step"})
+                    config={"workload": f"train step ({cfg_name}): {model_name} nc=1, {S}x{S}x3 uint8 slices, batch {B}/GPU, {args.dtype} activations+weights / "
+                                        f"fp32 master+accumulate; pack + forward(train BN) + loss + backward + {'all-reduce + ' if (world > 1 and dp) else ''}clip + AdamW + EMA; "
+                                        f"{wdesc}, 1-6 random polygons per slice",
+                            "per_gpu_batch": B, "global_batch": B * world,
+                            "parallelism": (f"dp{world}: slices sharded, one flat-gradient all-reduce per step" if dp else
+                                            f"replicas x{world}: independent trainings (the reference's fold x plane jobs), one per GPU, no collective")})
         if rank == 0:
             line["roofline"] = None if args.no_roofline else train_roofline(tr, dbatch, args, value / world)
-            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_train(state, batch)
+            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_train(state, batch, scale=args.scale)
             if not args.no_infer and world == 1:
                 del tr, dbatch
                 torch.cuda.empty_cache()
-                pargs = argparse.Namespace(**{**vars(args), "steps": 10, "warmup": 3})
-                eng, imgs, host, pstate, shift = predict_setup(pargs, dev, rank, state, 128)
-                t0 = None
-                for i in range(13):
-                    if i == 3:
-                        torch.cuda.synchronize(dev)
-                        t0 = time.perf_counter()
-                    eng.predict_slices(imgs)
-                torch.cuda.synchronize(dev)
-                pdt = time.perf_counter() - t0
-                line["infer"] = {"value": round(128 * 10 / pdt, 2), "unit": "slices/s (1 GPU)", "ms_per_step": round(pdt / 10 * 1e3, 3), "per_gpu_batch": 128,
-                                 "workload": f"predict leg: LetterBox+net+NMS+masks+merge, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
-                                 "mean_kept_instances_per_slice": round(float(eng.plan(128, S, S).keep_cnt.float().mean().item()), 1)}
+                line["infer"] = {}
+                # the inference leg in both arithmetic modes: fp32 = the default of YOLO() predict (exact parity with the CPU path: identical NMS
+                # indices and mask bytes, tests/test_gpu_trained.py), bf16 = the opt-in throughput mode
+                for pdt in ("fp32", "bf16"):
+                    pargs = argparse.Namespace(**{**vars(args), "steps": 10, "warmup": 3, "dtype": pdt})
+                    eng, imgs, host, pstate, shift = predict_setup(pargs, dev, rank, state, 128)
+                    t0 = None
+                    for i in range(13):
+                        if i == 3:
+                            torch.cuda.synchronize(dev)
+                            t0 = time.perf_counter()
+                        eng.predict_slices(imgs)
+                    torch.cuda.synchronize(dev)
+                    pdt_s = time.perf_counter() - t0
+                    line["infer"][pdt] = {"value": round(128 * 10 / pdt_s, 2), "unit": "slices/s (1 GPU)", "ms_per_step": round(pdt_s / 10 * 1e3, 3), "per_gpu_batch": 128,
+                                          "workload": f"predict leg: LetterBox+net+NMS+masks+merge, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
+                                          "mean_kept_instances_per_slice": round(float(eng.plan(128, S, S).keep_cnt.float().mean().item()), 1),
+                                          "parity": ("exact vs the CPU oracle (north_star tolerance met)" if pdt == "fp32" else
+                                                     "throughput mode: |dDice| <= 1e-3 per plane volume, not at the 1e-4 tolerance")}
+                    del eng, imgs
+                    torch.cuda.empty_cache()
+    elif args.mode == "train-e2e":
+        B = args.batch or 128
+        tr, step, split = train_e2e_bench(args, dev, rank, world, state, B)
+        dt = timed(step, args, dev, world, dist)
+        value = world * B * args.steps / dt
+        line.update(value=round(value, 2), ms_per_step=round(dt / args.steps * 1e3, 4), data="real FLAIR slices (demo patient P39, 361 lesion slices x 8) through the training augmentation",
+                    config={"workload": f"end-to-end train step ({cfg_name}): {model_name} nc=1, batch {B}/GPU, {args.dtype}; every batch drawn fresh from the data feeder "
+                                        f"(mosaic 1.0, scale 0.5, translate 0.1, hsv_v 0.4, fliplr 0.5; {'NumPy path (data.py)' if args.host_augment else 'device feeder (augment.py: 2 HIP launches per batch)'}) "
+                                        f"+ pack + forward + loss + backward + clip + AdamW + EMA",
+                            "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"})
+        if rank == 0:
+            # the resident-batch number beside it (what the headline `train` mode measures): same trainer, one batch replayed
+            it_batch = tr.aug.batch(list(range(B)), np.random.default_rng(1), True, True) if tr.aug is not None else None
+            if it_batch is not None:
+                def rstep():
+                    tr.forward_backward(it_batch)
+                    tr.optimizer_step(tr.lr0)
+
+                rdt = timed(rstep, args, dev, 1, None)
+                split["resident_batch_slices_per_s"] = round(B * args.steps / rdt, 1)
+                split["e2e_over_resident"] = round(value / world / split["resident_batch_slices_per_s"], 4)
+            line["feeder"] = split
     else:
         B = args.batch or 128
         eng, imgs, host, pstate, shift = predict_setup(args, dev, rank, state, B)
@@ -462,12 +579,12 @@ def main():
         dt = timed(step, args, dev, world, dist)
         value = world * B * args.steps / dt
         line.update(value=round(value, 2), ms_per_step=round(dt / args.steps * 1e3, 4),
-                    config={"workload": f"predict (infer leg of the metric): YOLO11n-seg nc=1, {S}x{S}x3 uint8 slices, LetterBox+net+NMS+masks+merge, batch {B}/GPU; "
-                                        f"calibrated random weights, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
+                    config={"workload": f"predict (infer leg of the metric): {model_name} nc=1, {S}x{S}x3 uint8 slices, LetterBox+net+NMS+masks+merge, batch {B}/GPU; "
+                                        f"{wdesc}, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
                             "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"slice-sharded x{world}, no collective"})
         if rank == 0:
             line["roofline"] = None if args.no_roofline else predict_roofline(eng, imgs, out, args, value / world)
-            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_predict(pstate, host[: min(B, 64)])
+            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_predict(pstate, host[: min(B, 64)], scale=args.scale)
             line["slice_extract"] = None if args.no_roofline else slice_extract_bench(dev, host_sample=not args.no_cpu_baseline)
             line["volume_plane"] = None if args.no_roofline else volume_plane_bench(eng, dev)
     if rank == 0:

@@ -175,6 +175,13 @@ enum {
                                      3 axis (0 sagital,1 coronal,2 axial), 4 B, 5 variant (0 none,1 HE,2 CLAHE,3 GC,4 LT) */
   MSL_OP_SGD = 36,                /* SGD + Nesterov momentum over a flat fp32 range (optimizer=auto beyond 10 000 iterations): p 0 params, 1 grads,
                                      2 momentum buffer, 5 clip scale f32[1]|NULL ; i 0,1 n, 2 first step ; f 0 lr, 1 momentum, 2 weight decay */
+  MSL_OP_AUGMENT = 37,            /* training-slice augmentation on the device [replaces the image side of ultralytics' Mosaic + RandomPerspective + RandomHSV +
+                                     RandomFlip under model.train(cache=True), REF scripts/train.py:358-366, args.yaml:85-103]: p 0 slice cache u8 (HBM resident),
+                                     1 records i64/f64 [B][48] (inverse affine 2x3, value gain, flip, tile count, canvas W/H, border, pad, then per tile: source byte
+                                     offset, row stride, canvas rectangle x1,y1,x2,y2, source origin x,y), 4 out u8 [B][H][W][3] ; i 0 B, 1 H, 2 W */
+  MSL_OP_RASTER_MASKS = 38,       /* instance polygons -> overlap-encoded prototype-resolution masks (even-odd fill at pixel centres, later polygons overwrite):
+                                     p 0 vertices f32 [V][2] (mask pixels), 1 polygons i32 [P][4] (first vertex, count, value, -), 2 ranges i32 [B][2] (first polygon,
+                                     count), 4 masks u8 [B][mh][mw] ; i 0 B, 1 mh, 2 mw */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

@@ -1,0 +1,63 @@
+"""Device data feeder (MSL_OP_AUGMENT + MSL_OP_RASTER_MASKS, augment.py) against the NumPy restatement data.augment + data.collate on the same
+generator state (-m gpu): images and overlap masks byte for byte, labels value for value — mosaic, single-slice affine and plain letterbox."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mslesseg_amd import augment as A  # noqa: E402
+from mslesseg_amd import data as D  # noqa: E402
+from test_augment_host import ShapesDataset  # noqa: E402
+
+
+@pytest.mark.parametrize("mosaic,augment,size", [(True, True, 640), (False, True, 640), (False, False, 640), (True, True, 256)])
+def test_device_batch_equals_numpy_restatement(mosaic, augment, size):
+    ds = ShapesDataset(24, seed=2, size=size)
+    aug = A.DeviceAugmenter(A.SliceCache(ds, "cuda:0"), size)
+    idx = [3, 0, 7, 7, 12, 21, 5, 10, 23, 1]
+    for seed in range(3):
+        r1, r2 = np.random.default_rng([seed, 5]), np.random.default_rng([seed, 5])
+        samples = [D.augment(ds, i, r1, mosaic, size) if augment else D.plain(ds, i, size) for i in idx]
+        want = D.collate(samples, size)
+        got = aug.batch(idx, r2, mosaic, augment)
+        torch.cuda.synchronize()
+        img, masks = got["img"].cpu().numpy(), got["masks"].cpu().numpy()
+        assert img.shape == want["img"].shape and masks.shape == want["masks"].shape
+        assert int((img != want["img"]).sum()) == 0, f"{int((img != want['img']).sum())} image bytes differ"
+        assert int((masks != want["masks"]).sum()) == 0, f"{int((masks != want['masks']).sum())} mask bytes differ"
+        assert np.array_equal(got["bboxes"], want["bboxes"]) and np.array_equal(got["batch_idx"], want["batch_idx"])
+        from mslesseg_amd.segloss import pack_targets
+
+        gt, _ = pack_targets(want["batch_idx"], want["cls"], want["bboxes"], len(idx), size, size)
+        assert np.array_equal(got["gt"].cpu().numpy(), gt)
+
+
+def test_real_slices_and_lesion_polygons(demo_volumes):
+    """P39 lesion slices (the three plane shapes, contour polygons with hundreds of vertices, up to 14 lesions per slice) through the mosaic."""
+    ds = D.VolumeSliceDataset(demo_volumes["P39_flair"], demo_volumes["P39_mask"], keep=lambda plano, i: i % 12 == 0)
+    assert len(ds) >= 20
+    aug = A.DeviceAugmenter(A.SliceCache(ds, "cuda:0"), 640)
+    idx = list(range(0, len(ds), 3))
+    r1, r2 = np.random.default_rng(11), np.random.default_rng(11)
+    want = D.collate([D.augment(ds, i, r1, True, 640) for i in idx], 640)
+    got = aug.batch(idx, r2, True, True)
+    assert int((got["img"].cpu().numpy() != want["img"]).sum()) == 0
+    assert int((got["masks"].cpu().numpy() != want["masks"]).sum()) == 0
+    assert np.array_equal(got["bboxes"], want["bboxes"]) and len(want["cls"]) > 20
+
+
+def test_trainer_epoch_through_the_device_feeder(tmp_path):
+    """`model.train()` with mosaic on: batches come from the device feeder; same files, finite decreasing loss."""
+    import csv
+
+    from ultralytics import YOLO
+
+    ds = D.SyntheticSegDataset(32, 128, seed=0)
+    model = YOLO("yolo11n-seg.pt", precision="bf16")
+    model.train(data=None, dataset=ds, val_dataset=D.SyntheticSegDataset(8, 128, seed=1), epochs=6, batch=8, project=tmp_path, name="f", imgsz=128, nbs=8,
+                warmup_epochs=0.0, close_mosaic=2)
+    assert model.trainer.aug is not None
+    rows = list(csv.DictReader(open(tmp_path / "f" / "results.csv")))
+    tot = [sum(float(r[k]) for k in ("train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss")) for r in rows]
+    assert len(rows) == 6 and all(np.isfinite(tot)) and tot[-1] < tot[0]

@@ -24,10 +24,10 @@ def synth_state(golden_dir):
     return {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
 
 
-def _oracle_run(state, img_rgb, R):
+def _oracle_run(state, img_rgb, R, scale="n"):
     from oracle import yolo11seg as Y
 
-    m = Y.build("n", 1)
+    m = Y.build(scale, 1)
     m.load_state_dict(state)
     m.train()
     x = torch.from_numpy(img_rgb).permute(0, 3, 1, 2).float() / 255
@@ -48,9 +48,9 @@ def _probe(N, H, W, seed=0):
     return R, shapes
 
 
-def _run_plan(state, img_rgb, R, shapes, dtype):
+def _run_plan(state, img_rgb, R, shapes, dtype, scale="n"):
     N, H, W, _ = img_rgb.shape
-    store = TP.ParamStore("n", 1, DEV)
+    store = TP.ParamStore(scale, 1, DEV)
     store.load_state(state)
     plan = TP.TrainPlan(store, N, H, W, dtype)
     plan.in_view.t.copy_(torch.from_numpy(img_rgb).reshape(-1))

@@ -1,0 +1,176 @@
+"""Parity on a TRAINED network and real FLAIR slices (-m gpu): the checkpoint tests/golden/demo_p39_n.pt was trained by this library's own
+trainer on the lesion slices of the reference's demo patient P39 (scripts/train_demo_checkpoint.py; 60 epochs, bf16 train engine, every
+5th slice held out; weights stored bf16-exact) and is the well-conditioned counterpart of the calibrated-random test weights.
+
+north_star tolerance (BASELINE.json): bit-exact indices after NMS, reconstructed-volume Dice within 1e-4 of the CPU reference.
+  * fp32 engine (the default of `YOLO()` predict, = the reference's half=False): identical ordered kept-index lists on every slice, identical
+    output bytes, |dDice| <= 1e-4 per plane volume and for the 3-plane consensus  -> asserted at exactly that tolerance.
+  * bf16 engine (opt-in throughput mode): bf16 storage rounds every activation to 8 significant bits (measured 0.2-0.5 % relative L2 at every
+    tap of this network, no growth with depth), which moves near-threshold scores and mask-boundary logits: measured on all 361 lesion slices
+    (profiles/r02a_precision_trained_p39.json) 303 identical kept lists, 699 of 13.4 M output bytes differ, |dDice| 9.7e-4 / 1.4e-4 / 4.4e-5
+    per plane, 3.8e-5 for the consensus.  It does NOT meet the 1e-4 tolerance per plane; the bounds asserted here are those measured ones
+    with headroom, and DESIGN.md says so.
+The oracle's model arithmetic restates ultralytics 8.3.70 (parity unpinned against the reference itself)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mslesseg_amd import engine as E  # noqa: E402
+from mslesseg_amd import volume as V  # noqa: E402
+from mslesseg_amd.hiplib import MSL_BF16, MSL_F32  # noqa: E402
+
+STRIDE = 3  # every 3rd slice of the reference's slice set (121 of the 361 lesion slices) keeps the oracle's CPU time to a few seconds
+
+
+@pytest.fixture(scope="module")
+def trained_state(golden_dir):
+    st = torch.load(golden_dir / "demo_p39_n.pt", map_location="cpu", weights_only=True)
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
+
+
+@pytest.fixture(scope="module")
+def oracle_run(trained_state, demo_volumes):
+    """Oracle results per plane: slice indices, rendered slices, kept-index lists, output bytes, plane volume, Dice."""
+    from oracle import prepost as P
+    from oracle import synth
+
+    torch.set_num_threads(16)
+    om = synth.model_from_state(trained_state)
+    fl, gt = demo_volumes["P39_flair"], demo_volumes["P39_mask"]
+    out = {}
+    for plano in ("axial", "coronal", "sagital"):
+        idx = V.select_slices(gt, plano)[::STRIDE]
+        imgs = np.stack([V.slice_as_png_array(V.take_slice(fl, plano, i)) for i in idx])
+        kept, outs = [], []
+        for im in imgs:
+            x = P.preprocess(im)
+            with torch.no_grad():
+                y, proto = om(x)
+            rows, k = P.non_max_suppression(y, nc=1)
+            kept.append(k[0].tolist())
+            m = P.postprocess_one(rows[0], proto[0], tuple(x.shape[2:]))
+            outs.append(P.normalizar_prediccion(P.combinar_predicciones([] if m is None else m.numpy(), im.shape[:2])))
+        vol = P.reconstruir_volumen(dict(zip(idx, outs)), gt.shape, plano)
+        out[plano] = dict(idx=idx, imgs=imgs, kept=kept, outs=outs, vol=vol, dice=P.dsc_unrounded(gt, vol))
+    return out
+
+
+def _engine_run(eng, oracle_run, gt):
+    from oracle import prepost as P
+
+    res = {}
+    for plano, o in oracle_run.items():
+        same_list = same_set = px = 0
+        outs = []
+        for b0 in range(0, len(o["idx"]), 64):
+            chunk = o["imgs"][b0 : b0 + 64]
+            plan = eng.predict_batch(torch.from_numpy(chunk))
+            out = plan.merged(*chunk.shape[1:3]).cpu().numpy()
+            cnt, kid = plan.keep_cnt.cpu().numpy(), plan.keep_idx.cpu().numpy()
+            for j in range(len(chunk)):
+                got = kid[j, : cnt[j]].tolist()
+                same_list += got == o["kept"][b0 + j]
+                same_set += set(got) == set(o["kept"][b0 + j])
+                px += int((out[j] != o["outs"][b0 + j]).sum())
+            outs += list(out)
+        vol = P.reconstruir_volumen(dict(zip(o["idx"], outs)), gt.shape, plano)
+        res[plano] = dict(n=len(o["idx"]), same_list=same_list, same_set=same_set, px=px, total=int(o["imgs"].shape[0] * o["imgs"].shape[1] * o["imgs"].shape[2]),
+                          vol=vol, dice=P.dsc_unrounded(gt, vol))
+    return res
+
+
+def test_fp32_engine_meets_the_north_star_tolerance_on_trained_weights(trained_state, oracle_run, demo_volumes):
+    from oracle import prepost as P
+
+    gt = demo_volumes["P39_mask"]
+    assert sum(len(k) for o in oracle_run.values() for k in o["kept"]) > 300, "the trained network must detect lesions for this test to mean anything"
+    res = _engine_run(E.InferEngine(trained_state, "n", 1, MSL_F32), oracle_run, gt)
+    for plano, r in res.items():
+        print(f"fp32 {plano}: {r['same_list']}/{r['n']} identical kept lists, {r['px']} of {r['total']} bytes differ, dice {r['dice']:.6f} oracle {oracle_run[plano]['dice']:.6f}")
+        assert r["same_list"] == r["n"], f"{plano}: kept indices differ on {r['n'] - r['same_list']} slices"
+        assert r["px"] <= 2, f"{plano}: {r['px']} output bytes differ"
+        assert abs(r["dice"] - oracle_run[plano]["dice"]) <= 1e-4
+    cons = P.combinar_volumenes(res["axial"]["vol"], res["coronal"]["vol"], res["sagital"]["vol"], 2)
+    cons_o = P.combinar_volumenes(oracle_run["axial"]["vol"], oracle_run["coronal"]["vol"], oracle_run["sagital"]["vol"], 2)
+    assert abs(P.dsc_unrounded(gt, cons) - P.dsc_unrounded(gt, cons_o)) <= 1e-4
+    assert P.dsc_unrounded(gt, cons_o) > 0.6  # a trained model: the consensus overlaps the GT lesions
+
+
+def test_bf16_engine_measured_deviation_on_trained_weights(trained_state, oracle_run, demo_volumes):
+    from oracle import prepost as P
+
+    gt = demo_volumes["P39_mask"]
+    res = _engine_run(E.InferEngine(trained_state, "n", 1, MSL_BF16), oracle_run, gt)
+    for plano, r in res.items():
+        dd = abs(r["dice"] - oracle_run[plano]["dice"])
+        print(f"bf16 {plano}: {r['same_list']}/{r['n']} identical kept lists, {r['same_set']} identical sets, {r['px']} of {r['total']} bytes differ, |dDice| {dd:.2e}")
+        assert r["same_set"] >= 0.8 * r["n"] and r["same_list"] >= 0.6 * r["n"]
+        assert r["px"] <= 3e-4 * r["total"]
+        assert dd <= 3e-3, "bf16 is the throughput mode: bounded, not at the 1e-4 tolerance (module docstring)"
+    cons = P.combinar_volumenes(res["axial"]["vol"], res["coronal"]["vol"], res["sagital"]["vol"], 2)
+    cons_o = P.combinar_volumenes(oracle_run["axial"]["vol"], oracle_run["coronal"]["vol"], oracle_run["sagital"]["vol"], 2)
+    assert abs(P.dsc_unrounded(gt, cons) - P.dsc_unrounded(gt, cons_o)) <= 1e-3
+
+
+def test_default_yolo_predicts_in_fp32_and_whole_volume_dice_on_device(trained_state, oracle_run, demo_volumes, tmp_path, monkeypatch):
+    """`YOLO(path)` as the reference constructs it (no precision argument) → fp32 predict; the batched whole-volume path on the reference's
+    slice set (`select_slices`) gives the oracle's Dice within 1e-4, computed on the device."""
+    from ultralytics import YOLO
+
+    from mslesseg_amd import params
+
+    monkeypatch.delenv("MSLESSEG_PRECISION", raising=False)
+    ck = tmp_path / "best.pt"
+    params.save_checkpoint(ck, trained_state, "n", 1, {0: "lesion"})
+    model = YOLO(ck)
+    assert model.dtype == MSL_F32 and model.train_dtype == MSL_BF16
+    fl, gt = demo_volumes["P39_flair"], demo_volumes["P39_mask"]
+    o = oracle_run["coronal"]
+    vol = V.predict_volume(model, fl, "coronal", indices=o["idx"])
+    assert int((vol.cpu().numpy() != o["vol"]).sum()) <= 2
+    d, d3 = V.dice(torch.from_numpy(gt).to(vol.device), vol.to(torch.uint8))
+    assert abs(d - o["dice"]) <= 1e-4 and d3 == round(d, 3)
+    # B3/B4 on one slice: the boundary returns one mask per kept instance at the letterboxed size
+    r = model(o["imgs"][len(o["imgs"]) // 2], verbose=False)[0]
+    k = o["kept"][len(o["imgs"]) // 2]
+    assert (r.masks is None and not k) or (r.masks is not None and 0 < len(r.masks) <= len(k))
+
+
+def test_bf16_train_step_against_the_fp32_engine_on_trained_weights(trained_state, demo_volumes):
+    """One real training step (16 P39 slices, mosaic batch from the device feeder, the segmentation loss) in both engines from the same trained
+    weights: the bf16 engine's loss items and flat gradient against the fp32 engine's (which tests/test_gpu_train.py pins to the oracle's
+    autograd)."""
+    from mslesseg_amd import data as D
+    from mslesseg_amd.train import Trainer
+    from mslesseg_amd.yolo import YOLO
+
+    ds = D.VolumeSliceDataset(demo_volumes["P39_flair"], demo_volumes["P39_mask"], keep=lambda plano, i: i % 8 == 0)
+    out = {}
+    for name, dt in (("fp32", MSL_F32), ("bf16", MSL_BF16)):
+        y = YOLO.__new__(YOLO)
+        y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = "trained", "segment", "cuda:0", {0: "lesion"}, None, None
+        y.dtype = y.train_dtype = dt
+        y.scale, y.nc, y.state, y.pretrained = "n", 1, trained_state, True
+        tr = Trainer(y, dataset=ds, val_dataset=None, epochs=1, batch=16, project="gpurun_out/test_runs", name=f"trained_{name}", nbs=16, warmup_epochs=0.0)
+        batch = tr.aug.batch(list(range(16)), np.random.default_rng(3), mosaic=True, augment=True)
+        tr.store.g.zero_()
+        items = tr.forward_backward(batch).cpu().numpy()
+        out[name] = (items, tr.store.g.clone().cpu(), tr.store)
+        assert np.isfinite(items).all()
+    (i32, g32, store), (i16, g16, _) = out["fp32"], out["bf16"]
+    rel_items = np.abs(i16 - i32) / np.abs(i32)
+    cos = float((g16 @ g32) / (g16.norm() * g32.norm()))
+    rel = float((g16 - g32).norm() / g32.norm())
+    per = []
+    for key, (off, shp) in store.entries.items():
+        n = int(np.prod(shp))
+        a, b = g16[off : off + n], g32[off : off + n]
+        if float(b.norm()) > 1e-3 * float(g32.norm()):
+            per.append((float((a @ b) / (a.norm() * b.norm() + 1e-30)), key))
+    per.sort()
+    print(f"bf16 vs fp32 train step on trained weights: loss items rel err {rel_items}, flat gradient cosine {cos:.5f} rel L2 {rel:.4f}, worst tensors {per[:4]}")
+    assert rel_items.max() < 2e-2
+    assert cos > 0.98 and rel < 0.2
+    assert per[0][0] > 0.8, per[:6]

@@ -82,3 +82,36 @@ def test_label_file_roundtrip(tmp_path):
     assert len(back) == 2 and all(np.allclose(a[1], b[1], atol=1e-6) and a[0] == b[0] for a, b in zip(inst, back))
     (tmp_path / "bad.txt").write_text("0 0.1 0.2\n0 0.1 0.2 0.3\n")
     assert LB.read_label_file(tmp_path / "bad.txt") == [] and LB.read_label_file(tmp_path / "missing.txt") == []
+
+
+def test_replica_schedule_is_deterministic_balanced_and_complete():
+    """Zero-communication mode: the reference's 15 fold x plane trainings [REF ejecutar_pipeline.py:174-184] dealt over the GPUs of a node."""
+    from mslesseg_amd import replicas as R
+
+    jobs = R.fold_plane_jobs()
+    assert len(jobs) == 15 and jobs[0] == ("axial", 1) and jobs[-1] == ("sagital", 5)
+    # iterations per epoch of the reference's runs (112 axial / 163 coronal / 117 sagittal): coronal jobs cost ~1.45x
+    costs = [{"axial": 112, "coronal": 163, "sagital": 117}[pl] for pl, _ in jobs]
+    for world in (1, 2, 4, 8):
+        parts = R.schedule(costs, world)
+        flat = sorted(j for p in parts for j in p)
+        assert flat == list(range(15))
+        loads = [sum(costs[j] for j in p) for p in parts]
+        assert max(loads) <= sum(costs) / world + max(costs)  # LPT bound
+        assert [R.jobs_of_rank(jobs, costs, r, world) for r in range(world)] == [[jobs[j] for j in p] for p in parts]
+    assert max(sum(costs[j] for j in p) for p in R.schedule(costs, 8)) == 275  # 8 GPUs: the makespan is one coronal + one axial job (lower bound sum/8 = 245)
+    seen = []
+    done = R.run_replicas(jobs, seen.append, costs, rank=3, world=8)
+    assert done == seen == R.jobs_of_rank(jobs, costs, 3, 8) and len(done) in (1, 2)
+
+
+def test_replica_skips_finished_runs(tmp_path):
+    from mslesseg_amd import replicas as R
+
+    jobs = R.fold_plane_jobs(2, ("axial",))
+    d = tmp_path / "axial" / "fold1" / "weights"
+    d.mkdir(parents=True)
+    (d / "best.pt").write_bytes(b"x")
+    seen = []
+    R.run_replicas(jobs, seen.append, run_dir_of=lambda job: tmp_path / job[0] / f"fold{job[1]}", rank=0, world=1)
+    assert seen == [("axial", 2)]

@@ -1,0 +1,229 @@
+"""Training-data feeder on the device: the dataset's uint8 slices stay resident in HBM (the `cache=True` RAM cache of the
+reference's call [REF yolo_mslesseg/scripts/train.py:358-366], uploaded once), and a whole batch is augmented by two HIP launches —
+MSL_OP_AUGMENT (mosaic gather + affine bilinear warp + value gain + flip) and MSL_OP_RASTER_MASKS (instance polygons → overlap-encoded
+160x160 masks) — instead of a Python loop building a 1280x1280 mosaic per slice.
+
+The host keeps what is tiny: the random draws (same generator, same order as `data.augment`, so both paths see the same numbers) and the label
+geometry, vectorised over the batch on ragged polygon arrays with the very functions `data.py` uses per sample (`affine_points`, `poly_bboxes`,
+`poly_areas`, `box_candidates`).  `data.augment` + `data.collate` remain the readable per-sample restatement; tests/test_gpu_augment.py checks
+this path against it byte for byte (images, masks) and value for value (boxes, classes, order).
+
+Hyper-parameters: the reference's resolved set [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/args.yaml:85-103] — mosaic 1.0, scale 0.5,
+translate 0.1, hsv_v 0.4, fliplr 0.5, mask_ratio 4, overlap_mask (degrees / shear / perspective / flipud / mixup are 0 there).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import data as D
+from . import hiplib
+from .segloss import pack_targets
+
+REC = 48  # 8-byte slots per sample record (csrc/augment.hip)
+
+
+def ragged_arange(starts: np.ndarray, counts: np.ndarray) -> np.ndarray:
+    """concatenate([arange(s, s + c) for s, c in zip(starts, counts)]) without the Python loop."""
+    counts = np.asarray(counts, np.int64)
+    total = int(counts.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    ends = np.cumsum(counts)
+    base = np.repeat(np.asarray(starts, np.int64) - (ends - counts), counts)
+    return base + np.arange(total, dtype=np.int64)
+
+
+class SliceCache:
+    """A dataset's slices as one flat uint8 device buffer + its labels as ragged arrays (pixel coordinates of the cached slice)."""
+
+    def __init__(self, ds, device=None):
+        """`device=None`: labels only, nothing is uploaded (the host half of the feeder can then be exercised without a GPU)."""
+        self.device = torch.device(device) if device is not None else None
+        n = len(ds)
+        self.n = n
+        self.h, self.w = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        self.off = np.zeros(n, np.int64)
+        chunks, cls, pts, pcount, icount = [], [], [], [], []
+        pos = 0
+        for i in range(n):
+            img, inst = ds.get(i)
+            assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+            self.h[i], self.w[i], self.off[i] = img.shape[0], img.shape[1], pos
+            chunks.append(np.ascontiguousarray(img).reshape(-1))
+            pos += img.size
+            k = 0
+            for c, p in inst:
+                p = np.asarray(p, np.float32).reshape(-1, 2)
+                if len(p) >= 3:  # shorter "polygons" never become a label (data.collate)
+                    cls.append(float(c))
+                    pts.append(p)
+                    pcount.append(len(p))
+                    k += 1
+            icount.append(k)
+        self.nbytes = pos
+        self.buf = torch.from_numpy(np.concatenate(chunks)).to(self.device) if self.device is not None else None
+        self.cls = np.asarray(cls, np.float32)
+        self.pts = np.concatenate(pts, 0) if pts else np.zeros((0, 2), np.float32)
+        self.poly_off = np.concatenate([[0], np.cumsum(pcount)]).astype(np.int64)
+        self.item_off = np.concatenate([[0], np.cumsum(icount)]).astype(np.int64)
+
+
+class DeviceAugmenter:
+    def __init__(self, cache: SliceCache, size: int = D.IMGSZ, mask_ratio: int = 4, scale: float = 0.5, translate: float = 0.1,
+                 hsv=(0.015, 0.7, 0.4), fliplr: float = 0.5):
+        self.c, self.size, self.mask_ratio = cache, int(size), int(mask_ratio)
+        self.scale, self.translate, self.hsv, self.fliplr = scale, translate, hsv, fliplr
+        self.device = cache.device
+
+    # ------------------------------------------------------------------ random draws + geometry of one sample (order of data.augment)
+    def _draw(self, idx: int, rng, mosaic: bool, rec: np.ndarray, tiles: list, b: int):
+        c, s = self.c, self.size
+        recf = rec.view(np.float64)
+        if mosaic:
+            yc, xc = (int(rng.uniform(s // 2, 2 * s - s // 2)) for _ in range(2))
+            items = [idx] + [int(rng.integers(0, c.n)) for _ in range(3)]
+            for k, i in enumerate(items):
+                h, w = int(c.h[i]), int(c.w[i])
+                if k == 0:
+                    x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+                    x1b, y1b = w - (x2a - x1a), h - (y2a - y1a)
+                elif k == 1:
+                    x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, 2 * s), yc
+                    x1b, y1b = 0, h - (y2a - y1a)
+                elif k == 2:
+                    x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(2 * s, yc + h)
+                    x1b, y1b = w - (x2a - x1a), 0
+                else:
+                    x1a, y1a, x2a, y2a = xc, yc, min(xc + w, 2 * s), min(2 * s, yc + h)
+                    x1b, y1b = 0, 0
+                rec[16 + 8 * k : 24 + 8 * k] = (c.off[i], w, x1a, y1a, x2a, y2a, x1b, y1b)
+                tiles.append((b, i, x1a - x1b, y1a - y1b))
+            nt, cw, chh, border_arg = 4, 2 * s, 2 * s, -s // 2
+        else:
+            i = idx
+            h, w = int(c.h[i]), int(c.w[i])
+            top, left = (s - h) // 2, (s - w) // 2
+            rec[16:24] = (c.off[i], w, left, top, left + w, top + h, 0, 0)
+            tiles.append((b, i, left, top))
+            nt, cw, chh, border_arg = 1, s, s, 0
+        oh, ow = chh + 2 * border_arg, cw + 2 * border_arg
+        C = np.eye(3)
+        C[0, 2], C[1, 2] = -cw / 2, -chh / 2
+        sc = rng.uniform(1 - self.scale, 1 + self.scale)
+        R = np.diag([sc, sc, 1.0])
+        T = np.eye(3)
+        T[0, 2] = rng.uniform(0.5 - self.translate, 0.5 + self.translate) * ow
+        T[1, 2] = rng.uniform(0.5 - self.translate, 0.5 + self.translate) * oh
+        M = T @ R @ C
+        Mi = np.linalg.inv(np.vstack([M[:2], [0, 0, 1]]))
+        r = rng.uniform(-1, 1, 3) * list(self.hsv) + 1
+        flip = rng.random() < self.fliplr
+        recf[0:6] = (Mi[0, 0], Mi[0, 1], Mi[0, 2], Mi[1, 0], Mi[1, 1], Mi[1, 2])
+        recf[6] = r[2]
+        rec[7:13] = (int(flip), nt, cw, chh, D.PAD, D.PAD)
+        assert (oh, ow) == (s, s)
+        return M, sc, flip
+
+    def _plain(self, idx: int, rec: np.ndarray, tiles: list, b: int):
+        c, s = self.c, self.size
+        h, w = int(c.h[idx]), int(c.w[idx])
+        top, left = (s - h) // 2, (s - w) // 2
+        rec[16:24] = (c.off[idx], w, left, top, left + w, top + h, 0, 0)
+        tiles.append((b, idx, left, top))
+        recf = rec.view(np.float64)
+        recf[0:6] = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0)
+        recf[6] = 1.0
+        rec[7:13] = (0, 1, s, s, D.PAD, D.PAD)
+
+    # ------------------------------------------------------------------ host part of a batch
+    def prepare(self, indices: Sequence[int], rng, mosaic: bool = True, augment: bool = True) -> Dict[str, np.ndarray]:
+        """Random draws + label geometry of a batch → host arrays (records, vertices, polygon table, ranges, labels)."""
+        c, s, B = self.c, self.size, len(indices)
+        rec = np.zeros((B, REC), np.int64)
+        tiles: list = []
+        Ms, scs, flips = np.zeros((B, 6)), np.ones(B), np.zeros(B, bool)
+        for b, idx in enumerate(indices):
+            if augment:
+                M, sc, fl = self._draw(int(idx), rng, mosaic, rec[b], tiles, b)
+                Ms[b] = (M[0, 0], M[0, 1], M[0, 2], M[1, 0], M[1, 1], M[1, 2])
+                scs[b], flips[b] = sc, fl
+            else:
+                self._plain(int(idx), rec[b], tiles, b)
+        t = np.asarray(tiles, np.int64).reshape(-1, 4)
+        t_b, t_item = t[:, 0], t[:, 1]
+        t_off = t[:, 2:4].astype(np.float32)
+        # polygons of every tile, vertices of every polygon (ragged gathers)
+        p_cnt = c.item_off[t_item + 1] - c.item_off[t_item]
+        pid = ragged_arange(c.item_off[t_item], p_cnt)
+        p_tile = np.repeat(np.arange(len(t)), p_cnt)
+        v_cnt = c.poly_off[pid + 1] - c.poly_off[pid]
+        vid = ragged_arange(c.poly_off[pid], v_cnt)
+        v_poly = np.repeat(np.arange(len(pid)), v_cnt)
+        off = np.concatenate([[0], np.cumsum(v_cnt)]).astype(np.int64)
+        pts = c.pts[vid] + t_off[p_tile[v_poly]]
+        p_b = t_b[p_tile]
+        cls = c.cls[pid]
+        if augment and len(pid):
+            vb = p_b[v_poly]
+            q = D.affine_points(pts, Ms[vb, 0], Ms[vb, 1], Ms[vb, 2], Ms[vb, 3], Ms[vb, 4], Ms[vb, 5])
+            q = np.clip(q, 0, [s - 1e-3, s - 1e-3]).astype(np.float32)
+            keep = D.box_candidates(D.poly_bboxes(pts, off) * scs.astype(np.float32)[p_b][:, None], D.poly_bboxes(q, off))
+            fl = flips[vb]
+            q[:, 0] = np.where(fl, np.float32(s) - q[:, 0], q[:, 0])
+            kv = keep[v_poly]
+            q, v_cnt, p_b, cls = q[kv], v_cnt[keep], p_b[keep], cls[keep]
+            off = np.concatenate([[0], np.cumsum(v_cnt)]).astype(np.int64)
+            pts = q
+        P = len(p_b)
+        if P:
+            areas = D.poly_areas(pts, off)
+            order = np.lexsort((np.arange(P), -areas, p_b))  # by slice, then largest area first, then original order
+            counts = np.bincount(p_b, minlength=B)
+            first = np.concatenate([[0], np.cumsum(counts)])[:-1]
+            rank = np.arange(P) - first[p_b[order]]
+            if (rank >= D.MAX_INSTANCES).any():
+                import logging
+
+                logging.getLogger("ultralytics").warning(f"a slice of the batch holds more than {D.MAX_INSTANCES} instances: keeping the largest")
+                sel = rank < D.MAX_INSTANCES
+                order, rank = order[sel], rank[sel]
+            bb = D.poly_bboxes(pts, off)[order]
+            bidx = p_b[order].astype(np.float32)
+            boxes = np.stack([(bb[:, 0] + bb[:, 2]) / 2 / s, (bb[:, 1] + bb[:, 3]) / 2 / s, (bb[:, 2] - bb[:, 0]) / s, (bb[:, 3] - bb[:, 1]) / s], 1).astype(np.float32)
+            cls_o = cls[order]
+            o_cnt = v_cnt[order]
+            vsel = ragged_arange(off[order], o_cnt)
+            rpts = (pts[vsel] / self.mask_ratio).astype(np.float32)
+            o_first = np.concatenate([[0], np.cumsum(o_cnt)])[:-1]
+            poly = np.stack([o_first, o_cnt, rank + 1, np.zeros_like(rank)], 1).astype(np.int32)
+            cnt_b = np.bincount(p_b[order], minlength=B)
+            ranges = np.stack([np.concatenate([[0], np.cumsum(cnt_b)])[:-1], cnt_b], 1).astype(np.int32)
+        else:
+            bidx, boxes, cls_o = np.zeros(0, np.float32), np.zeros((0, 4), np.float32), np.zeros(0, np.float32)
+            rpts, poly, ranges = np.zeros((1, 2), np.float32), np.zeros((1, 4), np.int32), np.zeros((B, 2), np.int32)
+        gt, n_max = pack_targets(bidx, cls_o, boxes, B, s, s)
+        return {"rec": rec, "pts": np.ascontiguousarray(rpts), "poly": np.ascontiguousarray(poly), "ranges": np.ascontiguousarray(ranges),
+                "batch_idx": bidx, "cls": cls_o, "bboxes": boxes, "gt": gt, "n_max": n_max, "B": B}
+
+    # ------------------------------------------------------------------ device part
+    def render(self, h: Dict[str, np.ndarray], out_img: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Host arrays of `prepare` → {"img" u8 [B,S,S,3], "masks" u8 [B,S/r,S/r], "gt" f32 [B,n,5]} on the device (two launches, current stream)."""
+        dev, s, B = self.device, self.size, int(h["B"])
+        m = s // self.mask_ratio
+        rec = torch.from_numpy(h["rec"]).to(dev, non_blocking=True)
+        pts = torch.from_numpy(h["pts"]).to(dev, non_blocking=True)
+        poly = torch.from_numpy(h["poly"]).to(dev, non_blocking=True)
+        ranges = torch.from_numpy(h["ranges"]).to(dev, non_blocking=True)
+        gt = torch.from_numpy(h["gt"]).to(dev, non_blocking=True)
+        img = torch.empty(B, s, s, 3, dtype=torch.uint8, device=dev) if out_img is None else out_img
+        masks = torch.empty(B, m, m, dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        hiplib.launch(hiplib.make_op(hiplib.OP_AUGMENT, hiplib.MSL_F32, p=(self.c.buf.data_ptr(), rec.data_ptr(), 0, 0, img.data_ptr()), i={0: B, 1: s, 2: s}), st)
+        hiplib.launch(hiplib.make_op(hiplib.OP_RASTER_MASKS, hiplib.MSL_F32, p=(pts.data_ptr(), poly.data_ptr(), ranges.data_ptr(), 0, masks.data_ptr()), i={0: B, 1: m, 2: m}), st)
+        return {"img": img, "masks": masks, "gt": gt, "batch_idx": h["batch_idx"], "cls": h["cls"], "bboxes": h["bboxes"], "n_max": h["n_max"]}
+
+    def batch(self, indices, rng, mosaic: bool = True, augment: bool = True):
+        return self.render(self.prepare(indices, rng, mosaic, augment))

@@ -20,7 +20,7 @@ HEADER = PKG_ROOT.parent / "include" / "mslesseg_hip.h"
 ARCH = "gfx950"
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # head.hip holds the NMS/box arithmetic that must round like the CPU path: no FMA contraction there.
-EXTRA_FLAGS = {"head.hip": ["-ffp-contract=off"], "extract.hip": ["-ffp-contract=off"]}  # extract.hip restates NumPy float expressions
+EXTRA_FLAGS = {"head.hip": ["-ffp-contract=off"], "extract.hip": ["-ffp-contract=off"], "augment.hip": ["-ffp-contract=off"]}  # extract / augment restate NumPy float expressions
 
 
 def _hipcc() -> str:

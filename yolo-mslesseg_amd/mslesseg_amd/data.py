@@ -38,9 +38,9 @@ def fill_polygon(mask: np.ndarray, poly: np.ndarray, value) -> None:
             continue
         xs = np.sort(x[cross] + (yc - y[cross]) * (x2[cross] - x[cross]) / (y2[cross] - y[cross]))
         for a, b in zip(xs[0::2], xs[1::2]):
-            c0, c1 = int(math.ceil(a - 0.5)), int(math.floor(b - 0.5))
+            c0, c1 = max(int(math.ceil(a - 0.5)), 0), min(int(math.floor(b - 0.5)), w - 1)
             if c1 >= c0:
-                mask[row, max(c0, 0) : min(c1, w - 1) + 1] = value
+                mask[row, c0 : c1 + 1] = value
 
 
 def warp_affine(img: np.ndarray, M: np.ndarray, out_hw: Tuple[int, int], border: int = PAD) -> np.ndarray:
@@ -70,7 +70,58 @@ def resize_keep_ratio(img: np.ndarray, size: int) -> np.ndarray:
         return img
     nh, nw = max(int(round(h * r)), 1), max(int(round(w * r)), 1)
     M = np.array([[nw / w, 0, (nw / w - 1) * 0.5], [0, nh / h, (nh / h - 1) * 0.5]], dtype=np.float64)
+    if img.shape[2] == 3 and np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2]):
+        return np.repeat(warp_affine(img[..., :1], M, (nh, nw), border=0), 3, axis=2)  # grey slices: one channel warped, same bytes
     return warp_affine(img, M, (nh, nw), border=0)
+
+
+
+# ------------------------------------------------------------------------------------------------- label geometry (shared by the per-sample
+# restatement below and the batched device feeder in augment.py: the same functions on ragged polygon arrays, so both produce the same bits)
+def affine_points(pts: np.ndarray, m00, m01, m02, m10, m11, m12) -> np.ndarray:
+    """q = M p for float32 points [V,2]; the coefficients are float64 scalars or per-point arrays.  float64 elementwise arithmetic in a fixed
+    order (no BLAS: a matmul may contract to FMAs and would not be reproducible between the two callers)."""
+    x, y = pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)
+    return np.stack([m00 * x + m01 * y + m02, m10 * x + m11 * y + m12], 1)
+
+
+def poly_bboxes(pts: np.ndarray, off: np.ndarray) -> np.ndarray:
+    """[P,4] (xmin, ymin, xmax, ymax) of the polygons pts[off[i]:off[i+1]] (every polygon non-empty); dtype of `pts`."""
+    st = off[:-1]
+    return np.stack([np.minimum.reduceat(pts[:, 0], st), np.minimum.reduceat(pts[:, 1], st), np.maximum.reduceat(pts[:, 0], st), np.maximum.reduceat(pts[:, 1], st)], 1)
+
+
+def poly_areas(pts: np.ndarray, off: np.ndarray) -> np.ndarray:
+    """Shoelace areas in float64, on coordinates relative to each polygon's first vertex (translation does not change the rounding)."""
+    st, cnt = off[:-1], np.diff(off)
+    seg = np.repeat(np.arange(len(st)), cnt)
+    x = pts[:, 0].astype(np.float64) - pts[st, 0].astype(np.float64)[seg]
+    y = pts[:, 1].astype(np.float64) - pts[st, 1].astype(np.float64)[seg]
+    nxt = np.arange(len(pts)) + 1
+    nxt[off[1:] - 1] = st  # last vertex of a polygon -> its first
+    cross = x * y[nxt] - x[nxt] * y
+    return 0.5 * np.abs(np.add.reduceat(cross, st))
+
+
+def box_candidates(b0: np.ndarray, b1: np.ndarray) -> np.ndarray:
+    """[UPSTREAM RandomPerspective.box_candidates(wh_thr 2, ar_thr 100, area_thr 0.01 for segments, eps 1e-16)] on float32 boxes [P,4]
+    before (scaled) and after the warp."""
+    w0, h0, w1, h1 = b0[:, 2] - b0[:, 0], b0[:, 3] - b0[:, 1], b1[:, 2] - b1[:, 0], b1[:, 3] - b1[:, 1]
+    e = np.float32(1e-16)
+    ar = np.maximum(w1 / (h1 + e), h1 / (w1 + e))
+    return (w1 > 2) & (h1 > 2) & (w1 * h1 / (w0 * h0 + e) > np.float32(0.01)) & (ar < 100)
+
+
+def flatten_instances(inst):
+    """list of (cls, [k,2] float32) -> (cls [P], pts [V,2] float32, off [P+1])."""
+    cls = np.asarray([c for c, _ in inst], np.float32)
+    off = np.zeros(len(inst) + 1, np.int64)
+    if inst:
+        off[1:] = np.cumsum([len(p) for _, p in inst])
+        pts = np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for _, p in inst], 0)
+    else:
+        pts = np.zeros((0, 2), np.float32)
+    return cls, pts, off
 
 
 # ------------------------------------------------------------------------------------------------- dataset
@@ -207,17 +258,19 @@ def _random_affine(img, inst, rng, size, border, scale=0.5, translate=0.1):
     T[1, 2] = rng.uniform(0.5 - translate, 0.5 + translate) * h
     M = T @ R @ C
     out = warp_affine(img, M[:2], (h, w))
-    new = []
-    for c, p in inst:
-        q = p @ M[:2, :2].T + M[:2, 2]
-        q = np.clip(q, 0, [w - 1e-3, h - 1e-3]).astype(np.float32)
-        b0 = np.array([p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max()]) * s
-        b1 = np.array([q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max()])
-        w0, h0, w1, h1 = b0[2] - b0[0], b0[3] - b0[1], b1[2] - b1[0], b1[3] - b1[1]
-        ar = max(w1 / (h1 + 1e-16), h1 / (w1 + 1e-16))
-        if w1 > 2 and h1 > 2 and w1 * h1 / (w0 * h0 + 1e-16) > 0.01 and ar < 100:  # box_candidates (segments: area_thr 0.01)
-            new.append((c, q))
-    return out, new
+    return out, warp_instances(inst, M, s, w, h)
+
+
+def warp_instances(inst, M, s, w, h):
+    """Polygons through the affine M, clipped to the output image, filtered by box_candidates on the scaled source box."""
+    inst = [(c, p) for c, p in inst if len(p)]
+    if not inst:
+        return []
+    cls, pts, off = flatten_instances(inst)
+    q = affine_points(pts, M[0, 0], M[0, 1], M[0, 2], M[1, 0], M[1, 1], M[1, 2])
+    q = np.clip(q, 0, [w - 1e-3, h - 1e-3]).astype(np.float32)
+    keep = box_candidates(poly_bboxes(pts, off) * np.float32(s), poly_bboxes(q, off))
+    return [(c, q[off[i] : off[i + 1]]) for i, (c, _) in enumerate(inst) if keep[i]]
 
 
 def _hsv(img, rng, hgain=0.015, sgain=0.7, vgain=0.4):
@@ -257,9 +310,10 @@ def collate(samples: Sequence[Tuple[np.ndarray, list]], size: int = IMGSZ, mask_
     masks = np.zeros((B, m, m), np.uint8)
     bidx, cls, boxes = [], [], []
     for b, (_, inst) in enumerate(samples):
-        polys = [(c, p) for c, p in inst if len(p) >= 3]
-        areas = [0.5 * abs(np.dot(p[:, 0], np.roll(p[:, 1], 1)) - np.dot(p[:, 1], np.roll(p[:, 0], 1))) for _, p in polys]
-        order = np.argsort(areas)[::-1]
+        polys = [(c, np.asarray(p, np.float32)) for c, p in inst if len(p) >= 3]
+        _, fp, fo = flatten_instances(polys)
+        areas = poly_areas(fp, fo) if polys else np.zeros(0)
+        order = np.argsort(-areas, kind="stable")  # largest first; equal areas keep their order
         if len(order) > MAX_INSTANCES:  # one byte per pixel in the overlap encoding: keep the largest instances, deterministically, and say so
             import logging
 

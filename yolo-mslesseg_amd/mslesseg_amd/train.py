@@ -41,7 +41,7 @@ RESULT_COLUMNS = ["epoch", "time", "train/box_loss", "train/seg_loss", "train/cl
 
 DEFAULTS = dict(imgsz=640, nbs=64, seed=0, lrf=0.01, warmup_epochs=3.0, warmup_bias_lr=0.0, weight_decay=0.0005, close_mosaic=10,
                 beta1=0.9, beta2=0.999, eps=1e-8, clip=10.0, ema_decay=0.9999, ema_tau=2000.0, auto_batch=None, augment=True, val_max=None,
-                optimizer=None, momentum=0.937, warmup_momentum=0.8)
+                optimizer=None, momentum=0.937, warmup_momentum=0.8, device_augment=True)
 
 
 def _fbits(x: float) -> int:
@@ -87,28 +87,39 @@ def shard_indices(n: int, epoch: int, seed: int, rank: int, world: int) -> np.nd
 
 
 def allreduce_gradients(flat: torch.Tensor) -> torch.Tensor:
-    """The one collective of the training data path: SUM of the flat gradient buffer over ranks (RCCL on GPUs, gloo in tests)."""
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+    """The one collective of the training data path: SUM of the flat gradient buffer over ranks (RCCL on GPUs, gloo in tests).  A gloo group
+    over device tensors (two ranks sharing one GPU in the single-box rehearsal test) stages through host memory."""
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
 class Trainer:
     def __init__(self, yolo, data=None, epochs: int = 100, batch: int = -1, cache: bool = True, project=None, name: str = "train",
-                 verbose: bool = False, dataset=None, val_dataset=None, max_iters: Optional[int] = None, **overrides):
+                 verbose: bool = False, dataset=None, val_dataset=None, max_iters: Optional[int] = None, replica: bool = False, **overrides):
+        """`replica=True`: an independent training on this process's GPU even under a multi-process launch — the zero-communication mode of
+        SURVEY §8e (the reference's 15 fold x plane trainings are independent jobs [REF yolo_mslesseg/ejecutar_pipeline.py:174-184]); no process
+        group is joined and no gradient is exchanged (replicas.py schedules such jobs over the GPUs of a node)."""
         self.yolo, self.epochs, self.verbose = yolo, int(epochs), verbose
         self.hyp = {**DEFAULTS, **{k: v for k, v in overrides.items() if k in DEFAULTS}}
         self.max_iters = max_iters
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.device = torch.device(f"cuda:{self.local}" if self.world > 1 else yolo.device)
+        self.rank = 0 if replica else int(os.environ.get("RANK", "0"))
+        self.world = 1 if replica else int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)  # more ranks than GPUs only in the single-box rehearsal test
+        self.device = torch.device(f"cuda:{self.local}" if (self.world > 1 or (replica and "LOCAL_RANK" in os.environ)) else yolo.device)
         if not torch.cuda.is_available():
             raise hiplib.MslError("no GPU: training runs only on the HIP kernels (no CPU fallback)")
         torch.cuda.set_device(self.device)
         if self.world > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.distributed.init_process_group("nccl", device_id=self.device)
+        self.yolo_device = str(self.device)
         # ---- data
         self.names, self.nc = {0: "lesion"}, 1
         if dataset is None:
@@ -121,6 +132,14 @@ class Trainer:
             dataset = D.SegDataset(tr if tr.is_absolute() else root / tr, self.hyp["imgsz"])
             val_dataset = D.SegDataset(va if va.is_absolute() else root / va, self.hyp["imgsz"])
         self.ds, self.val_ds = dataset, val_dataset
+        # the slice cache of `cache=True` lives in HBM and batches are augmented there (augment.py); device_augment=False keeps the NumPy path of data.py
+        self.aug = self.val_aug = None
+        if self.hyp["device_augment"]:
+            from .augment import DeviceAugmenter, SliceCache
+
+            self.aug = DeviceAugmenter(SliceCache(self.ds, self.device), self.hyp["imgsz"])
+            if self.val_ds is not None and len(self.val_ds):
+                self.val_aug = DeviceAugmenter(SliceCache(self.val_ds, self.device), self.hyp["imgsz"])
         self.data_path = str(data) if data is not None else "synthetic"
         # batch=-1: "choose for me" [REF train.py:361] — upstream's autobatch fills 60 % of the device memory; same rule here (see auto_batch_size)
         self.batch = int(batch) if batch and batch > 0 else int(self.hyp["auto_batch"] or auto_batch_size(self.device, self.hyp["imgsz"]))
@@ -141,7 +160,7 @@ class Trainer:
         state = {k: (v.float() if v.is_floating_point() else v) for k, v in state.items()}
         self.store = ParamStore(scale, self.nc, self.device)
         self.store.load_state(state)
-        self.dtype = yolo.dtype
+        self.dtype = getattr(yolo, "train_dtype", yolo.dtype)  # training arithmetic (bf16 by default: the counterpart of the reference's amp=True)
         S = self.hyp["imgsz"]
         self.plan = TrainPlan(self.store, self.batch, S, S, self.dtype)
         lv = [self.plan.levels[i] for i in sorted(self.plan.levels)]
@@ -189,6 +208,10 @@ class Trainer:
             try:
                 for b in range(self.nb):
                     idx = [int(mine[(b * self.batch + j) % len(mine)]) for j in range(self.batch)]
+                    if self.aug is not None:  # host part only (random draws + label geometry); the consumer launches the two device ops
+                        if not put(self.aug.prepare(idx, rng, mosaic, augment=bool(self.hyp["augment"]))):
+                            return
+                        continue
                     if self.hyp["augment"]:
                         samples = [D.augment(self.ds, i, rng, mosaic, self.hyp["imgsz"]) for i in idx]
                     else:
@@ -207,7 +230,7 @@ class Trainer:
                     return
                 if isinstance(item, BaseException):
                     raise RuntimeError(f"data feeder failed: {item!r}") from item
-                yield item
+                yield self.aug.render(item) if self.aug is not None else item
         finally:
             stop.set()  # early exit (max_iters, an exception in the step): the feeder stops waiting on the queue
 
@@ -259,7 +282,8 @@ class Trainer:
 
     def optimizer_step(self, lr: float) -> None:
         st = self.store
-        allreduce_gradients(st.g)  # the one collective of the data path (SUM over ranks)
+        if self.world > 1:
+            allreduce_gradients(st.g)  # the one collective of the data path (SUM over ranks)
         norm = torch.linalg.vector_norm(st.g)
         self.gscale.copy_(torch.clamp(self.hyp["clip"] / (norm + 1e-6), max=1.0))
         self.opt_steps += 1
@@ -313,14 +337,19 @@ class Trainer:
         for b0 in range(0, limit, vb):
             idx = list(range(b0, min(b0 + vb, limit)))
             nb_ = len(idx)
-            batch = D.collate([D.plain(self.val_ds, i, S) for i in idx], S)
-            plan = eng.plan(nb_, S, S)  # validation slices are already letterboxed RGB at the training size: no LetterBox pass
-            plan.input.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
+            plan = eng.plan(nb_, S, S)  # validation slices are letterboxed RGB at the training size: no LetterBox pass
+            if self.val_aug is not None:
+                batch = self.val_aug.batch(idx, None, mosaic=False, augment=False)
+                plan.input.t.copy_(batch["img"].reshape(-1))
+                gt, masks_d = batch["gt"], batch["masks"]
+            else:
+                batch = D.collate([D.plain(self.val_ds, i, S) for i in idx], S)
+                plan.input.t.copy_(torch.from_numpy(batch["img"]).reshape(-1))
+                gt, masks_d = device_targets(batch, nb_, S, S, self.device)
             plan.run()
             if nb_ not in loss_ops:
                 lv = [plan.builder.levels[i] for i in sorted(plan.builder.levels)]
                 loss_ops[nb_] = SegLossOp(lv, lv, plan.proto, plan.proto, self.nc, S, S, self.dtype, self.device)  # no_grad: the gradient views are never written
-            gt, masks_d = device_targets(batch, nb_, S, S, self.device)
             tot += loss_ops[nb_](gt, masks_d, no_grad=True)[:4].cpu().numpy()
             nbat += 1
             cnt = plan.keep_cnt.cpu()

@@ -28,8 +28,8 @@ LOGGER = logging.getLogger("ultralytics")
 _NAME_RE = re.compile(r"^yolo11([nsmlx])-seg(\.pt|\.yaml)?$")
 
 
-def _precision(p: Optional[str]) -> int:
-    p = (p or os.environ.get("MSLESSEG_PRECISION", "bf16")).lower()
+def _precision(p: Optional[str], env: str, default: str) -> int:
+    p = (p or os.environ.get(env, default)).lower()
     if p in ("bf16", "bfloat16"):
         return MSL_BF16
     if p in ("fp32", "f32", "float32"):
@@ -100,11 +100,18 @@ def _scale_boxes(lb: geometry.LetterBox, xyxy: torch.Tensor) -> torch.Tensor:
 
 class YOLO:
     def __init__(self, model: Union[str, Path] = "yolo11n-seg.pt", task=None, verbose: bool = False, precision: Optional[str] = None,
-                 device: str = "cuda:0"):
+                 device: str = "cuda:0", train_precision: Optional[str] = None):
+        """`precision` (or MSLESSEG_PRECISION): arithmetic of predict — default **fp32**, what the reference's `model(img)` runs (ultralytics
+        predict, half=False) and the engine that reproduces the CPU path exactly (identical NMS indices, identical mask bytes on the trained demo
+        checkpoint: tests/test_gpu_trained.py); "bf16" is the opt-in throughput mode (~3x the slices/s; |dDice| up to 1e-3 per plane volume,
+        profiles/r02a_precision_trained_p39.json).  `train_precision` (or MSLESSEG_TRAIN_PRECISION): arithmetic of `.train()` — default
+        **bf16** compute with fp32 master weights, the MI355X counterpart of the reference's `amp: true` [REF …/args.yaml:28].  An explicit
+        `precision=` sets both unless `train_precision=` is given too."""
         self.ckpt_path = Path(model)
         self.task = task or "segment"
         self.device = device
-        self.dtype = _precision(precision)
+        self.dtype = _precision(precision, "MSLESSEG_PRECISION", "fp32")
+        self.train_dtype = _precision(train_precision or precision, "MSLESSEG_TRAIN_PRECISION", "bf16")
         self.names = {0: "lesion"}
         self._engine = None
         self.trainer = None
@@ -173,9 +180,17 @@ class YOLO:
                 if n == 0:
                     results[i] = Results(imgs[i], self.names, None, None)
                     continue
-                rows = det[j, :n]
+                rows, mk = det[j, :n], masks[j]
+                # instances whose mask came out empty are dropped together with their boxes, as the oracle's reading of 8.3.70's
+                # construct_result does (oracle/prepost.py postprocess_one); invisible after the reference's np.maximum merge, visible in len()
+                live = (mk.sum((-2, -1)) > 0).cpu()
+                if not bool(live.any()):
+                    results[i] = Results(imgs[i], self.names, None, None)
+                    continue
+                if not bool(live.all()):
+                    rows, mk = rows[live], mk[live.to(mk.device)]
                 boxes = torch.cat([_scale_boxes(lb, rows[:, :4]), rows[:, 4:6]], 1)
-                results[i] = Results(imgs[i], self.names, Boxes(boxes, shape[:2]), Masks(masks[j], shape[:2]),
+                results[i] = Results(imgs[i], self.names, Boxes(boxes, shape[:2]), Masks(mk, shape[:2]),
                                      path=srcs[i] if isinstance(srcs[i], (str, Path)) else None)
         return results  # type: ignore[return-value]
 
