@@ -165,7 +165,7 @@ enum {
   MSL_OP_GATHER_CAST = 30,        /* dst[i] = idx[i]>=0 ? src[idx[i]] : 0, cast to op dtype: packs weight images from the flat master buffer */
   MSL_OP_ADAMW = 31,              /* fused AdamW step over a flat fp32 range */
   MSL_OP_EMA = 32,                /* e = d*e + (1-d)*p over a flat fp32 range */
-  MSL_OP_ATTENTION_BWD = 34,      /* PSA attention core backward (bf16): dq, dk written, dv added into the qkv gradient view; p 0 qkv, 1 y, 2 dy,
+  MSL_OP_ATTENTION_BWD = 34,      /* PSA attention core backward (bf16: matrix-core kernels; fp32: VALU kernels): dq, dk written, dv added into the qkv gradient view; p 0 qkv, 1 y, 2 dy,
                                      3 statistics scratch f32 [N][heads][ceil16(HW)+16][4], 4 gqkv ; i as ATTENTION + 14,15 gradient view cs/co */
   MSL_OP_SLICE_EXTRACT = 35,      /* FLAIR volume → batch of rendered slices, with the reference's enhancement variants, on the device
                                      [replaces Paciente.aplicar_mejora + plt.imsave + cv2.imread, REF utils/Paciente.py:195-249,

@@ -95,7 +95,7 @@ def test_fp32_engine_meets_the_north_star_tolerance_on_trained_weights(trained_s
     cons = P.combinar_volumenes(res["axial"]["vol"], res["coronal"]["vol"], res["sagital"]["vol"], 2)
     cons_o = P.combinar_volumenes(oracle_run["axial"]["vol"], oracle_run["coronal"]["vol"], oracle_run["sagital"]["vol"], 2)
     assert abs(P.dsc_unrounded(gt, cons) - P.dsc_unrounded(gt, cons_o)) <= 1e-4
-    assert P.dsc_unrounded(gt, cons_o) > 0.6  # a trained model: the consensus overlaps the GT lesions
+    assert min(o["dice"] for o in oracle_run.values()) > 0.25  # a trained model: with every 3rd lesion slice predicted, each plane volume alone overlaps a third of the GT
 
 
 def test_bf16_engine_measured_deviation_on_trained_weights(trained_state, oracle_run, demo_volumes):
@@ -174,3 +174,35 @@ def test_bf16_train_step_against_the_fp32_engine_on_trained_weights(trained_stat
     assert rel_items.max() < 2e-2
     assert cos > 0.98 and rel < 0.2
     assert per[0][0] > 0.8, per[:6]
+
+
+def test_predict_variants_mixed_work_list_equals_single_variant_runs(trained_state, demo_volumes, golden_dir, tmp_path):
+    """BASELINE configs[4]: a mixed list of (volume, variant, plane) items, one model per enhancement variant [REF ConfigPred.py:150-166,
+    mejora_imagen.py:43-184], dealt over ranks without a collective: every item's plane volume equals the single-variant path, each item is
+    predicted by exactly one rank, and the variant really selects the weights and the slice rendering."""
+    from ultralytics import YOLO
+
+    from mslesseg_amd import params
+
+    synth = torch.load(golden_dir / "synth_n_nc1.pt", map_location="cpu", weights_only=True)
+    paths = {}
+    for name, st in (("GC", trained_state), ("HE", {k: (v.float() if v.is_floating_point() else v) for k, v in synth.items()})):
+        paths[name] = tmp_path / name / "weights" / "best.pt"
+        params.save_checkpoint(paths[name], st, "n", 1, {0: "lesion"})
+    models = {k: YOLO(p) for k, p in paths.items()}
+    fl, gt = demo_volumes["P39_flair"], demo_volumes["P39_mask"]
+    idx = {pl: V.select_slices(gt, pl, 12) for pl in ("axial", "coronal", "sagital")}
+    items = [(fl, "GC", "axial", idx["axial"]), (fl, "HE", "coronal", idx["coronal"]), (fl, "GC", "sagital", idx["sagital"]), (fl, "HE", "axial", idx["axial"])]
+    single = [V.predict_volume(models[m], f, pl, ii, mejora=m).cpu() for f, m, pl, ii in items]
+    seen = [0] * len(items)
+    for world in (1, 2):
+        for rank in range(world):
+            outs = V.predict_variants(models, items, rank=rank, world=world)
+            for k, o in enumerate(outs):
+                if o is not None:
+                    assert torch.equal(o.cpu(), single[k]), (world, rank, k)
+                    seen[k] += world == 2
+    assert seen == [1, 1, 1, 1]
+    assert not torch.equal(single[0], V.predict_volume(models["HE"], fl, "axial", idx["axial"], mejora="GC").cpu())  # the weights matter
+    with pytest.raises(KeyError):
+        V.predict_variants(models, [(fl, "LT", "axial", idx["axial"])], rank=0, world=1)

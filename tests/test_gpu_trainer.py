@@ -94,14 +94,25 @@ def test_optimizer_auto_takes_sgd_beyond_10k_iterations_and_feeder_errors_surfac
     assert Trainer(model, dataset=ds, val_dataset=None, epochs=10, batch=4, project=tmp_path, name="adamw", imgsz=64, nbs=4).optimizer == "AdamW"
 
     class Broken(D.SyntheticSegDataset):
+        armed = False
+
         def get(self, i):
-            if i == 5:
+            if self.armed and i == 5:
                 raise OSError("unreadable label file")
             return super().get(i)
 
-    bad = Trainer(model, dataset=Broken(8, 64, seed=0), val_dataset=None, epochs=1, batch=4, project=tmp_path, name="bad", imgsz=64, nbs=4, augment=False)
-    with pytest.raises(RuntimeError, match="data feeder failed"):
-        bad.fit()
+    for dev_aug in (False, True):  # the NumPy feeder reads the dataset in its thread; the device feeder prepares labels there
+        ds_bad = Broken(8, 64, seed=0)
+        bad = Trainer(model, dataset=ds_bad, val_dataset=None, epochs=1, batch=4, project=tmp_path, name=f"bad{int(dev_aug)}", imgsz=64, nbs=4, augment=False,
+                      device_augment=dev_aug)
+        ds_bad.armed = True
+        if dev_aug:
+            def boom(*a, **k):
+                raise OSError("label geometry failed")
+
+            bad.aug.prepare = boom
+        with pytest.raises(RuntimeError, match="data feeder failed"):
+            bad.fit()
 
 
 def test_train_through_the_reference_call_signature(tmp_path):

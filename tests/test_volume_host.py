@@ -47,3 +47,18 @@ def test_select_slices_restates_indices_a_usar(demo_volumes):
         centro, start = n // 2, max(0, n // 2 - 25)
         assert sub == idx[start : start + 50] and len(sub) == 50 and idx[centro] in sub
     assert V.select_slices(np.zeros((4, 5, 6), np.uint8), "axial", 3) == []
+
+
+def test_variant_work_items_are_dealt_completely_and_grouped():
+    """configs[4]: a mixed list of (volume, variant, plane) items over 1..8 ranks — every item exactly once, a rank's share ordered by variant."""
+    from mslesseg_amd import volume as V
+
+    items = [(None, mej, pl, n) for mej in (None, "HE", "CLAHE", "GC", "LT") for pl, n in (("axial", 182), ("coronal", 218), ("sagital", 182))] * 2
+    for world in (1, 2, 3, 8):
+        parts = V.assign_variant_items(items, world)
+        assert sorted(k for p in parts for k in p) == list(range(len(items)))
+        loads = [sum(items[k][3] for k in p) for p in parts]
+        assert max(loads) - min(loads) <= 218
+        for p in parts:
+            keys = [(str(items[k][1]), str(items[k][2])) for k in p]
+            assert keys == sorted(keys)

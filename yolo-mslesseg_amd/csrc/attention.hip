@@ -444,18 +444,201 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(const unsigned sh
   }
 }
 
-// ATTENTION_BWD (bf16 only): p 0 qkv view, 1 forward output view y, 2 gradient of y (same view geometry), 3 statistics scratch
+
+// ---- generic backward on the VALU (fp32 parity engine; also any bf16 geometry the matrix-core kernels do not take) --------------------------
+// S = scale q k^T, P = softmax_rows(S), O = P V;  dV = P^T dO, dP = dO V^T, dS = P o (dP - D) with D_i = dO_i . O_i, dQ = scale dS K, dK = scale dS^T Q.
+// Two launches, both recomputing P from (row max, 1 / row sum) so that no [HW,HW] tensor exists:
+//   rows  (thread = query i): row max / sum over all keys, then dq_i; leaves (m_i, 1/l_i, D_i) in the statistics scratch
+//   cols  (thread = key j)  : dk_j (written) and dv_j (ADDED to what the positional-encoding branch left in the v slots)
+// K/V (rows) and Q/dO/statistics (cols) tiles of 32 tokens go through LDS as fp32 and are read back as broadcasts.
+template <bool F32>
+__global__ __launch_bounds__(128) void attention_bwd_rows_kernel(const void* __restrict__ qkv, const void* __restrict__ yo, const void* __restrict__ dyo,
+                                                                 float* __restrict__ stats, void* __restrict__ gqkv, int HW, int HWp, int x_cs, int x_co,
+                                                                 int y_cs, int y_co, int g_cs, int g_co, float scale) {
+  constexpr int KD = 32, HD = 64, TK = 32, ROW = KD + HD;
+  __shared__ __attribute__((aligned(16))) float skv[TK][ROW];
+  const int head = blockIdx.y, n = blockIdx.z, heads = gridDim.y;
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  const bool valid = i < HW;
+  const long rowbase = (long)n * HW;
+  const int hoff = x_co + head * (2 * KD + HD);
+  float q[KD], dq[KD], dO[HD];
+  float D = 0.f;
+#pragma unroll
+  for (int d = 0; d < KD; d += 4) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) ld4<F32>(qkv, (rowbase + i) * x_cs + hoff + d, v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { q[d + r] = v[r]; dq[d + r] = 0.f; }
+  }
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      ld4<F32>(dyo, (rowbase + i) * y_cs + y_co + head * HD + d, a);
+      ld4<F32>(yo, (rowbase + i) * y_cs + y_co + head * HD + d, o);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dO[d + r] = a[r]; D = fmaf(a[r], o[r], D); }
+  }
+  float m = -__builtin_inff(), l = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float invl = pass ? 1.0f / l : 0.f;
+    for (int j0 = 0; j0 < HW; j0 += TK) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < TK * ROW / 4; e += 128) {
+        const int j = e / (ROW / 4), d4 = (e - j * (ROW / 4)) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (j0 + j < HW) ld4<F32>(qkv, (rowbase + j0 + j) * x_cs + hoff + KD + d4, v);
+        *(float4*)&skv[j][d4] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      __syncthreads();
+      const int nk = min(TK, HW - j0);
+      for (int j = 0; j < nk; ++j) {
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < KD; d += 4) {
+          const float4 k4 = *(const float4*)&skv[j][d];
+          dot = fmaf(q[d], k4.x, dot); dot = fmaf(q[d + 1], k4.y, dot); dot = fmaf(q[d + 2], k4.z, dot); dot = fmaf(q[d + 3], k4.w, dot);
+        }
+        const float sc = dot * scale;
+        if (pass == 0) {
+          const float mn = fmaxf(m, sc);
+          l = l * __expf(m - mn) + __expf(sc - mn);
+          m = mn;
+        } else {
+          const float p = __expf(sc - m) * invl;
+          float dp = 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; d += 4) {
+            const float4 v4 = *(const float4*)&skv[j][KD + d];
+            dp = fmaf(dO[d], v4.x, dp); dp = fmaf(dO[d + 1], v4.y, dp); dp = fmaf(dO[d + 2], v4.z, dp); dp = fmaf(dO[d + 3], v4.w, dp);
+          }
+          const float ds = p * (dp - D);
+#pragma unroll
+          for (int d = 0; d < KD; d += 4) {
+            const float4 k4 = *(const float4*)&skv[j][d];
+            dq[d] = fmaf(ds, k4.x, dq[d]); dq[d + 1] = fmaf(ds, k4.y, dq[d + 1]); dq[d + 2] = fmaf(ds, k4.z, dq[d + 2]); dq[d + 3] = fmaf(ds, k4.w, dq[d + 3]);
+          }
+        }
+      }
+    }
+  }
+  if (!valid) return;
+  float* st = stats + (((long)n * heads + head) * HWp + i) * 4;
+  st[0] = m; st[1] = 1.0f / l; st[2] = D; st[3] = 0.f;
+  const long o = (rowbase + i) * g_cs + g_co + head * (2 * KD + HD);
+#pragma unroll
+  for (int d = 0; d < KD; d += 4) {
+    const float v[4] = {dq[d] * scale, dq[d + 1] * scale, dq[d + 2] * scale, dq[d + 3] * scale};
+    st4<F32>(gqkv, o + d, v);
+  }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(128) void attention_bwd_cols_kernel(const void* __restrict__ qkv, const void* __restrict__ dyo, const float* __restrict__ stats,
+                                                                 void* __restrict__ gqkv, int HW, int HWp, int x_cs, int x_co, int y_cs, int y_co, int g_cs,
+                                                                 int g_co, float scale) {
+  constexpr int KD = 32, HD = 64, TQ = 32, ROW = KD + HD + 4;
+  __shared__ __attribute__((aligned(16))) float sq[TQ][ROW];  // q | dO | (m, 1/l, D, -)
+  const int head = blockIdx.y, n = blockIdx.z, heads = gridDim.y;
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  const bool valid = j < HW;
+  const long rowbase = (long)n * HW;
+  const int hoff = x_co + head * (2 * KD + HD);
+  float k[KD], dk[KD], v[HD], dv[HD];
+#pragma unroll
+  for (int d = 0; d < KD; d += 4) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) ld4<F32>(qkv, (rowbase + j) * x_cs + hoff + KD + d, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { k[d + r] = t[r]; dk[d + r] = 0.f; }
+  }
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) ld4<F32>(qkv, (rowbase + j) * x_cs + hoff + 2 * KD + d, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[d + r] = t[r]; dv[d + r] = 0.f; }
+  }
+  for (int i0 = 0; i0 < HW; i0 += TQ) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < TQ * ROW / 4; e += 128) {
+      const int i = e / (ROW / 4), d4 = (e - i * (ROW / 4)) * 4;
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      if (i0 + i < HW) {
+        if (d4 < KD) ld4<F32>(qkv, (rowbase + i0 + i) * x_cs + hoff + d4, t);
+        else if (d4 < KD + HD) ld4<F32>(dyo, (rowbase + i0 + i) * y_cs + y_co + head * HD + (d4 - KD), t);
+        else { const float4 s4 = *(const float4*)(stats + (((long)n * heads + head) * HWp + i0 + i) * 4); t[0] = s4.x; t[1] = s4.y; t[2] = s4.z; }
+      }
+      *(float4*)&sq[i][d4] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();
+    const int nq = min(TQ, HW - i0);
+    for (int i = 0; i < nq; ++i) {
+      float dot = 0.f;
+#pragma unroll
+      for (int d = 0; d < KD; d += 4) {
+        const float4 q4 = *(const float4*)&sq[i][d];
+        dot = fmaf(q4.x, k[d], dot); dot = fmaf(q4.y, k[d + 1], dot); dot = fmaf(q4.z, k[d + 2], dot); dot = fmaf(q4.w, k[d + 3], dot);
+      }
+      const float4 s4 = *(const float4*)&sq[i][KD + HD];
+      const float p = __expf(dot * scale - s4.x) * s4.y;
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const float4 a4 = *(const float4*)&sq[i][KD + d];
+        dp = fmaf(a4.x, v[d], dp); dp = fmaf(a4.y, v[d + 1], dp); dp = fmaf(a4.z, v[d + 2], dp); dp = fmaf(a4.w, v[d + 3], dp);
+        dv[d] = fmaf(p, a4.x, dv[d]); dv[d + 1] = fmaf(p, a4.y, dv[d + 1]); dv[d + 2] = fmaf(p, a4.z, dv[d + 2]); dv[d + 3] = fmaf(p, a4.w, dv[d + 3]);
+      }
+      const float ds = p * (dp - s4.z);
+#pragma unroll
+      for (int d = 0; d < KD; d += 4) {
+        const float4 q4 = *(const float4*)&sq[i][d];
+        dk[d] = fmaf(ds, q4.x, dk[d]); dk[d + 1] = fmaf(ds, q4.y, dk[d + 1]); dk[d + 2] = fmaf(ds, q4.z, dk[d + 2]); dk[d + 3] = fmaf(ds, q4.w, dk[d + 3]);
+      }
+    }
+  }
+  if (!valid) return;
+  const long o = (rowbase + j) * g_cs + g_co + head * (2 * KD + HD);
+#pragma unroll
+  for (int d = 0; d < KD; d += 4) {
+    const float t[4] = {dk[d] * scale, dk[d + 1] * scale, dk[d + 2] * scale, dk[d + 3] * scale};
+    st4<F32>(gqkv, o + KD + d, t);
+  }
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    float old[4];
+    ld4<F32>(gqkv, o + 2 * KD + d, old);
+    const float t[4] = {old[0] + dv[d], old[1] + dv[d + 1], old[2] + dv[d + 2], old[3] + dv[d + 3]};
+    st4<F32>(gqkv, o + 2 * KD + d, t);
+  }
+}
+
+// ATTENTION_BWD: p 0 qkv view, 1 forward output view y, 2 gradient of y (same view geometry), 3 statistics scratch
 // f32 [N][heads][ceil16(HW)+16][4], 4 gradient view of qkv (dq, dk written; dv ADDED) ; i 0 N,1 H,2 W,3 heads,4 kd,5 hd,
 // 10 x_cs,11 x_co,12 y_cs,13 y_co,14 g_cs,15 g_co ; f 0 scale
 int msl_launch_attention_bwd(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], heads = op.i[3], kd = op.i[4], hd = op.i[5];
   const int x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13], g_cs = op.i[14], g_co = op.i[15];
-  MSL_REQUIRE(op.dtype == MSL_BF16, "attention_bwd: bf16 tensors only (the fp32 engine differentiates the attention core with tensor ops)");
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && N > 0 && H > 0 && W > 0 && heads > 0 && kd == 32 && hd == 64, "attention_bwd: bad args");
   const int HW = H * W;
-  MSL_REQUIRE(HW <= 16 * AT_MAX_KT - 16 && ((x_cs | x_co | y_cs | y_co | g_cs | g_co) & 7) == 0 && x_co + heads * 128 <= x_cs && g_co + heads * 128 <= g_cs &&
-                  y_co + heads * 64 <= y_cs, "attention_bwd: at most %d tokens; views must be 8-aligned", 16 * AT_MAX_KT - 16);
+  MSL_REQUIRE(((x_cs | x_co | y_cs | y_co | g_cs | g_co) & 3) == 0 && x_co + heads * 128 <= x_cs && g_co + heads * 128 <= g_cs && y_co + heads * 64 <= y_cs,
+              "attention_bwd: views must be 4-aligned and hold heads x (q 32 | k 32 | v 64)");
   const int HWp = ((HW + 15) / 16) * 16 + 16;
+  if (op.dtype == MSL_F32 || HW > 16 * AT_MAX_KT - 16 || ((x_cs | x_co | y_cs | y_co | g_cs | g_co) & 7) != 0) {
+    // the VALU kernels: fp32 tensors (the parity engine), or a bf16 geometry the matrix-core kernels do not take
+    const dim3 grid((unsigned)((HW + 127) / 128), (unsigned)heads, (unsigned)N);
+    if (op.dtype == MSL_F32) {
+      hipLaunchKernelGGL(attention_bwd_rows_kernel<true>, grid, dim3(128), 0, s, op.p[0], op.p[1], op.p[2], (float*)op.p[3], op.p[4], HW, HWp, x_cs, x_co, y_cs, y_co, g_cs, g_co, op.f[0]);
+      hipLaunchKernelGGL(attention_bwd_cols_kernel<true>, grid, dim3(128), 0, s, op.p[0], op.p[2], (const float*)op.p[3], op.p[4], HW, HWp, x_cs, x_co, y_cs, y_co, g_cs, g_co, op.f[0]);
+    } else {
+      hipLaunchKernelGGL(attention_bwd_rows_kernel<false>, grid, dim3(128), 0, s, op.p[0], op.p[1], op.p[2], (float*)op.p[3], op.p[4], HW, HWp, x_cs, x_co, y_cs, y_co, g_cs, g_co, op.f[0]);
+      hipLaunchKernelGGL(attention_bwd_cols_kernel<false>, grid, dim3(128), 0, s, op.p[0], op.p[2], (const float*)op.p[3], op.p[4], HW, HWp, x_cs, x_co, y_cs, y_co, g_cs, g_co, op.f[0]);
+    }
+    MSL_CHECK_LAUNCH("attention_bwd");
+    return MSL_OK;
+  }
   const size_t lds = (size_t)(((HWp * 5 + 63) & ~63) + ((HWp * 9 + 63) & ~63)) * 16;
   static bool attr = false;
   if (!attr) {

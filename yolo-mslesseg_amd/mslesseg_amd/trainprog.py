@@ -241,8 +241,8 @@ class TrainPlan(graph.Visitor):
     """Forward + backward programs of YOLO11-seg in training mode for a fixed batch shape.
 
     step order:  pack() → forward() → [loss: fills head gradients] → backward()  → grads in `store.g`
-    `forward/backward` are lists of segments: hiplib.Program or a Python callable (the PSA attention core, < 1 % of
-    the FLOPs, still runs through rocBLAS batched GEMMs via torch in training — see DESIGN.md)."""
+    `forward/backward` are lists of segments (hiplib.Program; the segment machinery still accepts a Python callable, none is emitted any more:
+    every op of both engines, the PSA attention core included, is a kernel of this library)."""
 
     def __init__(self, store: ParamStore, N: int, H: int, W: int, dtype: int = MSL_BF16):
         assert H % 32 == 0 and W % 32 == 0
@@ -717,60 +717,24 @@ class TrainPlan(graph.Visitor):
         self._add_bw(bw)
 
     def attention(self, qkv, heads, kd, hd):
+        """PSA attention core, forward (MSL_OP_ATTENTION) and backward (MSL_OP_ATTENTION_BWD, probabilities recomputed) in HIP for both engines:
+        bf16 on the matrix-core kernels of attention.hip, fp32 (the parity engine) on its VALU kernels."""
         self._set_lane(None)
-        """PSA attention core.  bf16: the matrix-core kernels of attention.hip, forward (MSL_OP_ATTENTION) and backward
-        (MSL_OP_ATTENTION_BWD, probabilities recomputed).  fp32 (parity engine): torch batched GEMMs + softmax and the hand-derived backward."""
         y = self._new(qkv.H, qkv.W, heads * hd)
         HW, N = qkv.H * qkv.W, self.N
         scale = kd**-0.5
-        if self.dtype == MSL_BF16 and HW <= 496 and not any(v % 8 for v in (qkv.cs, qkv.co, y.cs, y.co)):
-            dims = {0: N, 1: qkv.H, 2: qkv.W, 3: heads, 4: kd, 5: hd, 10: qkv.cs, 11: qkv.co, 12: y.cs, 13: y.co}
-            self._f(hiplib.make_op(hiplib.OP_ATTENTION, self.dtype, p=(qkv.t.data_ptr(), 0, 0, 0, y.t.data_ptr()), i=dims, f=(scale,)))
-            stats = torch.zeros(N * heads * ((HW + 15) // 16 * 16 + 16) * 4, dtype=torch.float32, device=self.device)
-            self._keep.append(stats)
+        dims = {0: N, 1: qkv.H, 2: qkv.W, 3: heads, 4: kd, 5: hd, 10: qkv.cs, 11: qkv.co, 12: y.cs, 13: y.co}
+        self._f(hiplib.make_op(hiplib.OP_ATTENTION, self.dtype, p=(qkv.t.data_ptr(), 0, 0, 0, y.t.data_ptr()), i=dims, f=(scale,)))
+        stats = torch.zeros(N * heads * ((HW + 15) // 16 * 16 + 16) * 4, dtype=torch.float32, device=self.device)
+        self._keep.append(stats)
 
-            def bw_hip():
-                gq, gy = self.G(qkv), self.G(y)
-                self._init.mark(gq)  # dq, dk are written, dv is added to what the positional-encoding branch left there
-                return [hiplib.make_op(hiplib.OP_ATTENTION_BWD, self.dtype, p=(qkv.t.data_ptr(), y.t.data_ptr(), gy.t.data_ptr(), stats.data_ptr(), gq.t.data_ptr()),
-                                       i={**dims, 14: gq.cs, 15: gq.co}, f=(scale,))]
+        def bw_hip():
+            gq, gy = self.G(qkv), self.G(y)
+            self._init.mark(gq)  # dq, dk are written, dv is added to what the positional-encoding branch left there
+            return [hiplib.make_op(hiplib.OP_ATTENTION_BWD, self.dtype, p=(qkv.t.data_ptr(), y.t.data_ptr(), gy.t.data_ptr(), stats.data_ptr(), gq.t.data_ptr()),
+                                   i={**dims, 14: gq.cs, 15: gq.co}, f=(scale,))]
 
-            self._add_bw(bw_hip)
-            return y
-        saved = {}
-
-        def split():
-            t = qkv.torch().reshape(N, HW, heads, 2 * kd + hd).float().permute(0, 2, 1, 3)  # [N,heads,HW,128]
-            return t[..., :kd], t[..., kd : 2 * kd], t[..., 2 * kd :]
-
-        def fwd():
-            q, k, v = split()
-            p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
-            saved["p"] = p
-            o = p @ v  # [N,heads,HW,hd]
-            y.torch().copy_(o.permute(0, 2, 1, 3).reshape(N, qkv.H, qkv.W, heads * hd))
-
-        self._fwd.append(fwd)
-        self._fwd.append([])
-
-        def bw():
-            def run():
-                q, k, v = split()
-                p = saved["p"]
-                do = self.G(y).torch().reshape(N, HW, heads, hd).float().permute(0, 2, 1, 3)
-                dv = p.transpose(-1, -2) @ do
-                dp = do @ v.transpose(-1, -2)
-                ds = p * (dp - (dp * p).sum(-1, keepdim=True))
-                dq = (ds @ k) * scale
-                dk = (ds.transpose(-1, -2) @ q) * scale
-                g = self.G(qkv).torch().reshape(N, HW, heads, 2 * kd + hd)
-                g[..., :kd] = dq.permute(0, 2, 1, 3)
-                g[..., kd : 2 * kd] = dk.permute(0, 2, 1, 3)
-                g[..., 2 * kd :] += dv.permute(0, 2, 1, 3)  # v slots already hold the pe gradient
-            self._init.mark(self.G(qkv))
-            return [run]
-
-        self._add_bw(bw)
+        self._add_bw(bw_hip)
         return y
 
     def head_level(self, i, box, cls, coef):

@@ -14,7 +14,7 @@ from __future__ import annotations
 import gzip
 import struct
 from pathlib import Path
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Dict, Iterable, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -228,3 +228,42 @@ def predict_consensus(models: Dict[str, object], flair: np.ndarray, umbral: int 
     """Three plane models → (consensus uint8 volume on device, per-plane float32 volumes)."""
     vols = {pl: predict_volume(models[pl], flair, pl, None if indices is None else indices.get(pl)) for pl in ("axial", "coronal", "sagital")}
     return consensus(vols["axial"], vols["coronal"], vols["sagital"], umbral), vols
+
+
+# ------------------------------------------------------------------------------------------------- enhancement variants, mixed work lists
+def assign_variant_items(items: Sequence[Tuple], world: int) -> list:
+    """Work items (…, mejora, plano, n_slices) → per-rank lists of item positions.  Items are ordered by (variant, plane) so that a rank's share is
+    made of few variants (one set of weights each), then dealt longest-first to the least-loaded rank by slice count; deterministic, so every rank
+    derives the same table without a collective (inference shards over independent volumes, no exchange)."""
+    from .replicas import schedule
+
+    order = sorted(range(len(items)), key=lambda k: (str(items[k][1]), str(items[k][2]), k))
+    parts = schedule([float(items[k][3]) for k in order], world)
+    return [[order[j] for j in sorted(p)] for p in parts]
+
+
+def predict_variants(models: Dict[Optional[str], object], items: Sequence[Tuple], rank: Optional[int] = None, world: Optional[int] = None, batch: int = 128):
+    """BASELINE configs[4]: inference over a mixed list of (flair volume, mejora, plano[, slice indices]) work items with one trained model per
+    enhancement variant — the reference selects the weights by the variant's name (`trains/<mejora>/…/<plano>/fold<k>/weights/best.pt`
+    [REF yolo_mslesseg/configs/ConfigPred.py:150-166]) and enhances every slice before it is rendered [REF utils/mejora_imagen.py:43-184,
+    utils/Paciente.py:195-222].  `models` maps a variant (None, "HE", "CLAHE", "GC", "LT") — or a (variant, plano) pair — to a YOLO object.
+    This rank's share (`assign_variant_items`) is grouped by variant so that each model's weights are used in consecutive whole-volume batches;
+    → list aligned with `items`: the plane volume (float32 {0,1}, device) for items of this rank, None for the others."""
+    import os
+
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    norm = []
+    for it in items:
+        flair, mejora, plano = it[0], it[1], it[2]
+        idx = list(it[3]) if len(it) > 3 and it[3] is not None else None
+        norm.append((flair, mejora, plano, len(idx) if idx is not None else flair.shape[PLANE_AXIS[plano]], idx))
+    mine = assign_variant_items(norm, world)[rank]
+    out: list = [None] * len(items)
+    for k in mine:  # already grouped: assign_variant_items keeps (variant, plane) order inside a rank's share
+        flair, mejora, plano, _, idx = norm[k]
+        model = models.get((mejora, plano), models.get(mejora))
+        if model is None:
+            raise KeyError(f"no model for enhancement variant {mejora!r} (plane {plano})")
+        out[k] = predict_volume(model, flair, plano, idx, batch=batch, mejora=mejora)
+    return out
