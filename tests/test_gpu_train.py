@@ -143,3 +143,40 @@ def test_train_step_bf16_gradients_are_close_in_direction(synth_state):
         a, b = gsd[k].flatten(), grads[k].flatten()
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-20))
         assert cos > 0.5, (k, cos)
+
+
+def test_full_resolution_gradients_of_both_engines_match_oracle_autograd(golden_dir, demo_volumes):
+    """640x640 (400 attention tokens, the tile/persistent kernel shapes of the real workload), trained weights, two real FLAIR slices: every
+    parameter gradient of the fp32 engine AND of the bf16 engine against the oracle's autograd, tensor by tensor.  (The small-shape tests above
+    have 6 attention tokens; a wrong attention backward at full size — the PSA output overwritten in place by `attn + pe(v)` before its backward
+    read it — went unnoticed there and corrupted every gradient upstream of C2PSA.)"""
+    from mslesseg_amd import data as D
+    from mslesseg_amd import volume as V
+
+    st = torch.load(golden_dir / "demo_p39_n.pt", map_location="cpu", weights_only=True)
+    st = {k: (v.float() if v.is_floating_point() else v) for k, v in st.items()}
+    fl = demo_volumes["P39_flair"]
+    N, H, W = 2, 640, 640
+    img = np.stack([D._letterbox(D.resize_keep_ratio(np.ascontiguousarray(V.slice_as_png_array(V.take_slice(fl, "axial", 60 + 25 * i))[..., ::-1]), 640), [], 640)[0]
+                    for i in range(N)])
+    R, shapes = _probe(N, H, W)
+    torch.set_num_threads(16)
+    _, _, _, grads, _ = _oracle_run(st, img, R)
+    keys = [k for k in grads if k != "model.23.dfl.conv.weight"]
+    flat_o = torch.cat([grads[k].flatten() for k in keys]).double()
+    for dtype, tol_flat, tol_each in ((MSL_F32, 1e-5, 1e-4), (MSL_BF16, 2e-3, 3e-2)):
+        store, plan, _ = _run_plan(st, img, R, shapes, dtype)
+        gsd = store.state_dict(p=store.g)
+        flat = torch.cat([gsd[k].flatten() for k in keys]).double()
+        cos = float((flat @ flat_o) / (flat.norm() * flat_o.norm()))
+        worst = []
+        for k in keys:
+            a, b = gsd[k].flatten().double(), grads[k].flatten().double()
+            if float(b.norm()) > 1e-4 * float(flat_o.norm()):  # shift-invariant biases have a true gradient of ~0
+                worst.append((1.0 - float((a @ b) / (a.norm() * b.norm() + 1e-30)), k))
+        worst.sort(reverse=True)
+        print(f"dtype {dtype}: flat gradient 1-cos {1 - cos:.2e}, worst tensors {[(f'{w:.1e}', k) for w, k in worst[:3]]}")
+        assert 1.0 - cos < tol_flat, (dtype, cos)
+        assert worst[0][0] < tol_each, (dtype, worst[:5])
+        del store, plan
+        torch.cuda.empty_cache()
