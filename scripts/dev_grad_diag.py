@@ -13,7 +13,12 @@ from test_gpu_train import _oracle_run, _probe, _run_plan  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "trained"
 N, H, W = int(sys.argv[2]) if len(sys.argv) > 2 else 2, 640, 640
-if which == "trained":
+SCALE = "s" if which.startswith("s_") else "n"
+if which == "s_init":
+    from mslesseg_amd import params
+
+    st = params.init_state("s", 1, seed=0)
+elif which == "trained":
     st = torch.load(ROOT / "tests/golden/demo_p39_n.pt", map_location="cpu", weights_only=True)
 else:
     st = torch.load(ROOT / "tests/golden/synth_n_nc1.pt", map_location="cpu", weights_only=True)
@@ -30,10 +35,10 @@ for i in range(N):
 img = np.stack(imgs)
 R, shapes = _probe(N, H, W)
 torch.set_num_threads(16)
-feats, mc, p, grads, bufs = _oracle_run(st, img, R)
+feats, mc, p, grads, bufs = _oracle_run(st, img, R, scale=SCALE)
 res = {}
 for name, dt in (("fp32", MSL_F32), ("bf16", MSL_BF16)):
-    store, plan, fw = _run_plan(st, img, R, shapes, dt)
+    store, plan, fw = _run_plan(st, img, R, shapes, dt, scale=SCALE)
     res[name] = store.state_dict(p=store.g)
     perr = float((fw["proto"] - p.permute(0, 2, 3, 1).detach()).norm() / p.norm())
     print(name, "forward proto rel L2", perr)

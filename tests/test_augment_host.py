@@ -47,13 +47,13 @@ def test_prepare_labels_equal_the_per_sample_path(mosaic, augment, size):
     aug = A.DeviceAugmenter(A.SliceCache(ds), size)
     idx = [3, 0, 7, 7, 12, 21, 5, 10]
     for seed in range(4):
-        r1, r2 = np.random.default_rng([seed, 9]), np.random.default_rng([seed, 9])
+        draws = D.draw_params(np.random.default_rng([seed, 9]), len(idx), len(ds), mosaic, size)
         if augment:
-            samples = [D.augment(ds, i, r1, mosaic, size) for i in idx]
+            samples = [D.augment(ds, i, None, mosaic, size, draws=D.draw_row(draws, b)) for b, i in enumerate(idx)]
         else:
             samples = [D.plain(ds, i, size) for i in idx]
         want = D.collate(samples, size)
-        got = aug.prepare(idx, r2, mosaic, augment)
+        got = aug.prepare(idx, None, mosaic, augment, draws=draws)
         assert np.array_equal(got["batch_idx"], want["batch_idx"])
         assert np.array_equal(got["cls"], want["cls"])
         assert np.array_equal(got["bboxes"], want["bboxes"])  # bit-equal float32
@@ -71,5 +71,8 @@ def test_prepare_labels_equal_the_per_sample_path(mosaic, augment, size):
                 assert val == j + 1 and np.array_equal(got["pts"][v0 : v0 + nv], polys[o] / 4)
                 k += 1
         assert k == len(want["cls"])
-        if augment:  # both generators consumed the same number of draws
-            assert r1.random() == r2.random()
+    if augment:  # a generator instead of a record: the batch draw is what the per-sample path draws for a batch of one
+        r1, r2 = np.random.default_rng(5), np.random.default_rng(5)
+        a = D.collate([D.augment(ds, 3, r1, mosaic, size)], size)
+        b = aug.prepare([3], r2, mosaic, True)
+        assert np.array_equal(a["bboxes"], b["bboxes"]) and r1.random() == r2.random()

@@ -17,10 +17,10 @@ def test_device_batch_equals_numpy_restatement(mosaic, augment, size):
     aug = A.DeviceAugmenter(A.SliceCache(ds, "cuda:0"), size)
     idx = [3, 0, 7, 7, 12, 21, 5, 10, 23, 1]
     for seed in range(3):
-        r1, r2 = np.random.default_rng([seed, 5]), np.random.default_rng([seed, 5])
-        samples = [D.augment(ds, i, r1, mosaic, size) if augment else D.plain(ds, i, size) for i in idx]
+        draws = D.draw_params(np.random.default_rng([seed, 5]), len(idx), len(ds), mosaic, size)
+        samples = [D.augment(ds, i, None, mosaic, size, draws=D.draw_row(draws, b)) if augment else D.plain(ds, i, size) for b, i in enumerate(idx)]
         want = D.collate(samples, size)
-        got = aug.batch(idx, r2, mosaic, augment)
+        got = aug.batch(idx, None, mosaic, augment, draws=draws)
         torch.cuda.synchronize()
         img, masks = got["img"].cpu().numpy(), got["masks"].cpu().numpy()
         assert img.shape == want["img"].shape and masks.shape == want["masks"].shape
@@ -39,9 +39,9 @@ def test_real_slices_and_lesion_polygons(demo_volumes):
     assert len(ds) >= 20
     aug = A.DeviceAugmenter(A.SliceCache(ds, "cuda:0"), 640)
     idx = list(range(0, len(ds), 3))
-    r1, r2 = np.random.default_rng(11), np.random.default_rng(11)
-    want = D.collate([D.augment(ds, i, r1, True, 640) for i in idx], 640)
-    got = aug.batch(idx, r2, True, True)
+    draws = D.draw_params(np.random.default_rng(11), len(idx), len(ds), True, 640)
+    want = D.collate([D.augment(ds, i, None, True, 640, draws=D.draw_row(draws, b)) for b, i in enumerate(idx)], 640)
+    got = aug.batch(idx, None, True, True, draws=draws)
     assert int((got["img"].cpu().numpy() != want["img"]).sum()) == 0
     assert int((got["masks"].cpu().numpy() != want["masks"]).sum()) == 0
     assert np.array_equal(got["bboxes"], want["bboxes"]) and len(want["cls"]) > 20

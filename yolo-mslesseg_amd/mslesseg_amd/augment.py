@@ -78,87 +78,46 @@ class DeviceAugmenter:
         self.scale, self.translate, self.hsv, self.fliplr = scale, translate, hsv, fliplr
         self.device = cache.device
 
-    # ------------------------------------------------------------------ random draws + geometry of one sample (order of data.augment)
-    def _draw(self, idx: int, rng, mosaic: bool, rec: np.ndarray, tiles: list, b: int):
-        c, s = self.c, self.size
-        recf = rec.view(np.float64)
-        if mosaic:
-            yc, xc = (int(rng.uniform(s // 2, 2 * s - s // 2)) for _ in range(2))
-            items = [idx] + [int(rng.integers(0, c.n)) for _ in range(3)]
-            for k, i in enumerate(items):
-                h, w = int(c.h[i]), int(c.w[i])
-                if k == 0:
-                    x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
-                    x1b, y1b = w - (x2a - x1a), h - (y2a - y1a)
-                elif k == 1:
-                    x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, 2 * s), yc
-                    x1b, y1b = 0, h - (y2a - y1a)
-                elif k == 2:
-                    x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(2 * s, yc + h)
-                    x1b, y1b = w - (x2a - x1a), 0
-                else:
-                    x1a, y1a, x2a, y2a = xc, yc, min(xc + w, 2 * s), min(2 * s, yc + h)
-                    x1b, y1b = 0, 0
-                rec[16 + 8 * k : 24 + 8 * k] = (c.off[i], w, x1a, y1a, x2a, y2a, x1b, y1b)
-                tiles.append((b, i, x1a - x1b, y1a - y1b))
-            nt, cw, chh, border_arg = 4, 2 * s, 2 * s, -s // 2
-        else:
-            i = idx
-            h, w = int(c.h[i]), int(c.w[i])
-            top, left = (s - h) // 2, (s - w) // 2
-            rec[16:24] = (c.off[i], w, left, top, left + w, top + h, 0, 0)
-            tiles.append((b, i, left, top))
-            nt, cw, chh, border_arg = 1, s, s, 0
-        oh, ow = chh + 2 * border_arg, cw + 2 * border_arg
-        C = np.eye(3)
-        C[0, 2], C[1, 2] = -cw / 2, -chh / 2
-        sc = rng.uniform(1 - self.scale, 1 + self.scale)
-        R = np.diag([sc, sc, 1.0])
-        T = np.eye(3)
-        T[0, 2] = rng.uniform(0.5 - self.translate, 0.5 + self.translate) * ow
-        T[1, 2] = rng.uniform(0.5 - self.translate, 0.5 + self.translate) * oh
-        M = T @ R @ C
-        Mi = np.linalg.inv(np.vstack([M[:2], [0, 0, 1]]))
-        r = rng.uniform(-1, 1, 3) * list(self.hsv) + 1
-        flip = rng.random() < self.fliplr
-        recf[0:6] = (Mi[0, 0], Mi[0, 1], Mi[0, 2], Mi[1, 0], Mi[1, 1], Mi[1, 2])
-        recf[6] = r[2]
-        rec[7:13] = (int(flip), nt, cw, chh, D.PAD, D.PAD)
-        assert (oh, ow) == (s, s)
-        return M, sc, flip
-
-    def _plain(self, idx: int, rec: np.ndarray, tiles: list, b: int):
-        c, s = self.c, self.size
-        h, w = int(c.h[idx]), int(c.w[idx])
-        top, left = (s - h) // 2, (s - w) // 2
-        rec[16:24] = (c.off[idx], w, left, top, left + w, top + h, 0, 0)
-        tiles.append((b, idx, left, top))
-        recf = rec.view(np.float64)
-        recf[0:6] = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0)
-        recf[6] = 1.0
-        rec[7:13] = (0, 1, s, s, D.PAD, D.PAD)
-
     # ------------------------------------------------------------------ host part of a batch
-    def prepare(self, indices: Sequence[int], rng, mosaic: bool = True, augment: bool = True) -> Dict[str, np.ndarray]:
-        """Random draws + label geometry of a batch → host arrays (records, vertices, polygon table, ranges, labels)."""
+    def prepare(self, indices: Sequence[int], rng=None, mosaic: bool = True, augment: bool = True, draws: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
+        """Random draws (`data.draw_params`, or the given `draws`) + tile geometry + label geometry of a batch, all vectorised over the batch →
+        host arrays (records, vertices, polygon table, ranges, labels)."""
         c, s, B = self.c, self.size, len(indices)
+        idx = np.asarray(indices, np.int64)
         rec = np.zeros((B, REC), np.int64)
-        tiles: list = []
+        recf = rec.view(np.float64)
+        if augment and draws is None:
+            draws = D.draw_params(rng, B, c.n, mosaic, s, self.scale, self.translate, self.hsv, self.fliplr)
+        if augment and mosaic:
+            items = np.concatenate([idx[:, None], np.asarray(draws["others"], np.int64)], 1)  # [B,4]
+            x1a, y1a, x2a, y2a, x1b, y1b = D.mosaic_tiles(draws["xc"], draws["yc"], c.h[items], c.w[items], s)
+            nt, cw, chh = 4, 2 * s, 2 * s
+        else:
+            items = idx[:, None]
+            h, w = c.h[items], c.w[items]
+            y1a, x1a = (s - h) // 2, (s - w) // 2
+            x2a, y2a, x1b, y1b = x1a + w, y1a + h, np.zeros_like(w), np.zeros_like(h)
+            nt, cw, chh = 1, s, s
+        for k in range(nt):
+            rec[:, 16 + 8 * k : 24 + 8 * k] = np.stack([c.off[items[:, k]], c.w[items[:, k]], x1a[:, k], y1a[:, k], x2a[:, k], y2a[:, k], x1b[:, k], y1b[:, k]], 1)
+        t_b = np.repeat(np.arange(B), nt)
+        t_item = items.reshape(-1)
+        t_off = np.stack([(x1a - x1b).reshape(-1), (y1a - y1b).reshape(-1)], 1).astype(np.float32)
         Ms, scs, flips = np.zeros((B, 6)), np.ones(B), np.zeros(B, bool)
-        for b, idx in enumerate(indices):
-            if augment:
-                M, sc, fl = self._draw(int(idx), rng, mosaic, rec[b], tiles, b)
-                Ms[b] = (M[0, 0], M[0, 1], M[0, 2], M[1, 0], M[1, 1], M[1, 2])
-                scs[b], flips[b] = sc, fl
-            else:
-                self._plain(int(idx), rec[b], tiles, b)
-        t = np.asarray(tiles, np.int64).reshape(-1, 4)
-        t_b, t_item = t[:, 0], t[:, 1]
-        t_off = t[:, 2:4].astype(np.float32)
+        if augment:
+            scs = np.asarray(draws["scale"], np.float64)
+            m02, m12 = D.affine_coeffs(scs, np.asarray(draws["tx"]), np.asarray(draws["ty"]), cw, chh, s, s)
+            Ms = np.stack([scs, np.zeros(B), m02, np.zeros(B), scs, m12], 1)
+            recf[:, 0:6] = np.stack([1.0 / scs, np.zeros(B), -m02 / scs, np.zeros(B), 1.0 / scs, -m12 / scs], 1)
+            recf[:, 6] = np.asarray(draws["gain"])[:, 2]
+            flips = np.asarray(draws["flip"], bool)
+        else:
+            recf[:, 0], recf[:, 4], recf[:, 6] = 1.0, 1.0, 1.0
+        rec[:, 7], rec[:, 8], rec[:, 9], rec[:, 10], rec[:, 11], rec[:, 12] = flips.astype(np.int64), nt, cw, chh, D.PAD, D.PAD
         # polygons of every tile, vertices of every polygon (ragged gathers)
         p_cnt = c.item_off[t_item + 1] - c.item_off[t_item]
         pid = ragged_arange(c.item_off[t_item], p_cnt)
-        p_tile = np.repeat(np.arange(len(t)), p_cnt)
+        p_tile = np.repeat(np.arange(len(t_item)), p_cnt)
         v_cnt = c.poly_off[pid + 1] - c.poly_off[pid]
         vid = ragged_arange(c.poly_off[pid], v_cnt)
         v_poly = np.repeat(np.arange(len(pid)), v_cnt)
@@ -225,5 +184,5 @@ class DeviceAugmenter:
         hiplib.launch(hiplib.make_op(hiplib.OP_RASTER_MASKS, hiplib.MSL_F32, p=(pts.data_ptr(), poly.data_ptr(), ranges.data_ptr(), 0, masks.data_ptr()), i={0: B, 1: m, 2: m}), st)
         return {"img": img, "masks": masks, "gt": gt, "batch_idx": h["batch_idx"], "cls": h["cls"], "bboxes": h["bboxes"], "n_max": h["n_max"]}
 
-    def batch(self, indices, rng, mosaic: bool = True, augment: bool = True):
-        return self.render(self.prepare(indices, rng, mosaic, augment))
+    def batch(self, indices, rng=None, mosaic: bool = True, augment: bool = True, draws=None):
+        return self.render(self.prepare(indices, rng, mosaic, augment, draws))

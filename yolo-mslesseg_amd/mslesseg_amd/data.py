@@ -43,10 +43,12 @@ def fill_polygon(mask: np.ndarray, poly: np.ndarray, value) -> None:
                 mask[row, c0 : c1 + 1] = value
 
 
-def warp_affine(img: np.ndarray, M: np.ndarray, out_hw: Tuple[int, int], border: int = PAD) -> np.ndarray:
-    """dst(x,y) = src(M^-1 (x,y,1)) with bilinear sampling and constant border (cv2.warpAffine semantics)."""
+def warp_affine(img: np.ndarray, M: np.ndarray, out_hw: Tuple[int, int], border: int = PAD, Mi: Optional[np.ndarray] = None) -> np.ndarray:
+    """dst(x,y) = src(M^-1 (x,y,1)) with bilinear sampling and constant border (cv2.warpAffine semantics); `Mi` = the inverse when the caller
+    has it in closed form (the augmentation's scale + translate affine)."""
     h, w = out_hw
-    Mi = np.linalg.inv(np.vstack([M[:2], [0, 0, 1]]))
+    if Mi is None:
+        Mi = np.linalg.inv(np.vstack([M[:2], [0, 0, 1]]))
     xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
     sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
     sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
@@ -221,43 +223,72 @@ def _letterbox(img, inst, size):
     return out, [(c, p + np.array([left, top], np.float32)) for c, p in inst]
 
 
-def _mosaic(ds, idx, rng, size):
+# Random draws of a whole batch in one go (the device feeder prepares 128 slices per step: per-sample scalar draws and 3x3 matrix products cost
+# more host time than everything else it does).  Both paths — `augment` below and augment.DeviceAugmenter — consume the same record, so they see
+# the same numbers however those were generated.
+def draw_params(rng, B: int, n_ds: int, mosaic: bool, size: int = IMGSZ, scale: float = 0.5, translate: float = 0.1, hsv=(0.015, 0.7, 0.4),
+                fliplr: float = 0.5) -> Dict[str, np.ndarray]:
+    """Mosaic centre and the three extra slices [UPSTREAM Mosaic], RandomPerspective's scale and translation (degrees / shear / perspective are 0 in
+    the reference's runs), RandomHSV's gains, the flip decision [REF trains/Base/…/args.yaml:85-103]."""
+    d: Dict[str, np.ndarray] = {}
+    if mosaic:
+        c = rng.uniform(size // 2, 2 * size - size // 2, (B, 2)).astype(np.int64)  # int(random.uniform(-border, 2*s + border)) per axis
+        d["yc"], d["xc"] = c[:, 0], c[:, 1]
+        d["others"] = rng.integers(0, n_ds, (B, 3))
+    d["scale"] = rng.uniform(1 - scale, 1 + scale, B)
+    d["tx"] = rng.uniform(0.5 - translate, 0.5 + translate, B)
+    d["ty"] = rng.uniform(0.5 - translate, 0.5 + translate, B)
+    d["gain"] = rng.uniform(-1, 1, (B, 3)) * np.asarray(hsv) + 1  # (h, s, v): grey input only feels the value gain
+    d["flip"] = rng.random(B) < fliplr
+    return d
+
+
+def draw_row(d: Dict[str, np.ndarray], b: int) -> Dict:
+    return {k: v[b] for k, v in d.items()}
+
+
+def affine_coeffs(sc, tx, ty, cw, ch, ow, oh):
+    """M = T(tx*ow, ty*oh) . S(sc) . T(-cw/2, -ch/2) in closed form → (m02, m12) of M = [[sc, 0, m02], [0, sc, m12]]; scalars or arrays.
+    Its inverse is [[1/sc, 0, -m02/sc], [0, 1/sc, -m12/sc]]."""
+    return tx * ow - sc * (cw / 2), ty * oh - sc * (ch / 2)
+
+
+def mosaic_tiles(xc, yc, hs, ws, size):
+    """Placement of the four slices around the mosaic centre [UPSTREAM Mosaic._mosaic4]: per slice k the canvas rectangle (x1a, y1a, x2a, y2a) and
+    the source origin (x1b, y1b); `hs`, `ws` [..., 4]; works on scalars-with-a-last-axis or on [B, 4] arrays."""
+    s2 = 2 * size
+    xc, yc = np.asarray(xc)[..., None], np.asarray(yc)[..., None]
+    h, w = np.asarray(hs), np.asarray(ws)
+    left, top = np.array([1, 0, 1, 0], bool), np.array([1, 1, 0, 0], bool)  # k = 0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right
+    x1a = np.where(left, np.maximum(xc - w, 0), xc)
+    x2a = np.where(left, xc, np.minimum(xc + w, s2))
+    y1a = np.where(top, np.maximum(yc - h, 0), yc)
+    y2a = np.where(top, yc, np.minimum(yc + h, s2))
+    x1b = np.where(left, w - (x2a - x1a), 0)
+    y1b = np.where(top, h - (y2a - y1a), 0)
+    return x1a, y1a, x2a, y2a, x1b, y1b
+
+
+def _mosaic(ds, idx, dr, size):
     s = size
-    yc, xc = (int(rng.uniform(s // 2, 2 * s - s // 2)) for _ in range(2))
     canvas = np.full((2 * s, 2 * s, 3), PAD, np.uint8)
+    items = [ds.get(i) for i in [idx] + [int(i) for i in dr["others"]]]
+    x1a, y1a, x2a, y2a, x1b, y1b = mosaic_tiles(dr["xc"], dr["yc"], [im.shape[0] for im, _ in items], [im.shape[1] for im, _ in items], s)
     inst_all = []
-    for k, i in enumerate([idx] + [int(rng.integers(0, len(ds))) for _ in range(3)]):
-        img, inst = ds.get(i)
-        h, w = img.shape[:2]
-        if k == 0:
-            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
-            x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
-        elif k == 1:
-            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, 2 * s), yc
-            x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
-        elif k == 2:
-            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(2 * s, yc + h)
-            x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
-        else:
-            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, 2 * s), min(2 * s, yc + h)
-            x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
-        canvas[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
-        off = np.array([x1a - x1b, y1a - y1b], np.float32)
+    for k, (img, inst) in enumerate(items):
+        canvas[y1a[k] : y2a[k], x1a[k] : x2a[k]] = img[y1b[k] : y1b[k] + (y2a[k] - y1a[k]), x1b[k] : x1b[k] + (x2a[k] - x1a[k])]
+        off = np.array([x1a[k] - x1b[k], y1a[k] - y1b[k]], np.float32)
         inst_all += [(c, p + off) for c, p in inst]
     return canvas, inst_all
 
 
-def _random_affine(img, inst, rng, size, border, scale=0.5, translate=0.1):
+def _random_affine(img, inst, dr, size, border):
     h, w = img.shape[0] + 2 * border, img.shape[1] + 2 * border  # output size
-    C = np.eye(3)
-    C[0, 2], C[1, 2] = -img.shape[1] / 2, -img.shape[0] / 2
-    s = rng.uniform(1 - scale, 1 + scale)
-    R = np.diag([s, s, 1.0])
-    T = np.eye(3)
-    T[0, 2] = rng.uniform(0.5 - translate, 0.5 + translate) * w
-    T[1, 2] = rng.uniform(0.5 - translate, 0.5 + translate) * h
-    M = T @ R @ C
-    out = warp_affine(img, M[:2], (h, w))
+    s = float(dr["scale"])
+    m02, m12 = affine_coeffs(s, float(dr["tx"]), float(dr["ty"]), img.shape[1], img.shape[0], w, h)
+    M = np.array([[s, 0.0, m02], [0.0, s, m12], [0.0, 0.0, 1.0]])
+    Mi = np.array([[1.0 / s, 0.0, -m02 / s], [0.0, 1.0 / s, -m12 / s], [0.0, 0.0, 1.0]])
+    out = warp_affine(img, M[:2], (h, w), Mi=Mi)
     return out, warp_instances(inst, M, s, w, h)
 
 
@@ -273,24 +304,25 @@ def warp_instances(inst, M, s, w, h):
     return [(c, q[off[i] : off[i + 1]]) for i, (c, _) in enumerate(inst) if keep[i]]
 
 
-def _hsv(img, rng, hgain=0.015, sgain=0.7, vgain=0.4):
+def _hsv(img, gain_v):
     """RandomHSV on grey-looking RGB input: hue/saturation gains act on (near-)zero saturation, so only the value
     gain changes pixels; apply it as the same LUT upstream builds for V."""
-    r = rng.uniform(-1, 1, 3) * [hgain, sgain, vgain] + 1
-    lut = np.clip(np.arange(256) * r[2], 0, 255).astype(np.uint8)
+    lut = np.clip(np.arange(256) * gain_v, 0, 255).astype(np.uint8)
     return lut[img]
 
 
-def augment(ds, idx, rng, mosaic: bool, size: int = IMGSZ):
+def augment(ds, idx, rng, mosaic: bool, size: int = IMGSZ, draws: Optional[Dict] = None):
+    """One training sample: mosaic (or letterbox) → scale/translate warp → value gain → flip.  `draws` = one row of `draw_params` (else drawn here)."""
+    dr = draws if draws is not None else draw_row(draw_params(rng, 1, len(ds), mosaic, size), 0)
     if mosaic:
-        img, inst = _mosaic(ds, idx, rng, size)
-        img, inst = _random_affine(img, inst, rng, size, border=-size // 2)
+        img, inst = _mosaic(ds, idx, dr, size)
+        img, inst = _random_affine(img, inst, dr, size, border=-size // 2)
     else:
         img, inst = ds.get(idx)
         img, inst = _letterbox(img, inst, size)
-        img, inst = _random_affine(img, inst, rng, size, border=0)
-    img = _hsv(img, rng)
-    if rng.random() < 0.5:
+        img, inst = _random_affine(img, inst, dr, size, border=0)
+    img = _hsv(img, dr["gain"][2])
+    if dr["flip"]:
         img = img[:, ::-1]
         inst = [(c, np.stack([size - p[:, 0], p[:, 1]], 1)) for c, p in inst]
     return np.ascontiguousarray(img), inst
