@@ -64,6 +64,11 @@ CONV_CASES = [
     (1, 30, 30, 32, 64, 1, 1, 32, 0, 64, 0, 0, 0, 1),      # fp32 output (box head)
     (1, 20, 20, 128, 96, 1, 1, 128, 0, 96, 0, 1, 0, 0),
     (2, 20, 20, 384, 128, 1, 1, 384, 0, 128, 0, 1, 0, 0),  # too wide for LDS → generic kernel
+    # YOLO11s-seg widths (BASELINE configs[2])
+    (1, 20, 20, 768, 256, 1, 1, 768, 0, 256, 0, 1, 0, 0),    # model.13.cv1 at scale s: K = 768 from the neck concat
+    (1, 10, 10, 1024, 512, 1, 1, 1024, 0, 512, 0, 1, 0, 0),  # SPPF.cv2 at scale s: K = 1024, Cout = 512 (2 x 256)
+    (1, 12, 12, 256, 512, 1, 1, 512, 256, 512, 0, 0, 0, 0),  # PSA qkv at scale s (4 heads) from a concat slice
+    (2, 16, 16, 512, 512, 1, 1, 512, 0, 768, 256, 1, 1, 0),  # C2PSA.cv1 at scale s into a concat slice with residual
 ]
 
 
@@ -116,6 +121,12 @@ LDS3_CASES = [
     (1, 20, 20, 8, 32, 2, 8, 0, 32, 0, 0, 0, 1),         # stride 2, fp32 output
     (2, 30, 45, 16, 8, 1, 16, 0, 8, 0, 1, 0, 0),         # Cout = 8: one 16-row block, upper half zero (C3k2 bottleneck of the 160² level)
     (1, 17, 33, 32, 8, 1, 32, 0, 24, 8, 1, 1, 0),        # Cout = 8 into a concat slice with residual
+    # YOLO11s-seg widths (BASELINE configs[2]): 4 / 8 / 16 channel chunks, 2-8 output blocks
+    (1, 24, 40, 128, 128, 1, 128, 0, 128, 0, 1, 1, 0),   # proto.cv2 / bottlenecks at scale s
+    (1, 20, 20, 256, 256, 2, 256, 0, 256, 0, 1, 0, 0),   # model.5 at scale s
+    (1, 10, 12, 512, 512, 2, 512, 0, 512, 0, 1, 0, 0),   # model.7 at scale s
+    (2, 16, 40, 128, 64, 1, 128, 0, 64, 0, 1, 0, 0),     # box head first conv at scale s
+    (1, 16, 24, 128, 32, 1, 128, 0, 32, 0, 1, 0, 0),     # mask-coefficient head first conv at scale s
 ]
 
 
@@ -375,6 +386,13 @@ WGRAD_CASES = [
     (4, 96, 96, 32, 16, 2, 2, 32, 0, 16, 0),
     (2, 40, 40, 64, 1, 1, 1, 64, 0, 8, 0),        # the nc=1 class head: one output channel in an 8-wide gradient buffer
     (2, 20, 20, 64, 3, 1, 1, 64, 0, 8, 0),
+    # YOLO11s-seg widths (BASELINE configs[2])
+    (1, 24, 24, 128, 128, 3, 1, 128, 0, 128, 0),
+    (1, 20, 20, 256, 256, 3, 1, 256, 0, 256, 0),
+    (1, 12, 12, 512, 512, 3, 2, 512, 0, 512, 0),
+    (1, 20, 20, 768, 256, 1, 1, 768, 0, 256, 0),
+    (1, 16, 16, 1024, 512, 1, 1, 1024, 0, 512, 0),
+    (2, 24, 40, 128, 128, 2, 2, 128, 0, 128, 0),  # ConvTranspose2d weight gradient at scale s
 ]
 
 
@@ -525,7 +543,8 @@ def test_stride2_input_gradient_parity_classes_lds_kernel(case):
     _close(gx.cpu(), ref, dtype, f"s2 dgrad (LDS kernel) {case}")
 
 
-@pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1), (2, 70, 41, 64, 64, 1), (1, 33, 66, 8, 32, 0), (3, 40, 40, 16, 32, 1)])
+@pytest.mark.parametrize("case", [(2, 16, 24, 32, 64, 0), (1, 21, 35, 16, 32, 1), (2, 8, 8, 128, 128, 1), (2, 70, 41, 64, 64, 1), (1, 33, 66, 8, 32, 0), (3, 40, 40, 16, 32, 1),
+                                  (1, 20, 20, 256, 256, 1), (1, 12, 10, 512, 512, 0), (2, 24, 24, 32, 64, 0)])  # the last three: stride-2 layers at scale s
 def test_stride2_input_gradient_all_classes_one_pass(case):
     """MSL_OP_CONV store mode 3: the whole 3x3 / stride-2 / pad-1 input gradient (four parity classes) in one launch of the LDS-tiled kernel
     (weights = 3x3 LDS image of the transposed weight, at most two channel tiles), with and without accumulation into the gradient view."""
