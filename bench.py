@@ -281,6 +281,9 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             if rec.get("kernel") == kname and rec.get("launch_shape") == roof["launch_shape"]:
                 roof["traffic"] = rec["traffic_bytes_per_launch"]
                 roof["traffic_note"] = rec.get("note", "")
+                if rec.get("mfma_util") is not None:  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of the same replayed launches
+                    roof["mfma_util"] = round(rec["mfma_util"], 4)
+                    roof["mfma_util_counters"] = {k: rec["sq"][k] for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "kernel_cycles") if k in rec["sq"]}
                 roof["traffic_source"] = "profiles/pmc_latest.json: a committed rocprofv3 --pmc summary of an earlier run of this kernel and shape (scripts/pmc_traffic.py), not collected in this run"
     if args.replay_dominant > 0:  # for the PMC passes: the three longest MFMA launches, each alone and back to back, as the LAST dispatches of the process
         s_ = torch.cuda.current_stream(tr.device).cuda_stream

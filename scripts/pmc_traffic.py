@@ -19,8 +19,13 @@ ROOT = Path(__file__).resolve().parents[1]
 K = 5
 
 
+SQ_PASS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+           "GRBM_GUI_ACTIVE"]  # 8 SQ slots + 1 GRBM slot (/opt/skills/guides/MI355X_MICROARCH.md §rocprofv3 PMC slots)
+
+
 def one_pass(counter, outdir):
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", str(outdir), "-o", counter.lower(), "--",
+    names = counter.split()
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", *names, "--output-format", "csv", "-d", str(outdir), "-o", names[0].lower(), "--",
            "python3", str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--no-infer", "--no-cpu-baseline", "--replay-dominant", str(K)]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
@@ -31,6 +36,37 @@ def one_pass(counter, outdir):
     if not files:
         sys.exit(f"no counter_collection.csv under {outdir}")
     return json.loads(line[-1]), list(csv.DictReader(open(files[0])))
+
+
+def sq_pass(out):
+    """Third pass: the issue / stall / matrix-core counters of the same replayed launches → per record a dict of per-launch means and
+    mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs)."""
+    bench, rows = one_pass(" ".join(SQ_PASS), out / "SQ")
+    replay = bench["roofline"]["replay"]
+    by_disp = {}
+    for r in rows:
+        by_disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "grid": r["Grid_Size"]})[r["Counter_Name"]] = float(r["Counter_Value"])
+    disp = [by_disp[k] for k in sorted(by_disp)]
+    sent = [i for i, d in enumerate(disp) if "ema_kernel" in d["name"]]
+    if len(sent) < len(replay):
+        sys.exit(f"SQ pass: {len(sent)} sentinel dispatches for {len(replay)} replayed records")
+    cuts = sent[-len(replay):] + [len(disp)]
+    found = {}
+    for j, rp in enumerate(replay):
+        groups = {}
+        for d in disp[cuts[j] + 1 : cuts[j + 1]]:
+            groups.setdefault((d["name"], d["grid"]), []).append(d)
+        full = {k: v for k, v in groups.items() if len(v) % K == 0}
+        if not full:
+            continue
+        (name, grid), ds = max(full.items(), key=lambda kv: sum(d.get("SQ_WAVE_CYCLES", 0.0) for d in kv[1]))
+        mean = {c: sum(d.get(c, 0.0) for d in ds) / len(ds) for c in SQ_PASS}
+        cyc = mean["GRBM_GUI_ACTIVE"] / 8.0
+        mean["kernel_cycles"] = cyc
+        mean["mfma_util"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc > 0 else None
+        mean["dispatch_kernel_name"] = name
+        found[(rp["kernel"], json.dumps(rp["launch_shape"], sort_keys=True))] = mean
+    return found
 
 
 def main():
@@ -64,6 +100,7 @@ def main():
             found[key] = (sum(vals) / K * 1024.0, name, grid, rp, {k: sum(v) / K * 1024.0 for k, v in full.items()})
         per_counter[counter] = found
         order = order or list(found)
+    sq = sq_pass(out)
     records = []
     for key in order:
         if key not in per_counter["WRITE_SIZE"]:
@@ -75,7 +112,8 @@ def main():
         write = wgroups[(name, grid)]
         records.append({"kernel": rp["kernel"], "launch_shape": rp["launch_shape"], "traffic_bytes_per_launch": round(2.0 * fetch + write),
                         "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write), "dispatch_kernel_name": name, "grid_size": grid,
-                        "note": "rocprofv3 --pmc, two passes, mean of 5 replayed launches; FETCH_SIZE doubled (gfx950), both counters KiB -> bytes"})
+                        "note": "rocprofv3 --pmc, two passes, mean of 5 replayed launches; FETCH_SIZE doubled (gfx950), both counters KiB -> bytes",
+                        "sq": sq.get(key), "mfma_util": (sq.get(key) or {}).get("mfma_util")})
     doc = {"records": records}
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
     for dst in (ROOT / "profiles" / "pmc_latest.json", ROOT / "gpurun_out" / "pmc_latest.json"):

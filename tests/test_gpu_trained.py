@@ -161,6 +161,7 @@ def test_bf16_train_step_against_the_fp32_engine_on_trained_weights(trained_stat
         assert np.isfinite(items).all()
     (i32, g32, store), (i16, g16, _) = out["fp32"], out["bf16"]
     rel_items = np.abs(i16 - i32) / np.abs(i32)
+    g16, g32 = g16.double(), g32.double()
     cos = float((g16 @ g32) / (g16.norm() * g32.norm()))
     rel = float((g16 - g32).norm() / g32.norm())
     per = []
@@ -171,9 +172,10 @@ def test_bf16_train_step_against_the_fp32_engine_on_trained_weights(trained_stat
             per.append((float((a @ b) / (a.norm() * b.norm() + 1e-30)), key))
     per.sort()
     print(f"bf16 vs fp32 train step on trained weights: loss items rel err {rel_items}, flat gradient cosine {cos:.5f} rel L2 {rel:.4f}, worst tensors {per[:4]}")
+    # measured (r02f): loss items within 4e-3, flat gradient rel L2 1.6 %, worst tensor cosine 0.964
     assert rel_items.max() < 2e-2
-    assert cos > 0.98 and rel < 0.2
-    assert per[0][0] > 0.8, per[:6]
+    assert cos > 0.999 and rel < 0.05
+    assert per[0][0] > 0.9, per[:6]
 
 
 def test_predict_variants_mixed_work_list_equals_single_variant_runs(trained_state, demo_volumes, golden_dir, tmp_path):
