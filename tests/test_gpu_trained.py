@@ -1,15 +1,15 @@
 """Parity on a TRAINED network and real FLAIR slices (-m gpu): the checkpoint tests/golden/demo_p39_n.pt was trained by this library's own
-trainer on the lesion slices of the reference's demo patient P39 (scripts/train_demo_checkpoint.py; 60 epochs, bf16 train engine, every
-5th slice held out; weights stored bf16-exact) and is the well-conditioned counterpart of the calibrated-random test weights.
+trainer on the lesion slices of the reference's demo patient P39 (scripts/train_demo_checkpoint.py; 80 epochs, mosaic augmentation from the
+device feeder, bf16 train engine, every 5th slice held out: mask mAP50 0.75 on those; weights stored bf16-exact) and is the well-conditioned counterpart of the calibrated-random test weights.
 
 north_star tolerance (BASELINE.json): bit-exact indices after NMS, reconstructed-volume Dice within 1e-4 of the CPU reference.
   * fp32 engine (the default of `YOLO()` predict, = the reference's half=False): identical ordered kept-index lists on every slice, identical
     output bytes, |dDice| <= 1e-4 per plane volume and for the 3-plane consensus  -> asserted at exactly that tolerance.
   * bf16 engine (opt-in throughput mode): bf16 storage rounds every activation to 8 significant bits (measured 0.2-0.5 % relative L2 at every
     tap of this network, no growth with depth), which moves near-threshold scores and mask-boundary logits: measured on all 361 lesion slices
-    (profiles/r02a_precision_trained_p39.json) 303 identical kept lists, 699 of 13.4 M output bytes differ, |dDice| 9.7e-4 / 1.4e-4 / 4.4e-5
-    per plane, 3.8e-5 for the consensus.  It does NOT meet the 1e-4 tolerance per plane; the bounds asserted here are those measured ones
-    with headroom, and DESIGN.md says so.
+    (profiles/r02g_precision_trained_p39.json) 333 identical kept lists, 644 of 13.4 M output bytes differ, |dDice| 4.1e-4 / 1.9e-4 / 1.1e-3
+    per plane, 2.0e-4 for the consensus.  It does NOT meet the 1e-4 tolerance; the bounds asserted here are those measured ones with headroom
+    (this test predicts every 3rd slice only, which makes the Dice of the partial volumes more sensitive: up to 2.4e-3), and DESIGN.md says so.
 The oracle's model arithmetic restates ultralytics 8.3.70 (parity unpinned against the reference itself)."""
 import numpy as np
 import pytest
@@ -108,10 +108,10 @@ def test_bf16_engine_measured_deviation_on_trained_weights(trained_state, oracle
         print(f"bf16 {plano}: {r['same_list']}/{r['n']} identical kept lists, {r['same_set']} identical sets, {r['px']} of {r['total']} bytes differ, |dDice| {dd:.2e}")
         assert r["same_set"] >= 0.8 * r["n"] and r["same_list"] >= 0.6 * r["n"]
         assert r["px"] <= 3e-4 * r["total"]
-        assert dd <= 3e-3, "bf16 is the throughput mode: bounded, not at the 1e-4 tolerance (module docstring)"
+        assert dd <= 5e-3, "bf16 is the throughput mode: bounded, not at the 1e-4 tolerance (module docstring)"
     cons = P.combinar_volumenes(res["axial"]["vol"], res["coronal"]["vol"], res["sagital"]["vol"], 2)
     cons_o = P.combinar_volumenes(oracle_run["axial"]["vol"], oracle_run["coronal"]["vol"], oracle_run["sagital"]["vol"], 2)
-    assert abs(P.dsc_unrounded(gt, cons) - P.dsc_unrounded(gt, cons_o)) <= 1e-3
+    assert abs(P.dsc_unrounded(gt, cons) - P.dsc_unrounded(gt, cons_o)) <= 3e-3
 
 
 def test_default_yolo_predicts_in_fp32_and_whole_volume_dice_on_device(trained_state, oracle_run, demo_volumes, tmp_path, monkeypatch):

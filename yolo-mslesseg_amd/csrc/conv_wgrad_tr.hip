@@ -48,11 +48,7 @@ struct WgCfg {
   static constexpr int ROWS = S == 1 ? TH + KD - 1 : 2 * TH + KD - 2;
   static constexpr int Z_SLOTS = TH * TW, X_SLOTS = ROWS * ROWP;
   static constexpr int Z_PIECES = (Z_SLOTS * CPZ + 63) / 64, X_PIECES = (X_SLOTS * CPX + 63) / 64;
-  // every wave issues the same number of LDS-DMA loads per staged tile (pieces rounded up to a multiple of the 8 waves; the surplus ones land in one
-  // spare KB), so that `s_waitcnt vmcnt(LOADS)` means "everything but the newest stage has arrived" — the handle of the 3-deep pipeline below
-  static constexpr int Z_PP = (Z_PIECES + 7) / 8 * 8, X_PP = (X_PIECES + 7) / 8 * 8, LOADS = (Z_PP + X_PP) / 8;
-  static constexpr int BUF = (Z_PIECES + X_PIECES + 1) * 1024;
-  static constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;  // tiles resident in LDS: one being multiplied, NBUF-1 in flight
+  static constexpr int BUF = (Z_PIECES + X_PIECES) * 1024;
   static constexpr int COT = (ZC + 1) / 2, CIT = (XC + 1) / 2;  // 16-channel tiles of the block
   static constexpr int TCO0 = COT >= 2 ? 2 : 1, TCI0 = CIT >= 2 ? 2 : 1;
   static constexpr int TCO = ((COT / TCO0) * (CIT / TCI0) * TH >= 8) ? TCO0 : 1;  // give up register blocking before idling waves
@@ -101,10 +97,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       n = (int)(tq / a.tiles_x);
       oy0 = tyi * TH; ox0 = txi * TW;
     }
-    unsigned char* s_spare = buf + (C::Z_PIECES + C::X_PIECES) * 1024;
-    for (int pc = wave; pc < C::Z_PP; pc += 8) {
+    for (int pc = wave; pc < C::Z_PIECES; pc += 8) {
       const int cidx = pc * 64 + lane, slot = cidx / C::CPZ, ch = cidx - slot * C::CPZ;
-      bool ok = pc < C::Z_PIECES && slot < C::Z_SLOTS && ch < ZC && cob * 64 + ch * 8 < a.Cout;
+      bool ok = slot < C::Z_SLOTS && ch < ZC && cob * 64 + ch * 8 < a.Cout;
       long pix;
       if constexpr (TAPS == 1) {
         pix = p0 + slot;
@@ -115,11 +110,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
         pix = ((long)n * a.Ho + oy) * a.Wo + ox;
       }
       const char* src = ok ? a.dz + (pix * a.z_cs + a.z_co + cob * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(pc < C::Z_PIECES ? s_z + pc * 1024 : s_spare), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_z + pc * 1024), 16, 0, 0);
     }
-    for (int pc = wave; pc < C::X_PP; pc += 8) {
+    for (int pc = wave; pc < C::X_PIECES; pc += 8) {
       const int cidx = pc * 64 + lane, slot = cidx / C::CPX, ch = cidx - slot * C::CPX;
-      bool ok = pc < C::X_PIECES && slot < C::X_SLOTS && ch < XC && cib * 64 + ch * 8 < a.Cin;
+      bool ok = slot < C::X_SLOTS && ch < XC && cib * 64 + ch * 8 < a.Cin;
       long pix;
       if constexpr (TAPS == 1) {
         pix = p0 + slot;
@@ -133,7 +128,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
         pix = ((long)n * a.H + iy) * a.W + ix;
       }
       const char* src = ok ? a.x + (pix * a.x_cs + a.x_co + cib * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(pc < C::X_PIECES ? s_x + pc * 1024 : s_spare), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_x + pc * 1024), 16, 0, 0);
     }
   };
 
@@ -200,37 +195,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
   long tile_end = tile0 + a.tiles_per_block;
   if (tile_end > a.total_tiles) tile_end = a.total_tiles;
   if (tile0 < tile_end) {
-    // NBUF-deep pipeline: while tile i is multiplied, the LDS-DMA of tiles i+1 .. i+NBUF-1 is in flight.  One staged tile is ~47 KB per CU; a single
-    // tile in flight (the double-buffered form) leaves the kernel latency-bound at ~2.5 TB/s — this layer sits on the roofline ridge (288 FLOP/B).
     stage(tile0, smem);
-    if constexpr (C::NBUF == 3) {
-      if (tile0 + 1 < tile_end) {
-        stage(tile0 + 1, smem + C::BUF);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LOADS) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (long tile = tile0; tile < tile_end; ++tile) {  // block-uniform trip count
-      const int nxt = cur + 1 == C::NBUF ? 0 : cur + 1;
-      if constexpr (C::NBUF == 3) {
-        const int nx2 = nxt + 1 == 3 ? 0 : nxt + 1;
-        const bool more = tile + 2 < tile_end;
-        if (more) stage(tile + 2, smem + nx2 * C::BUF);
-        if (wave_active) compute(smem + cur * C::BUF);
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LOADS) : "memory");  // tile+1 has landed, tile+2 may still be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        if (tile + 1 < tile_end) stage(tile + 1, smem + nxt * C::BUF);
-        if (wave_active) compute(smem + cur * C::BUF);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (tile + 1 < tile_end) stage(tile + 1, smem + (cur ^ 1) * C::BUF);
+      if (wave_active) compute(smem + cur * C::BUF);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      cur = nxt;
+      cur ^= 1;
     }
   }
   // ---- waves that split the tile rows hold partial sums of the same outputs: fold them into wave row 0 through LDS
@@ -339,7 +313,7 @@ template <int TAPS, int S, int ZC, int XC>
 static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
   typedef WgCfg<TAPS, S, ZC, XC> C;
   constexpr int RED = (C::WR - 1) * C::WCO * C::WCI * (TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1)) * C::TCO * C::TCI * 4 * 256;  // cross-wave fold
-  constexpr int LDS = C::NBUF * C::BUF > RED ? C::NBUF * C::BUF : RED;
+  constexpr int LDS = 2 * C::BUF > RED ? 2 * C::BUF : RED;
   static_assert(LDS <= 160 * 1024, "tile does not fit in LDS twice");
   static bool attr = false;
   if (!attr) {

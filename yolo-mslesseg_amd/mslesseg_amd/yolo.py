@@ -104,7 +104,7 @@ class YOLO:
         """`precision` (or MSLESSEG_PRECISION): arithmetic of predict — default **fp32**, what the reference's `model(img)` runs (ultralytics
         predict, half=False) and the engine that reproduces the CPU path exactly (identical NMS indices, identical mask bytes on the trained demo
         checkpoint: tests/test_gpu_trained.py); "bf16" is the opt-in throughput mode (~3x the slices/s; |dDice| up to 1e-3 per plane volume,
-        profiles/r02a_precision_trained_p39.json).  `train_precision` (or MSLESSEG_TRAIN_PRECISION): arithmetic of `.train()` — default
+        profiles/r02g_precision_trained_p39.json).  `train_precision` (or MSLESSEG_TRAIN_PRECISION): arithmetic of `.train()` — default
         **bf16** compute with fp32 master weights, the MI355X counterpart of the reference's `amp: true` [REF …/args.yaml:28].  An explicit
         `precision=` sets both unless `train_precision=` is given too."""
         self.ckpt_path = Path(model)
