@@ -84,8 +84,9 @@ int msl_launch_head_decode(const msl_op& op, hipStream_t s) {
 //   1. candidates = anchors with conf > conf_thres                      [UPSTREAM ops.non_max_suppression]
 //   2. bitonic sort in LDS on key = (conf bits << 32 | ~anchor): score descending, ties by lower anchor index —
 //      the order of torchvision's stable descending sort                 [UPSTREAM torchvision ops.nms CPU kernel]
-//   3. greedy: the next unsuppressed candidate is kept; all threads test the rest against it (IoU > thr suppresses);
-//      stops after max_det keeps (== nms(...)[:max_det]).
+//   3. greedy suppression (IoU > thr against an earlier kept box) in blocks of 64 candidates: pair tests spread over the workgroup, the per-row
+//      reduction a wave shuffle butterfly, the in-block resolution a ballot + readlane walk inside one wave; stops after max_det keeps
+//      (== nms(...)[:max_det]).
 // ---------------------------------------------------------------------------------------------------------
 #define NMS_CAP 16384
 __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ pred, int* __restrict__ keep_idx, int* __restrict__ keep_cnt,
@@ -126,41 +127,118 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ pre
       __syncthreads();
     }
   }
-  // greedy suppression
-  int kept = 0;
-  for (int i = 0; i < count && kept < max_det; ++i) {
-    if (supp[i]) continue;  // uniform: every thread reads the same byte, written before the last barrier
-    const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
-    const float* bi = P + (long)ai * MSL_PRED_STRIDE;
-    if (tid == 0) keep_idx[(long)n * max_det + kept] = ai;
-    if (tid < MSL_PRED_STRIDE) {
-      float v = bi[tid];
-      if (tid < 4) {  // xywh2xyxy
-        float c0 = bi[tid & 1], hw = bi[2 + (tid & 1)] / 2.f;
-        v = tid < 2 ? c0 - hw : c0 + hw;
+  // greedy suppression in blocks of 64 sorted candidates — the result is that of the one-box-at-a-time loop (a box is dropped iff an EARLIER KEPT box
+  // overlaps it by more than the threshold), but the workgroup meets at three barriers per 64 candidates instead of one per kept box:
+  //   A  every wave: the block's 64 x 64 suppression relation, 4 pair tests per thread; the 16 lanes of a row OR their bits with a shuffle
+  //      butterfly (xor 1, 2, 4, 8 inside the row) and lane 0 of the row publishes the 64-bit row mask
+  //   B  wave 0: lane l = candidate l; a ballot gives the alive set, a scalar walk over the 64 bits reads each kept lane's row mask with a
+  //      wave broadcast (readlane) — no LDS traffic and no barrier inside the block; kept lanes write their output rows
+  //   C  every thread: the block's kept boxes (<= 64, in LDS) against all later candidates
+  float4* kbox = (float4*)(smem + (size_t)NMS_CAP * 9);      // 64 kept / block boxes (xyxy)
+  float* karea = (float*)(kbox + 64);                         // 64 areas
+  unsigned long long* rowmask = (unsigned long long*)(karea + 64);  // 64 row masks
+  __shared__ int s_nk, s_kept;
+  if (tid == 0) s_kept = 0;
+  const int lane = tid & 63;
+  for (int b0 = 0; b0 < count; b0 += 64) {
+    const int nb = min(64, count - b0);
+    __syncthreads();  // previous block's phase C (and the sort) are complete
+    if (tid < 64) {
+      float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+      float ar = 0.f;
+      if (tid < nb) {
+        const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[b0 + tid] & 0xFFFFFFFFull));
+        const float4 q = *(const float4*)(P + (long)ai * MSL_PRED_STRIDE);
+        const float w2 = q.z / 2.f, h2 = q.w / 2.f;
+        bx = make_float4(q.x - w2, q.y - h2, q.x + w2, q.y + h2);
+        ar = (bx.z - bx.x) * (bx.w - bx.y);
       }
-      det[((long)n * max_det + kept) * MSL_PRED_STRIDE + tid] = v;
-    }
-    ++kept;
-    const float iw2 = bi[2] / 2.f, ih2 = bi[3] / 2.f;
-    const float ix1 = bi[0] - iw2, iy1 = bi[1] - ih2, ix2 = bi[0] + iw2, iy2 = bi[1] + ih2;
-    const float iarea = (ix2 - ix1) * (iy2 - iy1);
-    for (int j = i + 1 + tid; j < count; j += 1024) {
-      if (supp[j]) continue;
-      const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
-      const float4 bj = *(const float4*)(P + (long)aj * MSL_PRED_STRIDE);
-      const float jw2 = bj.z / 2.f, jh2 = bj.w / 2.f;
-      const float jx1 = bj.x - jw2, jy1 = bj.y - jh2, jx2 = bj.x + jw2, jy2 = bj.y + jh2;
-      const float jarea = (jx2 - jx1) * (jy2 - jy1);
-      const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1), xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
-      const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-      const float inter = w * h;
-      const float ovr = inter / (iarea + jarea - inter);
-      if (ovr > iou_thres) supp[j] = 1;
+      kbox[tid] = bx;
+      karea[tid] = ar;
     }
     __syncthreads();
+    {  // ---- A: row l = tid / 16 (earlier box), columns 4 * (tid % 16) .. + 3 (later boxes)
+      const int l = tid >> 4, m0 = (tid & 15) * 4;
+      const float4 bi = kbox[l];
+      const float iarea = karea[l];
+      unsigned long long bits = 0ull;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + e;
+        if (m > l && m < nb && l < nb) {
+          const float4 bj = kbox[m];
+          const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y), xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+          const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+          const float inter = w * h;
+          const float ovr = inter / (iarea + karea[m] - inter);
+          if (ovr > iou_thres) bits |= 1ull << m;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) bits |= __shfl_xor(bits, off);  // the 16 lanes of a row sit in one wave
+      if ((tid & 15) == 0) rowmask[l] = bits;
+    }
+    __syncthreads();
+    if (tid < 64) {  // ---- B: wave 0 resolves the block
+      const bool alive = lane < nb && !supp[b0 + lane];
+      const unsigned long long mine = rowmask[lane];
+      const unsigned long long alive_bits = __ballot(alive);
+      unsigned long long removed = 0ull, keepbits = 0ull;
+      int room = max_det - s_kept;
+      for (int l = 0; l < nb && room > 0; ++l) {
+        const unsigned long long row = __shfl(mine, l);  // wave-uniform: a readlane broadcast
+        if (((alive_bits >> l) & 1ull) && !((removed >> l) & 1ull)) {
+          keepbits |= 1ull << l;
+          removed |= row;
+          --room;
+        }
+      }
+      const int before = s_kept;
+      const int nk = __popcll(keepbits);
+      if ((keepbits >> lane) & 1ull) {
+        const int pos = before + __popcll(keepbits & ((1ull << lane) - 1ull));
+        const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[b0 + lane] & 0xFFFFFFFFull));
+        const float* bi = P + (long)ai * MSL_PRED_STRIDE;
+        keep_idx[(long)n * max_det + pos] = ai;
+        float* drow = det + ((long)n * max_det + pos) * MSL_PRED_STRIDE;
+        const float4 bx = kbox[lane];
+        drow[0] = bx.x; drow[1] = bx.y; drow[2] = bx.z; drow[3] = bx.w;  // xywh2xyxy, the same expressions as the suppression test
+        for (int c = 4; c < MSL_PRED_STRIDE; ++c) drow[c] = bi[c];
+      }
+      // compact the kept boxes to the front for phase C (lanes read their own entry before anyone overwrites it: same wave, lockstep)
+      const float4 mybox = kbox[lane];
+      const float myarea = karea[lane];
+      if ((keepbits >> lane) & 1ull) {
+        const int k = __popcll(keepbits & ((1ull << lane) - 1ull));
+        kbox[k] = mybox;
+        karea[k] = myarea;
+      }
+      if (lane == 0) { s_nk = nk; s_kept = before + nk; }
+    }
+    __syncthreads();
+    const int nk = s_nk;
+    if (s_kept >= max_det) break;  // uniform
+    if (nk > 0) {  // ---- C: later candidates against this block's kept boxes, in keep order
+      for (int j = b0 + 64 + tid; j < count; j += 1024) {
+        if (supp[j]) continue;
+        const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
+        const float4 bj = *(const float4*)(P + (long)aj * MSL_PRED_STRIDE);
+        const float jw2 = bj.z / 2.f, jh2 = bj.w / 2.f;
+        const float jx1 = bj.x - jw2, jy1 = bj.y - jh2, jx2 = bj.x + jw2, jy2 = bj.y + jh2;
+        const float jarea = (jx2 - jx1) * (jy2 - jy1);
+        for (int k = 0; k < nk; ++k) {
+          const float4 bi = kbox[k];
+          const float xx1 = fmaxf(bi.x, jx1), yy1 = fmaxf(bi.y, jy1), xx2 = fminf(bi.z, jx2), yy2 = fminf(bi.w, jy2);
+          const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+          const float inter = w * h;
+          const float ovr = inter / (karea[k] + jarea - inter);
+          if (ovr > iou_thres) { supp[j] = 1; break; }
+        }
+      }
+    }
   }
-  if (tid == 0) keep_cnt[n] = kept;
+  __syncthreads();
+  if (tid == 0) keep_cnt[n] = s_kept < max_det ? s_kept : max_det;
 }
 
 int msl_launch_nms(const msl_op& op, hipStream_t s) {
@@ -168,7 +246,7 @@ int msl_launch_nms(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3], "nms: null pointer");
   MSL_REQUIRE(N > 0 && A > 0 && A <= NMS_CAP && max_det > 0, "nms: bad dims (A=%d, cap %d)", A, NMS_CAP);
   static bool attr_set = false;
-  const size_t lds = (size_t)NMS_CAP * 9;
+  const size_t lds = (size_t)NMS_CAP * 9 + 64 * (16 + 4 + 8);  // keys + suppressed flags + one block's boxes, areas and row masks
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
