@@ -171,3 +171,25 @@ def test_trainer_step_same_gradients_with_either_loss():
     g_t = tr.store.g.clone()
     np.testing.assert_allclose(items_h, items_t, rtol=5e-4, atol=1e-6)
     assert float((g_h - g_t).abs().max()) <= 2e-3 * float(g_t.abs().max()) + 1e-6
+
+
+def test_seg_loss_op_matches_the_oracle_loss_directly():
+    """The HIP loss op against oracle/loss.py (the loop-based restatement of v8SegmentationLoss) on the same head outputs — not only against
+    the batched product loss that tests/test_loss.py pins to that oracle."""
+    from mslesseg_amd.hiplib import MSL_F32
+    from mslesseg_amd.segloss import SegLossOp, device_targets
+    from oracle import loss as OL
+
+    B, S, nc = 3, 128, 1
+    levels, glevels, proto, gproto = _views(B, S, nc, False, seed=21)
+    batch = _labels(B, S, nc, seed=5, empty=(1,))
+    op = SegLossOp(levels, glevels, proto, gproto, nc, S, S, MSL_F32, "cuda:0")
+    gt, masks = device_targets(batch, B, S, S, "cuda:0")
+    items = op(gt, masks).cpu().numpy()
+    feats = [torch.cat([lv[0].torch().float().cpu().permute(0, 3, 1, 2), lv[1].torch().float().cpu()[..., :nc].permute(0, 3, 1, 2)], 1) for lv in levels]
+    mc = torch.cat([lv[2].torch().float().cpu().reshape(B, -1, 32) for lv in levels], 1).permute(0, 2, 1)
+    pr = proto.torch().float().cpu().permute(0, 3, 1, 2)
+    tb = {"batch_idx": torch.from_numpy(batch["batch_idx"]), "cls": torch.from_numpy(batch["cls"]), "bboxes": torch.from_numpy(batch["bboxes"]),
+          "masks": torch.from_numpy(batch["masks"]).float()}
+    _, want = OL.v8_segmentation_loss(feats, mc, pr, tb, nc=nc)
+    np.testing.assert_allclose(items[:4], want.detach().numpy(), rtol=5e-4, atol=1e-6)
