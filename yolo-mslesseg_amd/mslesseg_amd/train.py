@@ -389,12 +389,12 @@ class Trainer:
                 det = plan.det[j, :k]
                 bl = det[:, :4] * (mw / S)
                 inbox = (xs >= bl[:, 0, None, None]) & (xs < bl[:, 2, None, None]) & (ys >= bl[:, 1, None, None]) & (ys < bl[:, 3, None, None])
-                pm = ((plan.lowres[j, :k] > 0) & inbox).float().reshape(k, -1)
+                pm = ((plan.lowres[j, :k] > 0) & inbox).float().reshape(k, mh * mw)
                 sel = batch["batch_idx"] == j
                 gb = torch.from_numpy(batch["bboxes"][sel]).to(self.device) * S
                 gxyxy = torch.cat((gb[:, :2] - gb[:, 2:] / 2, gb[:, :2] + gb[:, 2:] / 2), 1) if gb.numel() else torch.zeros(0, 4, device=self.device)
                 m = int(sel.sum())
-                gm = (gtm[j][None] == torch.arange(1, m + 1, device=self.device)[:, None, None]).float().reshape(m, -1)
+                gm = (gtm[j][None] == torch.arange(1, m + 1, device=self.device)[:, None, None]).float().reshape(m, mh * mw)  # m = 0: a slice whose lesions are all below 3 contour points
                 stats.add_image(det[:, :4], det[:, 4], det[:, 5], pm, gxyxy, torch.from_numpy(batch["cls"][sel]).to(self.device), gm)
         del eng, loss_ops
         return tot / max(nbat, 1), stats.result()
