@@ -50,3 +50,35 @@ def test_matching_is_one_to_one():
     c = MT.match_predictions(torch.zeros(2), torch.zeros(1), MT.box_iou(gt, pred))
     assert c[:, 0].sum() == 1 and c[0, 0]  # only the better duplicate counts
     assert MT.match_predictions(torch.ones(2), torch.zeros(1), MT.box_iou(gt, pred)).sum() == 0  # wrong class never matches
+
+
+def test_batched_device_matching_equals_the_per_image_path():
+    """SegStats.add_batch (one tensor program per batch, the validator's path) against add_image (upstream's NumPy matching, image by image)."""
+    import torch
+
+    from mslesseg_amd import metrics as MT
+
+    g = torch.Generator().manual_seed(0)
+    B, P, G, X = 5, 40, 7, 400
+    n_pred = torch.tensor([40, 0, 13, 25, 3])
+    n_gt = torch.tensor([7, 2, 0, 5, 1])
+    gc = torch.rand(B, G, 2, generator=g) * 80 + 10
+    gwh = torch.rand(B, G, 2, generator=g) * 30 + 8
+    gt_boxes = torch.cat([gc - gwh / 2, gc + gwh / 2], 2)
+    src = torch.randint(0, G, (B, P), generator=g)  # predictions are jittered copies of ground truths → a spread of IoUs, no exact ties
+    jit = torch.randn(B, P, 4, generator=g) * 4
+    pred_boxes = torch.gather(gt_boxes, 1, src[..., None].expand(-1, -1, 4)) + jit
+    pred_conf = torch.rand(B, P, generator=g)
+    pred_cls = torch.randint(0, 2, (B, P), generator=g).float()
+    gt_cls = torch.randint(0, 2, (B, G), generator=g).float()
+    gt_masks = (torch.rand(B, G, X, generator=g) < 0.3).float()
+    flip = (torch.rand(B, P, X, generator=g) < 0.15)
+    pred_masks = (torch.gather(gt_masks, 1, src[..., None].expand(-1, -1, X)).bool() ^ flip).float()
+    a, b = MT.SegStats(), MT.SegStats()
+    for i in range(B):
+        n, m = int(n_pred[i]), int(n_gt[i])
+        a.add_image(pred_boxes[i, :n], pred_conf[i, :n], pred_cls[i, :n], pred_masks[i, :n], gt_boxes[i, :m], gt_cls[i, :m], gt_masks[i, :m])
+    b.add_batch(pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt)
+    assert np.array_equal(np.concatenate(a.tp_b), np.concatenate(b.tp_b)) and np.array_equal(np.concatenate(a.tp_m), np.concatenate(b.tp_m))
+    assert np.array_equal(np.concatenate(a.conf), np.concatenate(b.conf)) and np.array_equal(np.concatenate(a.tcls), np.concatenate(b.tcls))
+    assert np.concatenate(a.tp_b)[:, 0].sum() >= 5 and np.concatenate(a.tp_m).sum() > 20 and a.result() == b.result()

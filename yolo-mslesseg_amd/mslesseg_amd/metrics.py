@@ -49,6 +49,26 @@ def match_predictions(pred_cls: torch.Tensor, true_cls: torch.Tensor, iou: torch
     return correct
 
 
+def match_batch(iou: torch.Tensor, same: torch.Tensor) -> torch.Tensor:
+    """`match_predictions` for a whole batch on the device: iou [B,G,P] (0 where a row / column is padding), same [B,G,P] bool (valid pair of equal
+    class) → correct [B,P,10] bool.  Per IoU threshold, the matching the NumPy code performs: every prediction keeps its best-IoU ground truth
+    among the pairs above the threshold, then every ground truth keeps the LOWEST-index prediction among those that chose it (the order
+    `np.unique` leaves behind in upstream's match_predictions) — one transfer per batch instead of seven per image."""
+    B, G, P = iou.shape
+    thr = torch.as_tensor(IOUV, dtype=iou.dtype, device=iou.device).view(1, -1, 1, 1)
+    x = (iou * same).unsqueeze(1)                                   # [B,1,G,P]
+    ok = x >= thr                                                   # [B,T,G,P]
+    masked = torch.where(ok, x, torch.full_like(x, -1.0))
+    best_g = masked.argmax(2)                                       # [B,T,P] best gt of every prediction
+    has = ok.any(2)                                                 # [B,T,P]
+    chose = torch.zeros_like(ok).scatter_(2, best_g.unsqueeze(2), has.unsqueeze(2))  # [B,T,G,P]: prediction p chose gt g
+    idx = torch.arange(P, device=iou.device).view(1, 1, 1, P).expand_as(chose)
+    first_p = torch.where(chose, idx, torch.full_like(idx, P)).amin(3)              # [B,T,G] lowest prediction index per gt
+    correct = torch.zeros(B, len(IOUV), P + 1, dtype=torch.bool, device=iou.device)
+    correct.scatter_(2, first_p, torch.ones_like(first_p, dtype=torch.bool))
+    return correct[:, :, :P].permute(0, 2, 1)
+
+
 def _smooth(y: np.ndarray, f: float = 0.1) -> np.ndarray:
     nf = round(len(y) * f * 2) // 2 + 1
     p = np.ones(nf // 2)
@@ -122,6 +142,37 @@ class SegStats:
         self.tp_m.append(cm)
         self.conf.append(pred_conf.cpu().numpy())
         self.pcls.append(pred_cls.cpu().numpy().astype(np.int64))
+
+    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt) -> None:
+        """A whole batch at once, matched on the device (`match_batch`): pred_* [B,P,…] with the first n_pred[b] rows valid, gt_* [B,G,…] with the
+        first n_gt[b] rows valid; masks as [B,·,pixels] {0,1} floats on one pixel grid."""
+        B, P = pred_conf.shape
+        G = gt_cls.shape[1]
+        dev = pred_conf.device
+        pv = torch.arange(P, device=dev)[None] < n_pred[:, None]
+        gv = torch.arange(G, device=dev)[None] < n_gt[:, None]
+        if G:
+            pair = gv[:, :, None] & pv[:, None, :]
+            same = pair & (gt_cls[:, :, None] == pred_cls[:, None, :])
+            lt = torch.maximum(gt_boxes[:, :, None, :2], pred_boxes[:, None, :, :2])
+            rb = torch.minimum(gt_boxes[:, :, None, 2:], pred_boxes[:, None, :, 2:])
+            inter = (rb - lt).clamp_(0).prod(3)
+            ag, ap = (gt_boxes[..., 2:] - gt_boxes[..., :2]).prod(2), (pred_boxes[..., 2:] - pred_boxes[..., :2]).prod(2)
+            cb = match_batch(inter / (ag[:, :, None] + ap[:, None, :] - inter + 1e-7), same)
+            mi = torch.bmm(gt_masks, pred_masks.transpose(1, 2))
+            union = gt_masks.sum(2)[:, :, None] + pred_masks.sum(2)[:, None, :] - mi
+            cm = match_batch(mi / (union + 1e-7), same)
+        else:
+            cb = cm = torch.zeros(B, P, len(IOUV), dtype=torch.bool, device=dev)
+        cb, cm, conf, pcls, pvh = cb.cpu().numpy(), cm.cpu().numpy(), pred_conf.cpu().numpy(), pred_cls.cpu().numpy(), pv.cpu().numpy()
+        gvh, tcls = gv.cpu().numpy(), gt_cls.cpu().numpy()
+        for b in range(B):
+            self.tcls.append(tcls[b][gvh[b]].astype(np.int64))
+            if pvh[b].any():
+                self.tp_b.append(cb[b][pvh[b]])
+                self.tp_m.append(cm[b][pvh[b]])
+                self.conf.append(conf[b][pvh[b]])
+                self.pcls.append(pcls[b][pvh[b]].astype(np.int64))
 
     def result(self) -> Dict[str, float]:
         tcls = np.concatenate(self.tcls) if self.tcls else np.zeros(0, np.int64)

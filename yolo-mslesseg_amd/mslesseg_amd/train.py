@@ -379,23 +379,18 @@ class Trainer:
                 loss_ops[nb_] = SegLossOp(lv, lv, plan.proto, plan.proto, self.nc, S, S, self.dtype, self.device)  # no_grad: the gradient views are never written
             tot += loss_ops[nb_](gt, masks_d, no_grad=True)[:4].cpu().numpy()
             nbat += 1
-            cnt = plan.keep_cnt.cpu()
+            # metrics: the whole batch matched on the device (metrics.SegStats.add_batch), one transfer per batch
             mh, mw = plan.proto.H, plan.proto.W
-            ys = torch.arange(mh, device=self.device, dtype=torch.float32)[None, :, None]
-            xs = torch.arange(mw, device=self.device, dtype=torch.float32)[None, None, :]
-            gtm = masks_d
-            for j in range(nb_):
-                k = int(cnt[j])
-                det = plan.det[j, :k]
-                bl = det[:, :4] * (mw / S)
-                inbox = (xs >= bl[:, 0, None, None]) & (xs < bl[:, 2, None, None]) & (ys >= bl[:, 1, None, None]) & (ys < bl[:, 3, None, None])
-                pm = ((plan.lowres[j, :k] > 0) & inbox).float().reshape(k, mh * mw)
-                sel = batch["batch_idx"] == j
-                gb = torch.from_numpy(batch["bboxes"][sel]).to(self.device) * S
-                gxyxy = torch.cat((gb[:, :2] - gb[:, 2:] / 2, gb[:, :2] + gb[:, 2:] / 2), 1) if gb.numel() else torch.zeros(0, 4, device=self.device)
-                m = int(sel.sum())
-                gm = (gtm[j][None] == torch.arange(1, m + 1, device=self.device)[:, None, None]).float().reshape(m, mh * mw)  # m = 0: a slice whose lesions are all below 3 contour points
-                stats.add_image(det[:, :4], det[:, 4], det[:, 5], pm, gxyxy, torch.from_numpy(batch["cls"][sel]).to(self.device), gm)
+            ys = torch.arange(mh, device=self.device, dtype=torch.float32)[None, None, :, None]
+            xs = torch.arange(mw, device=self.device, dtype=torch.float32)[None, None, None, :]
+            det = plan.det[:nb_]                                                    # [nb, max_det, 40]: xyxy, conf, cls, coefficients
+            bl = det[..., :4] * (mw / S)
+            inbox = (xs >= bl[..., 0, None, None]) & (xs < bl[..., 2, None, None]) & (ys >= bl[..., 1, None, None]) & (ys < bl[..., 3, None, None])
+            pm = ((plan.lowres[:nb_] > 0) & inbox).float().reshape(nb_, det.shape[1], mh * mw)
+            G = int(gt.shape[1])
+            n_gt = (gt[..., 1:].sum(2) > 0).sum(1)
+            gm = (masks_d[:, None] == torch.arange(1, G + 1, device=self.device)[None, :, None, None]).float().reshape(nb_, G, mh * mw)
+            stats.add_batch(det[..., :4], det[..., 4], det[..., 5], pm, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], gm, n_gt)
         del eng, loss_ops
         return tot / max(nbat, 1), stats.result()
 
