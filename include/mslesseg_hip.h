@@ -182,6 +182,10 @@ enum {
   MSL_OP_RASTER_MASKS = 38,       /* instance polygons -> overlap-encoded prototype-resolution masks (even-odd fill at pixel centres, later polygons overwrite):
                                      p 0 vertices f32 [V][2] (mask pixels), 1 polygons i32 [P][4] (first vertex, count, value, -), 2 ranges i32 [B][2] (first polygon,
                                      count), 4 masks u8 [B][mh][mw] ; i 0 B, 1 mh, 2 mw */
+  MSL_OP_MASK_IOU = 39,           /* validator masks [replaces process_mask + mask_iou of ultralytics' SegmentationValidator, run every epoch under model.train(),
+                                     REF scripts/train.py:358-366]: per kept prediction the area of its binary low-res mask (logit > 0 inside its crop box) and
+                                     its intersection with every ground-truth instance of the overlap-encoded label map.  p 0 lowres f32 [N,max_det,mh,mw], 1 det,
+                                     2 keep_cnt, 3 labels u8 [N,mh,mw], 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det] ; i 0 N,1 mh,2 mw,3 G,7 max_det,8 Hlb,9 Wlb */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

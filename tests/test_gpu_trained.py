@@ -208,3 +208,37 @@ def test_predict_variants_mixed_work_list_equals_single_variant_runs(trained_sta
     assert not torch.equal(single[0], V.predict_volume(models["HE"], fl, "axial", idx["axial"], mejora="GC").cpu())  # the weights matter
     with pytest.raises(KeyError):
         V.predict_variants(models, [(fl, "LT", "axial", idx["axial"])], rank=0, world=1)
+
+
+def test_validator_mask_counts_op_equals_the_dense_formulation(trained_state, demo_volumes):
+    """MSL_OP_MASK_IOU (per-prediction mask area and intersection with every GT instance, from the low-res logits) against the dense form it
+    replaces: binary [predictions, 160*160] masks multiplied with one-hot ground-truth masks — on real slices, conf 0.001 (hundreds of boxes)."""
+    from mslesseg_amd import augment as A
+    from mslesseg_amd import data as D
+    from mslesseg_amd import hiplib
+
+    ds = D.VolumeSliceDataset(demo_volumes["P39_flair"], demo_volumes["P39_mask"], keep=lambda plano, i: i % 16 == 0)
+    B = min(len(ds), 12)
+    aug = A.DeviceAugmenter(A.SliceCache(ds, "cuda:0"), 640)
+    batch = aug.batch(list(range(B)), None, mosaic=False, augment=False)
+    eng = E.InferEngine(trained_state, "n", 1, MSL_BF16, conf=0.001, iou=0.7, max_det=300)
+    plan = eng.plan(B, 640, 640)
+    plan.input.t.copy_(batch["img"].reshape(-1))
+    plan.run()
+    gt, labels = batch["gt"], batch["masks"]
+    G, mh, mw, P = int(gt.shape[1]), plan.proto.H, plan.proto.W, 300
+    assert G >= 2 and int(plan.keep_cnt.max()) > 20
+    inter = torch.full((B, P, G), -1, dtype=torch.int32, device="cuda:0")
+    parea = torch.full((B, P), -1, dtype=torch.int32, device="cuda:0")
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_IOU, MSL_F32, p=(plan.lowres.data_ptr(), plan.det.data_ptr(), plan.keep_cnt.data_ptr(), labels.data_ptr(), inter.data_ptr(), parea.data_ptr()),
+                                 i={0: B, 1: mh, 2: mw, 3: G, 7: P, 8: 640, 9: 640}), torch.cuda.current_stream().cuda_stream)
+    ys = torch.arange(mh, device="cuda:0", dtype=torch.float32)[None, None, :, None]
+    xs = torch.arange(mw, device="cuda:0", dtype=torch.float32)[None, None, None, :]
+    bl = plan.det[..., :4] * (mw / 640)
+    inbox = (xs >= bl[..., 0, None, None]) & (xs < bl[..., 2, None, None]) & (ys >= bl[..., 1, None, None]) & (ys < bl[..., 3, None, None])
+    valid = (torch.arange(P, device="cuda:0")[None] < plan.keep_cnt[:, None])
+    pm = ((plan.lowres > 0) & inbox & valid[:, :, None, None]).float().reshape(B, P, mh * mw)
+    gm = (labels[:, None] == torch.arange(1, G + 1, device="cuda:0")[None, :, None, None]).float().reshape(B, G, mh * mw)
+    want_inter = torch.bmm(pm, gm.transpose(1, 2)).round().int()
+    assert torch.equal(inter, want_inter) and torch.equal(parea, pm.sum(2).round().int())
+    assert int(want_inter.sum()) > 100

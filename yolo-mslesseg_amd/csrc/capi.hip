@@ -50,6 +50,7 @@ static int dispatch(const msl_op& op, hipStream_t s) {
     case MSL_OP_SGD: return msl_launch_sgd(op, s);
     case MSL_OP_AUGMENT: return msl_launch_augment(op, s);
     case MSL_OP_RASTER_MASKS: return msl_launch_raster_masks(op, s);
+    case MSL_OP_MASK_IOU: return msl_launch_mask_iou(op, s);
     case MSL_OP_SEG_LOSS: return msl_launch_seg_loss(op, s);
     case MSL_OP_ATTENTION_BWD: return msl_launch_attention_bwd(op, s);
     case MSL_OP_SLICE_EXTRACT: return msl_launch_slice_extract(op, s);

@@ -367,6 +367,63 @@ __device__ __forceinline__ void stage_boxes(float4* sbox, const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Validator masks (SegmentationValidator at prototype resolution, [UPSTREAM models/yolo/segment/val.py: process_mask + mask_iou]):
+// for every kept prediction the area of its binary mask (logit > 0 inside its crop box) and its intersection with every ground-truth
+// instance of the overlap-encoded label map — the two integers mask IoU needs — straight from the low-res logits, instead of
+// materialising a [predictions, 160*160] float matrix per slice and multiplying it with one-hot ground-truth masks.
+// One workgroup per (prediction, slice): the crop box is a few hundred proto pixels; per-instance counts in LDS.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mask_iou_counts_kernel(const float* __restrict__ lowres, const float* __restrict__ det, const int* __restrict__ keep_cnt,
+                                                             const uint8_t* __restrict__ labels, int* __restrict__ inter, int* __restrict__ parea, int mh, int mw,
+                                                             int max_det, int G, float wr, float hr) {
+  __shared__ int hist[256];
+  const int n = blockIdx.y, d = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) hist[i] = 0;
+  __syncthreads();
+  int* out = inter + ((long)n * max_det + d) * G;
+  if (d >= keep_cnt[n]) {  // not a prediction: zeros (the caller masks these rows out anyway)
+    for (int i = lane; i < G; i += 64) out[i] = 0;
+    if (lane == 0) parea[(long)n * max_det + d] = 0;
+    return;
+  }
+  const float* row = det + ((long)n * max_det + d) * MSL_PRED_STRIDE;
+  const float bx1 = row[0] * wr, by1 = row[1] * hr, bx2 = row[2] * wr, by2 = row[3] * hr;  // the crop test of mask_lowres: x >= x1 && x < x2 …
+  int x0 = (int)floorf(bx1), x1 = (int)ceilf(bx2), y0 = (int)floorf(by1), y1 = (int)ceilf(by2);
+  x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > mw ? mw : x1; y1 = y1 > mh ? mh : y1;
+  const int bw = x1 - x0, bh = y1 - y0;
+  int area = 0;
+  if (bw > 0 && bh > 0) {
+    const float* L = lowres + ((long)n * max_det + d) * mh * mw;
+    const uint8_t* lab = labels + (long)n * mh * mw;
+    for (int t = lane; t < bw * bh; t += 64) {
+      const int py = y0 + t / bw, px = x0 + t % bw;
+      const float fx = (float)px, fy = (float)py;
+      if (fx >= bx1 && fx < bx2 && fy >= by1 && fy < by2 && L[py * mw + px] > 0.f) {
+        ++area;
+        atomicAdd(&hist[lab[py * mw + px]], 1);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) area += __shfl_xor(area, off);
+  __syncthreads();
+  for (int i = lane; i < G; i += 64) out[i] = hist[i + 1];  // label value 1 + g ↔ ground-truth instance g
+  if (lane == 0) parea[(long)n * max_det + d] = area;
+}
+
+// p 0 lowres f32 [N,max_det,mh,mw], 1 det, 2 keep_cnt, 3 labels u8 [N,mh,mw] (0 background, 1 + instance), 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det]
+// i 0 N,1 mh,2 mw,3 G (<= 255),7 max_det,8 Hlb,9 Wlb
+int msl_launch_mask_iou(const msl_op& op, hipStream_t s) {
+  const int N = op.i[0], mh = op.i[1], mw = op.i[2], G = op.i[3], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9];
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5], "mask_iou: null pointer");
+  MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && G >= 1 && G <= 255 && max_det > 0 && Hlb > 0 && Wlb > 0 && N <= 65535, "mask_iou: bad dims");
+  hipLaunchKernelGGL(mask_iou_counts_kernel, dim3((unsigned)max_det, (unsigned)N), dim3(64), 0, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2],
+                     (const uint8_t*)op.p[3], (int*)op.p[4], (int*)op.p[5], mh, mw, max_det, G, (float)((double)mw / (double)Wlb), (float)((double)mh / (double)Hlb));
+  MSL_CHECK_LAUNCH("mask_iou");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Boundary masks (B4): [total_kept, Hlb, Wlb] float {0,1}.  [UPSTREAM process_mask upsample + gt_(0.0)]
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_upsample_kernel(const float* __restrict__ lowres, const float* __restrict__ det,

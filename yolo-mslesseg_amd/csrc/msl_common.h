@@ -174,6 +174,7 @@ int msl_launch_ema(const msl_op& op, hipStream_t s);
 int msl_launch_sgd(const msl_op& op, hipStream_t s);
 int msl_launch_augment(const msl_op& op, hipStream_t s);
 int msl_launch_raster_masks(const msl_op& op, hipStream_t s);
+int msl_launch_mask_iou(const msl_op& op, hipStream_t s);
 int msl_launch_seg_loss(const msl_op& op, hipStream_t s);
 int msl_launch_attention_bwd(const msl_op& op, hipStream_t s);
 int msl_launch_slice_extract(const msl_op& op, hipStream_t s);

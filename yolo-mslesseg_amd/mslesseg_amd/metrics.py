@@ -143,9 +143,10 @@ class SegStats:
         self.conf.append(pred_conf.cpu().numpy())
         self.pcls.append(pred_cls.cpu().numpy().astype(np.int64))
 
-    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt) -> None:
+    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts=None) -> None:
         """A whole batch at once, matched on the device (`match_batch`): pred_* [B,P,…] with the first n_pred[b] rows valid, gt_* [B,G,…] with the
-        first n_gt[b] rows valid; masks as [B,·,pixels] {0,1} floats on one pixel grid."""
+        first n_gt[b] rows valid; masks as [B,·,pixels] {0,1} floats on one pixel grid — or `mask_counts` = (intersection [B,P,G], prediction
+        areas [B,P], ground-truth areas [B,G]) as MSL_OP_MASK_IOU counts them, in which case no mask tensor is needed."""
         B, P = pred_conf.shape
         G = gt_cls.shape[1]
         dev = pred_conf.device
@@ -159,8 +160,12 @@ class SegStats:
             inter = (rb - lt).clamp_(0).prod(3)
             ag, ap = (gt_boxes[..., 2:] - gt_boxes[..., :2]).prod(2), (pred_boxes[..., 2:] - pred_boxes[..., :2]).prod(2)
             cb = match_batch(inter / (ag[:, :, None] + ap[:, None, :] - inter + 1e-7), same)
-            mi = torch.bmm(gt_masks, pred_masks.transpose(1, 2))
-            union = gt_masks.sum(2)[:, :, None] + pred_masks.sum(2)[:, None, :] - mi
+            if mask_counts is not None:
+                mi = mask_counts[0].transpose(1, 2).to(torch.float32)
+                union = mask_counts[2].to(torch.float32)[:, :, None] + mask_counts[1].to(torch.float32)[:, None, :] - mi
+            else:
+                mi = torch.bmm(gt_masks, pred_masks.transpose(1, 2))
+                union = gt_masks.sum(2)[:, :, None] + pred_masks.sum(2)[:, None, :] - mi
             cm = match_batch(mi / (union + 1e-7), same)
         else:
             cb = cm = torch.zeros(B, P, len(IOUV), dtype=torch.bool, device=dev)

@@ -358,7 +358,7 @@ class Trainer:
         eng = InferEngine({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, self.store.scale, self.nc, self.dtype, str(self.device),
                           conf=0.001, iou=0.7, max_det=300)
         stats = MT.SegStats()
-        vb = min(self.batch, 32)
+        vb = min(self.batch, 128)
         tot, nbat = np.zeros(4), 0
         loss_ops = {}
         for b0 in range(0, limit, vb):
@@ -379,18 +379,23 @@ class Trainer:
                 loss_ops[nb_] = SegLossOp(lv, lv, plan.proto, plan.proto, self.nc, S, S, self.dtype, self.device)  # no_grad: the gradient views are never written
             tot += loss_ops[nb_](gt, masks_d, no_grad=True)[:4].cpu().numpy()
             nbat += 1
-            # metrics: the whole batch matched on the device (metrics.SegStats.add_batch), one transfer per batch
+            # metrics: mask areas / intersections counted by MSL_OP_MASK_IOU from the low-res logits, the whole batch matched on the device
+            # (metrics.SegStats.add_batch), one transfer per batch
             mh, mw = plan.proto.H, plan.proto.W
-            ys = torch.arange(mh, device=self.device, dtype=torch.float32)[None, None, :, None]
-            xs = torch.arange(mw, device=self.device, dtype=torch.float32)[None, None, None, :]
             det = plan.det[:nb_]                                                    # [nb, max_det, 40]: xyxy, conf, cls, coefficients
-            bl = det[..., :4] * (mw / S)
-            inbox = (xs >= bl[..., 0, None, None]) & (xs < bl[..., 2, None, None]) & (ys >= bl[..., 1, None, None]) & (ys < bl[..., 3, None, None])
-            pm = ((plan.lowres[:nb_] > 0) & inbox).float().reshape(nb_, det.shape[1], mh * mw)
             G = int(gt.shape[1])
             n_gt = (gt[..., 1:].sum(2) > 0).sum(1)
-            gm = (masks_d[:, None] == torch.arange(1, G + 1, device=self.device)[None, :, None, None]).float().reshape(nb_, G, mh * mw)
-            stats.add_batch(det[..., :4], det[..., 4], det[..., 5], pm, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], gm, n_gt)
+            counts = None
+            if G:
+                inter = torch.empty(nb_, det.shape[1], G, dtype=torch.int32, device=self.device)
+                parea = torch.empty(nb_, det.shape[1], dtype=torch.int32, device=self.device)
+                hiplib.launch(hiplib.make_op(hiplib.OP_MASK_IOU, MSL_F32, p=(plan.lowres.data_ptr(), plan.det.data_ptr(), plan.keep_cnt.data_ptr(), masks_d.data_ptr(),
+                                                                             inter.data_ptr(), parea.data_ptr()),
+                                             i={0: nb_, 1: mh, 2: mw, 3: G, 7: det.shape[1], 8: S, 9: S}), torch.cuda.current_stream(self.device).cuda_stream)
+                lab = masks_d.reshape(nb_, -1).long()
+                garea = torch.zeros(nb_, 256, dtype=torch.int32, device=self.device).scatter_add_(1, lab, torch.ones_like(lab, dtype=torch.int32))[:, 1 : G + 1]
+                counts = (inter, parea, garea)
+            stats.add_batch(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt, mask_counts=counts)
         del eng, loss_ops
         return tot / max(nbat, 1), stats.result()
 
