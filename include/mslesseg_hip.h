@@ -185,7 +185,8 @@ enum {
   MSL_OP_MASK_IOU = 39,           /* validator masks [replaces process_mask + mask_iou of ultralytics' SegmentationValidator, run every epoch under model.train(),
                                      REF scripts/train.py:358-366]: per kept prediction the area of its binary low-res mask (logit > 0 inside its crop box) and
                                      its intersection with every ground-truth instance of the overlap-encoded label map.  p 0 lowres f32 [N,max_det,mh,mw], 1 det,
-                                     2 keep_cnt, 3 labels u8 [N,mh,mw], 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det] ; i 0 N,1 mh,2 mw,3 G,7 max_det,8 Hlb,9 Wlb */
+                                     2 keep_cnt, 3 labels u8 [N,mh,mw], 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det], 6 garea i32 [N,G] (areas of the ground-truth
+                                     instances) ; i 0 N,1 mh,2 mw,3 G,7 max_det,8 Hlb,9 Wlb */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

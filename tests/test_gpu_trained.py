@@ -230,7 +230,8 @@ def test_validator_mask_counts_op_equals_the_dense_formulation(trained_state, de
     assert G >= 2 and int(plan.keep_cnt.max()) > 20
     inter = torch.full((B, P, G), -1, dtype=torch.int32, device="cuda:0")
     parea = torch.full((B, P), -1, dtype=torch.int32, device="cuda:0")
-    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_IOU, MSL_F32, p=(plan.lowres.data_ptr(), plan.det.data_ptr(), plan.keep_cnt.data_ptr(), labels.data_ptr(), inter.data_ptr(), parea.data_ptr()),
+    garea = torch.full((B, G), -1, dtype=torch.int32, device="cuda:0")
+    hiplib.launch(hiplib.make_op(hiplib.OP_MASK_IOU, MSL_F32, p=(plan.lowres.data_ptr(), plan.det.data_ptr(), plan.keep_cnt.data_ptr(), labels.data_ptr(), inter.data_ptr(), parea.data_ptr(), garea.data_ptr()),
                                  i={0: B, 1: mh, 2: mw, 3: G, 7: P, 8: 640, 9: 640}), torch.cuda.current_stream().cuda_stream)
     ys = torch.arange(mh, device="cuda:0", dtype=torch.float32)[None, None, :, None]
     xs = torch.arange(mw, device="cuda:0", dtype=torch.float32)[None, None, None, :]
@@ -240,5 +241,5 @@ def test_validator_mask_counts_op_equals_the_dense_formulation(trained_state, de
     pm = ((plan.lowres > 0) & inbox & valid[:, :, None, None]).float().reshape(B, P, mh * mw)
     gm = (labels[:, None] == torch.arange(1, G + 1, device="cuda:0")[None, :, None, None]).float().reshape(B, G, mh * mw)
     want_inter = torch.bmm(pm, gm.transpose(1, 2)).round().int()
-    assert torch.equal(inter, want_inter) and torch.equal(parea, pm.sum(2).round().int())
+    assert torch.equal(inter, want_inter) and torch.equal(parea, pm.sum(2).round().int()) and torch.equal(garea, gm.sum(2).round().int())
     assert int(want_inter.sum()) > 100

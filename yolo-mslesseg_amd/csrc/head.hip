@@ -374,12 +374,19 @@ __device__ __forceinline__ void stage_boxes(float4* sbox, const float* __restric
 // One workgroup per (prediction, slice): the crop box is a few hundred proto pixels; per-instance counts in LDS.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void mask_iou_counts_kernel(const float* __restrict__ lowres, const float* __restrict__ det, const int* __restrict__ keep_cnt,
-                                                             const uint8_t* __restrict__ labels, int* __restrict__ inter, int* __restrict__ parea, int mh, int mw,
-                                                             int max_det, int G, float wr, float hr) {
+                                                             const uint8_t* __restrict__ labels, int* __restrict__ inter, int* __restrict__ parea, int* __restrict__ garea,
+                                                             int mh, int mw, int max_det, int G, float wr, float hr) {
   __shared__ int hist[256];
   const int n = blockIdx.y, d = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < 256; i += 64) hist[i] = 0;
   __syncthreads();
+  if (d == (int)gridDim.x - 1) {  // the extra workgroup of every slice: areas of the ground-truth instances (histogram of the label map)
+    const uint8_t* lab = labels + (long)n * mh * mw;
+    for (int t = lane; t < mh * mw; t += 64) atomicAdd(&hist[lab[t]], 1);
+    __syncthreads();
+    for (int i = lane; i < G; i += 64) garea[(long)n * G + i] = hist[i + 1];
+    return;
+  }
   int* out = inter + ((long)n * max_det + d) * G;
   if (d >= keep_cnt[n]) {  // not a prediction: zeros (the caller masks these rows out anyway)
     for (int i = lane; i < G; i += 64) out[i] = 0;
@@ -411,14 +418,15 @@ __global__ __launch_bounds__(64) void mask_iou_counts_kernel(const float* __rest
   if (lane == 0) parea[(long)n * max_det + d] = area;
 }
 
-// p 0 lowres f32 [N,max_det,mh,mw], 1 det, 2 keep_cnt, 3 labels u8 [N,mh,mw] (0 background, 1 + instance), 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det]
+// p 0 lowres f32 [N,max_det,mh,mw], 1 det, 2 keep_cnt, 3 labels u8 [N,mh,mw] (0 background, 1 + instance), 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det],
+//   6 garea i32 [N,G]
 // i 0 N,1 mh,2 mw,3 G (<= 255),7 max_det,8 Hlb,9 Wlb
 int msl_launch_mask_iou(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], mh = op.i[1], mw = op.i[2], G = op.i[3], max_det = op.i[7], Hlb = op.i[8], Wlb = op.i[9];
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5], "mask_iou: null pointer");
+  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6], "mask_iou: null pointer");
   MSL_REQUIRE(N > 0 && mh > 0 && mw > 0 && G >= 1 && G <= 255 && max_det > 0 && Hlb > 0 && Wlb > 0 && N <= 65535, "mask_iou: bad dims");
-  hipLaunchKernelGGL(mask_iou_counts_kernel, dim3((unsigned)max_det, (unsigned)N), dim3(64), 0, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2],
-                     (const uint8_t*)op.p[3], (int*)op.p[4], (int*)op.p[5], mh, mw, max_det, G, (float)((double)mw / (double)Wlb), (float)((double)mh / (double)Hlb));
+  hipLaunchKernelGGL(mask_iou_counts_kernel, dim3((unsigned)max_det + 1, (unsigned)N), dim3(64), 0, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2],
+                     (const uint8_t*)op.p[3], (int*)op.p[4], (int*)op.p[5], (int*)op.p[6], mh, mw, max_det, G, (float)((double)mw / (double)Wlb), (float)((double)mh / (double)Hlb));
   MSL_CHECK_LAUNCH("mask_iou");
   return MSL_OK;
 }

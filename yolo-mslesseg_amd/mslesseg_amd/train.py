@@ -389,11 +389,10 @@ class Trainer:
             if G:
                 inter = torch.empty(nb_, det.shape[1], G, dtype=torch.int32, device=self.device)
                 parea = torch.empty(nb_, det.shape[1], dtype=torch.int32, device=self.device)
+                garea = torch.empty(nb_, G, dtype=torch.int32, device=self.device)
                 hiplib.launch(hiplib.make_op(hiplib.OP_MASK_IOU, MSL_F32, p=(plan.lowres.data_ptr(), plan.det.data_ptr(), plan.keep_cnt.data_ptr(), masks_d.data_ptr(),
-                                                                             inter.data_ptr(), parea.data_ptr()),
+                                                                             inter.data_ptr(), parea.data_ptr(), garea.data_ptr()),
                                              i={0: nb_, 1: mh, 2: mw, 3: G, 7: det.shape[1], 8: S, 9: S}), torch.cuda.current_stream(self.device).cuda_stream)
-                lab = masks_d.reshape(nb_, -1).long()
-                garea = torch.zeros(nb_, 256, dtype=torch.int32, device=self.device).scatter_add_(1, lab, torch.ones_like(lab, dtype=torch.int32))[:, 1 : G + 1]
                 counts = (inter, parea, garea)
             stats.add_batch(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt, mask_counts=counts)
         del eng, loss_ops
