@@ -62,9 +62,9 @@ def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
     cout, K = wg.shape
     cout_pad = (cout + 15) // 16 * 16
     kpad = (K + kstep - 1) // kstep * kstep
-    wp = torch.zeros(cout_pad, kpad, dtype=torch.float32)
+    wp = torch.zeros(cout_pad, kpad, dtype=torch.float32, device=wg.device)
     wp[:cout, :K] = wg
-    bp = torch.zeros(cout_pad, dtype=torch.float32)
+    bp = torch.zeros(cout_pad, dtype=torch.float32, device=wg.device)
     bp[:cout] = b
     return wp.to(_dt(dtype)).contiguous().to(device), bp.to(device), dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
 
@@ -99,10 +99,10 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
     # the halo is then staged once per block of 32 output channels)
     cob = 16 * cot
     if cin % chunk:  # one partial chunk: zero weights for the channels that do not exist
-        wp = torch.zeros(cout, (cin + chunk - 1) // chunk * chunk, 3, 3, dtype=w.dtype)
+        wp = torch.zeros(cout, (cin + chunk - 1) // chunk * chunk, 3, 3, dtype=w.dtype, device=w.device)
         wp[:, :cin] = w
         w = wp
-    wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot)]   # [blk, col, cc, g, e, ky, kx]
+    wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot).to(w.device)]   # [blk, col, cc, g, e, ky, kx]
     img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
     return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
 
@@ -471,9 +471,22 @@ class InferEngine:
         self.scale, self.nc, self.dtype = scale, nc, dtype
         self.conf, self.iou, self.max_det = conf, iou, max_det
         params.validate_state(state, scale, nc)
+        self._use_lds3x3 = use_lds3x3
         self.weights = PackedWeights(state, scale, nc, dtype, self.device, use_lds3x3)
         self._plans: Dict[Tuple[int, int, int], Plan] = {}
         self._lb: Dict[Tuple[int, int, int, int], LetterBoxProgram] = {}
+
+    def refresh(self, state) -> None:
+        """New weights into the SAME packed tensors (the plans hold raw pointers to them, so every plan stays valid): the per-epoch validation of
+        the trainer re-uses one engine and its plans instead of rebuilding them.  `state` may live on the device: folding and packing then run
+        there."""
+        params.validate_state(state, self.scale, self.nc)
+        new = PackedWeights(state, self.scale, self.nc, self.dtype, self.device, self._use_lds3x3)
+        for name, (wt, bt, m) in self.weights.t.items():
+            nw, nb_, nm = new.t[name]
+            assert wt.shape == nw.shape and bt.shape == nb_.shape and m == nm, name
+            wt.copy_(nw)
+            bt.copy_(nb_)
 
     def plan(self, N: int, Hlb: int, Wlb: int) -> Plan:
         key = (N, Hlb, Wlb)

@@ -135,6 +135,7 @@ class Trainer:
         # the slice cache of `cache=True` lives in HBM and batches are augmented there (augment.py); device_augment=False keeps the NumPy path of data.py
         self.aug = self.val_aug = None
         self._aug_stream = None
+        self._val_engine, self._val_loss_ops = None, None
         if self.hyp["device_augment"]:
             from .augment import DeviceAugmenter, SliceCache
 
@@ -354,13 +355,16 @@ class Trainer:
             return np.zeros(4), None
         S, n = self.hyp["imgsz"], len(self.val_ds)
         limit = min(n, self.hyp.get("val_max") or n)
-        sd = self.store.state_dict(p=self.ema_p, b=self.ema_b)
-        eng = InferEngine({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, self.store.scale, self.nc, self.dtype, str(self.device),
-                          conf=0.001, iou=0.7, max_det=300)
+        sd = self.store.state_dict(p=self.ema_p, b=self.ema_b, on_device=True)  # EMA weights stay on the GPU: BN folding and packing run there
+        if self._val_engine is None:  # one engine and its plans for the whole training; only the weights change from epoch to epoch
+            self._val_engine = InferEngine(sd, self.store.scale, self.nc, self.dtype, str(self.device), conf=0.001, iou=0.7, max_det=300)
+            self._val_loss_ops = {}
+        else:
+            self._val_engine.refresh(sd)
+        eng, loss_ops = self._val_engine, self._val_loss_ops
         stats = MT.SegStats()
         vb = min(self.batch, 128)
         tot, nbat = np.zeros(4), 0
-        loss_ops = {}
         for b0 in range(0, limit, vb):
             idx = list(range(b0, min(b0 + vb, limit)))
             nb_ = len(idx)
@@ -395,7 +399,6 @@ class Trainer:
                                              i={0: nb_, 1: mh, 2: mw, 3: G, 7: det.shape[1], 8: S, 9: S}), torch.cuda.current_stream(self.device).cuda_stream)
                 counts = (inter, parea, garea)
             stats.add_batch(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt, mask_counts=counts)
-        del eng, loss_ops
         return tot / max(nbat, 1), stats.result()
 
     # ------------------------------------------------------------------ files

@@ -129,9 +129,12 @@ class ParamStore:
         self.p.copy_(cpu_p)
         self.b.copy_(cpu_b)
 
-    def state_dict(self, p: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None) -> "OrderedDict[str, torch.Tensor]":
-        P = (self.p if p is None else p).detach().cpu()
-        B = (self.b if b is None else b).detach().cpu()
+    def state_dict(self, p: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None, on_device: bool = False) -> "OrderedDict[str, torch.Tensor]":
+        """ultralytics-keyed state dict of the flat buffers (host tensors; `on_device=True`: views / copies that stay on the GPU)."""
+        P = (self.p if p is None else p).detach()
+        B = (self.b if b is None else b).detach()
+        if not on_device:
+            P, B = P.cpu(), B.cpu()
         out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
 
         def get(key):
@@ -157,10 +160,10 @@ class ParamStore:
                 for t, k in (("mean", "running_mean"), ("var", "running_var")):
                     o = self.bentries[f"{name}.{t}"]
                     out[f"{name}.bn.{k}"] = B[o : o + s["cout"]].clone()
-                out[f"{name}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+                out[f"{name}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=P.device)
             else:
                 out[f"{name}.bias"] = get(name + ".bias")
-        out["model.23.dfl.conv.weight"] = torch.arange(graph.REG_MAX, dtype=torch.float32).view(1, graph.REG_MAX, 1, 1)
+        out["model.23.dfl.conv.weight"] = torch.arange(graph.REG_MAX, dtype=torch.float32, device=P.device).view(1, graph.REG_MAX, 1, 1)
         return out
 
 
