@@ -402,3 +402,14 @@ def test_whole_volume_three_planes_consensus_and_dice_on_device(synth_state, ora
     V.write_nifti(tmp_path / "P39_consenso.nii.gz", cons_d.cpu().numpy(), demo_volumes["P39_affine"])
     back, aff = V.read_nifti(tmp_path / "P39_consenso.nii.gz")
     assert np.array_equal(back, cons_d.cpu().numpy().astype(np.float64))
+
+
+def test_graph_replay_equals_eager(eng_f32, golden):
+    """msl_graph_create / msl_graph_launch: the predict program captured into a hipGraph (on a stream of the library's own — torch's current
+    stream is usually the legacy default stream, which cannot be captured) and replayed on the caller's stream gives the eager result."""
+    img = _img(golden, 2)
+    eager = eng_f32.predict_batch(torch.from_numpy(img[None]))
+    want, n = eager.merged(*img.shape[:2]).cpu().numpy(), int(eager.keep_cnt.cpu()[0])
+    for _ in range(2):  # second pass re-uses the instantiated graph
+        plan = eng_f32.predict_batch(torch.from_numpy(img[None]), graph_replay=True)
+        assert int(plan.keep_cnt.cpu()[0]) == n and np.array_equal(plan.merged(*img.shape[:2]).cpu().numpy(), want)

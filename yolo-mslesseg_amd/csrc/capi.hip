@@ -167,12 +167,19 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
 
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out) {
   if (!ops || n <= 0 || !graph_exec_out) { msl_set_error("msl_graph_create: bad arguments"); return MSL_EINVAL; }
-  hipStream_t s = (hipStream_t)stream;
+  // Capture on a stream of the library's own: the caller's stream may be the legacy default stream (torch's current stream usually is), which
+  // cannot be captured.  Nothing executes during capture; the instantiated graph is launched on whatever stream msl_graph_launch is given.
+  // (The program must have run eagerly once before: first launches set kernel attributes, which is not a capturable operation.)
+  (void)stream;
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) { msl_set_error("msl_graph_create: hipStreamCreate: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
   hipGraph_t graph = nullptr;
-  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) { msl_set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
-  int rc = msl_run_program(ops, n, stream);
+  e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { (void)hipStreamDestroy(s); msl_set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  int rc = msl_run_program(ops, n, (void*)s);
   e = hipStreamEndCapture(s, &graph);
+  (void)hipStreamDestroy(s);
   if (rc != MSL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) { msl_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
   hipGraphExec_t exec = nullptr;
