@@ -231,6 +231,26 @@ int msl_event_record(void* ev, void* stream);
 int msl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
 int msl_event_destroy(void* ev);
 
+/* ---- Typed entry points: the same kernels with plain arguments, for callers that do not want to fill `msl_op` descriptors (the Python host
+ * builds whole programs of descriptors once and replays them; a C / C++ caller doing single ops is better served by these).  Device pointers,
+ * asynchronous on `stream`, 0 or a negative MSL_E* code.
+ *
+ * msl_conv2d_nhwc: y = act(conv(x, w) + bias) (+ res) on dense NHWC tensors (views start at channel 0, channel stride = channel count) — the
+ *   Conv2d + folded BatchNorm + SiLU of ultralytics' `Conv` module that the reference reaches through model(img) [REF generar_predicciones.py:114].
+ *   w_gemm: [ceil16(Cout)][Kpad] in `dtype`, K = (ky, kx, ci) zero padded to a multiple of 32 (bf16) / 16 (fp32); bias fp32 [ceil16(Cout)];
+ *   k in {1, 3}, pad = k / 2, stride in {1, 2}; res (same shape as y, activation dtype) or NULL; out_f32: write fp32 instead of `dtype`.
+ * msl_letterbox_u8: ultralytics' LetterBox on uint8 slices (MSL_OP_LETTERBOX; xtab [Wn][4], ytab [Hn][4] = OpenCV's INTER_LINEAR fixed-point taps).
+ * msl_nms: ops.non_max_suppression + torchvision.ops.nms on decoded rows (MSL_OP_NMS): keep_idx [N][max_det], keep_cnt [N], det [N][max_det][40].
+ * msl_volume_consensus: combinar_volumenes [REF scripts/generar_consenso.py:106-109]: out = (a + c + s >= umbral).
+ * msl_volume_dice_sums: the three integer sums of DSC [REF utils/utils.py:455-460]: sums3 += (sum gt*pred, sum gt, sum pred); DSC = 2 s0 / (s1 + s2 + 1e-8). */
+int msl_conv2d_nhwc(const void* x, const void* w_gemm, const float* bias, const void* res, void* y, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                    int32_t k, int32_t stride, int32_t act_silu, int32_t out_f32, int32_t dtype, void* stream);
+int msl_letterbox_u8(const uint8_t* src, const int32_t* xtab, const int32_t* ytab, uint8_t* dst, int32_t N, int32_t H0, int32_t W0, int32_t channels, int32_t Hn, int32_t Wn,
+                     int32_t top, int32_t left, int32_t Hlb, int32_t Wlb, int32_t pad_value, void* stream);
+int msl_nms(const float* pred, int32_t* keep_idx, int32_t* keep_cnt, float* det, int32_t N, int32_t A, int32_t max_det, float conf_thres, float iou_thres, void* stream);
+int msl_volume_consensus(const float* axial, const float* coronal, const float* sagital, uint8_t* out, int64_t voxels, int32_t umbral, void* stream);
+int msl_volume_dice_sums(const uint8_t* gt, const uint8_t* pred, uint64_t* sums3, int64_t voxels, void* stream);
+
 /* Bytes of device workspace MSL_OP_SEG_LOSS needs for B slices, A anchors and at most n_max instances per slice (negative = error). */
 int64_t msl_seg_loss_workspace(int32_t B, int32_t A, int32_t n_max);
 

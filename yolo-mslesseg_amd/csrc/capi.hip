@@ -230,4 +230,61 @@ int msl_event_destroy(void* ev) {
   return MSL_OK;
 }
 
+// ---- typed entry points: plain arguments instead of the generic descriptor, for callers other than the Python host.  Each fills the
+// descriptor of its op (slot lists in include/mslesseg_hip.h) and dispatches it; same conventions (device pointers, asynchronous, 0 / MSL_E*).
+int msl_conv2d_nhwc(const void* x, const void* w_gemm, const float* bias, const void* res, void* y, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                    int32_t k, int32_t stride, int32_t act_silu, int32_t out_f32, int32_t dtype, void* stream) {
+  if (k != 1 && k != 3) { msl_set_error("msl_conv2d_nhwc: k must be 1 or 3"); return MSL_EINVAL; }
+  if (stride != 1 && stride != 2) { msl_set_error("msl_conv2d_nhwc: stride must be 1 or 2"); return MSL_EINVAL; }
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  const int pad = k / 2, kstep = dtype == MSL_F32 ? 16 : 32, K = k * k * Cin;
+  op.kind = MSL_OP_CONV; op.dtype = dtype;
+  op.p[0] = (void*)x; op.p[1] = (void*)w_gemm; op.p[2] = (void*)bias; op.p[3] = (void*)res; op.p[4] = y;
+  op.i[0] = N; op.i[1] = H; op.i[2] = W; op.i[3] = Cin; op.i[4] = (H + 2 * pad - k) / stride + 1; op.i[5] = (W + 2 * pad - k) / stride + 1; op.i[6] = Cout;
+  op.i[7] = k; op.i[8] = stride; op.i[9] = pad; op.i[10] = Cin; op.i[11] = 0; op.i[12] = Cout; op.i[13] = 0; op.i[14] = Cout; op.i[15] = 0;
+  op.i[16] = K; op.i[17] = (K + kstep - 1) / kstep * kstep; op.i[18] = act_silu ? 1 : 0; op.i[19] = out_f32 ? 1 : 0; op.i[21] = (Cout + 15) / 16 * 16;
+  return dispatch(op, (hipStream_t)stream);
+}
+
+int msl_letterbox_u8(const uint8_t* src, const int32_t* xtab, const int32_t* ytab, uint8_t* dst, int32_t N, int32_t H0, int32_t W0, int32_t channels, int32_t Hn, int32_t Wn,
+                     int32_t top, int32_t left, int32_t Hlb, int32_t Wlb, int32_t pad_value, void* stream) {
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_LETTERBOX; op.dtype = MSL_F32;
+  op.p[0] = (void*)src; op.p[1] = (void*)xtab; op.p[2] = (void*)ytab; op.p[4] = dst;
+  op.i[0] = N; op.i[1] = H0; op.i[2] = W0; op.i[3] = channels; op.i[4] = Hn; op.i[5] = Wn; op.i[6] = top; op.i[7] = left; op.i[8] = Hlb; op.i[9] = Wlb;
+  op.i[10] = pad_value; op.i[11] = (Hn != H0 || Wn != W0) ? 1 : 0;
+  return dispatch(op, (hipStream_t)stream);
+}
+
+int msl_nms(const float* pred, int32_t* keep_idx, int32_t* keep_cnt, float* det, int32_t N, int32_t A, int32_t max_det, float conf_thres, float iou_thres, void* stream) {
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_NMS; op.dtype = MSL_F32;
+  op.p[0] = (void*)pred; op.p[1] = keep_idx; op.p[2] = keep_cnt; op.p[3] = det;
+  op.i[0] = N; op.i[6] = A; op.i[7] = max_det; op.f[0] = conf_thres; op.f[1] = iou_thres;
+  return dispatch(op, (hipStream_t)stream);
+}
+
+int msl_volume_consensus(const float* axial, const float* coronal, const float* sagital, uint8_t* out, int64_t voxels, int32_t umbral, void* stream) {
+  if (voxels <= 0) { msl_set_error("msl_volume_consensus: no voxels"); return MSL_EINVAL; }
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_VOL_CONSENSUS; op.dtype = MSL_F32;
+  op.p[0] = (void*)axial; op.p[1] = (void*)coronal; op.p[2] = (void*)sagital; op.p[4] = out;
+  op.i[0] = (int32_t)(voxels & 0x7FFFFFFF); op.i[1] = (int32_t)(voxels >> 31); op.i[2] = umbral;
+  return dispatch(op, (hipStream_t)stream);
+}
+
+int msl_volume_dice_sums(const uint8_t* gt, const uint8_t* pred, uint64_t* sums3, int64_t voxels, void* stream) {
+  if (voxels <= 0) { msl_set_error("msl_volume_dice_sums: no voxels"); return MSL_EINVAL; }
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_VOL_DICE; op.dtype = MSL_F32;
+  op.p[0] = (void*)gt; op.p[1] = (void*)pred; op.p[4] = sums3;
+  op.i[0] = (int32_t)(voxels & 0x7FFFFFFF); op.i[1] = (int32_t)(voxels >> 31);
+  return dispatch(op, (hipStream_t)stream);
+}
+
 }  // extern "C"

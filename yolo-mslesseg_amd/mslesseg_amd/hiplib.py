@@ -23,7 +23,7 @@ OP_SEG_LOSS, OP_ATTENTION_BWD, OP_SLICE_EXTRACT, OP_SGD, OP_AUGMENT, OP_RASTER_M
 EXPORTS = (
     "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_launch",
     "msl_graph_destroy", "msl_event_create", "msl_event_record", "msl_event_elapsed_ms", "msl_event_destroy",
-    "msl_seg_loss_workspace",
+    "msl_seg_loss_workspace", "msl_conv2d_nhwc", "msl_letterbox_u8", "msl_nms", "msl_volume_consensus", "msl_volume_dice_sums",
 )
 
 
@@ -67,6 +67,12 @@ def lib() -> C.CDLL:
         L.msl_event_destroy.argtypes = [C.c_void_p]
         L.msl_seg_loss_workspace.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.msl_seg_loss_workspace.restype = C.c_int64
+        # typed entry points (plain arguments; the Python host itself goes through descriptors — these are exercised by tests/test_gpu_capi_typed.py)
+        L.msl_conv2d_nhwc.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 10 + [C.c_void_p]
+        L.msl_letterbox_u8.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 11 + [C.c_void_p]
+        L.msl_nms.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_float, C.c_void_p]
+        L.msl_volume_consensus.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_void_p]
+        L.msl_volume_dice_sums.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]
         if L.msl_abi_version() != 1:
             raise MslError(f"ABI version mismatch: library {L.msl_abi_version()}, binding 1")
         _lib = L
