@@ -61,3 +61,34 @@ def test_trainer_epoch_through_the_device_feeder(tmp_path):
     rows = list(csv.DictReader(open(tmp_path / "f" / "results.csv")))
     tot = [sum(float(r[k]) for k in ("train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss")) for r in rows]
     assert len(rows) == 6 and all(np.isfinite(tot)) and tot[-1] < tot[0]
+
+
+def test_dataset_cache_is_resized_on_the_device_with_the_same_bytes(demo_volumes, tmp_path):
+    """`cache=True`: raw slices are uploaded and resized to the long-side-640 cache by MSL_OP_AUGMENT (one tile, the resize affine, border 0) —
+    byte-equal to data.resize_keep_ratio on the host, for grey slices of the three plane shapes and for a colour image read from PNG files."""
+    from mslesseg_amd import pngio
+
+    ds = D.VolumeSliceDataset(demo_volumes["P39_flair"], demo_volumes["P39_mask"], keep=lambda plano, i: i % 20 == 0)
+    cache = A.SliceCache(ds, "cuda:0")
+    buf = cache.buf.cpu().numpy()
+    shapes = set()
+    for i in range(len(ds)):
+        img, _ = ds.get(i)  # host resize
+        h, w = img.shape[:2]
+        shapes.add((h, w))
+        assert (cache.h[i], cache.w[i]) == (h, w)
+        assert np.array_equal(buf[cache.off[i] : cache.off[i] + h * w * 3].reshape(h, w, 3), img), i
+    assert len(shapes) == 3
+    rng = np.random.default_rng(0)
+    (tmp_path / "images").mkdir()
+    (tmp_path / "labels").mkdir()
+    for k, (h, w) in enumerate([(182, 218), (100, 37), (640, 640)]):
+        pngio.write_png(tmp_path / "images" / f"c{k}.png", rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        (tmp_path / "labels" / f"c{k}.txt").write_text("0 0.1 0.1 0.5 0.1 0.5 0.6\n")
+    ds2 = D.SegDataset(tmp_path)
+    c2 = A.SliceCache(ds2, "cuda:0")
+    b2 = c2.buf.cpu().numpy()
+    for i in range(3):
+        img, inst = ds2.get(i)
+        h, w = img.shape[:2]
+        assert np.array_equal(b2[c2.off[i] : c2.off[i] + h * w * 3].reshape(h, w, 3), img) and len(inst) == 1

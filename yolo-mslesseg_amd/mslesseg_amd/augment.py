@@ -40,20 +40,29 @@ class SliceCache:
     """A dataset's slices as one flat uint8 device buffer + its labels as ragged arrays (pixel coordinates of the cached slice)."""
 
     def __init__(self, ds, device=None):
-        """`device=None`: labels only, nothing is uploaded (the host half of the feeder can then be exercised without a GPU)."""
+        """`device=None`: labels only, nothing is uploaded (the host half of the feeder can then be exercised without a GPU).  A dataset that
+        keeps its slices raw (`ds.raw`, data._SliceDataset) is resized to the long-side-`imgsz` cache ON THE DEVICE — the raw slices are a few
+        dozen KB each; the host resize is 30-80 ms per slice and was the largest cost of starting a training."""
         self.device = torch.device(device) if device is not None else None
         n = len(ds)
         self.n = n
         self.h, self.w = np.zeros(n, np.int64), np.zeros(n, np.int64)
         self.off = np.zeros(n, np.int64)
+        raw = getattr(ds, "raw", None) if self.device is not None else None
         chunks, cls, pts, pcount, icount = [], [], [], [], []
         pos = 0
         for i in range(n):
-            img, inst = ds.get(i)
-            assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
-            self.h[i], self.w[i], self.off[i] = img.shape[0], img.shape[1], pos
-            chunks.append(np.ascontiguousarray(img).reshape(-1))
-            pos += img.size
+            if raw is not None:
+                nh, nw = ds.resized_shape(i)
+                inst = [(c, p * np.array([nw, nh], dtype=np.float32)) for c, p in raw[i][1]]
+                self.h[i], self.w[i], self.off[i] = nh, nw, pos
+                pos += nh * nw * 3
+            else:
+                img, inst = ds.get(i)
+                assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+                self.h[i], self.w[i], self.off[i] = img.shape[0], img.shape[1], pos
+                chunks.append(np.ascontiguousarray(img).reshape(-1))
+                pos += img.size
             k = 0
             for c, p in inst:
                 p = np.asarray(p, np.float32).reshape(-1, 2)
@@ -64,11 +73,46 @@ class SliceCache:
                     k += 1
             icount.append(k)
         self.nbytes = pos
-        self.buf = torch.from_numpy(np.concatenate(chunks)).to(self.device) if self.device is not None else None
+        if raw is not None:
+            self.buf = self._resize_on_device(ds, raw)
+        else:
+            self.buf = torch.from_numpy(np.concatenate(chunks)).to(self.device) if self.device is not None else None
         self.cls = np.asarray(cls, np.float32)
         self.pts = np.concatenate(pts, 0) if pts else np.zeros((0, 2), np.float32)
         self.poly_off = np.concatenate([[0], np.cumsum(pcount)]).astype(np.int64)
         self.item_off = np.concatenate([[0], np.cumsum(icount)]).astype(np.int64)
+
+    def _resize_on_device(self, ds, raw) -> torch.Tensor:
+        """Raw slices → the cache, one MSL_OP_AUGMENT launch per raw shape: a single tile (the raw slice), the inverse resize affine of
+        data.resize_geometry, border 0 — the float64 arithmetic of data.resize_keep_ratio, hence the same bytes."""
+        buf = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+        groups: Dict[tuple, list] = {}
+        for i in range(self.n):
+            groups.setdefault(tuple(raw[i][0].shape[:2]), []).append(i)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for (h, w), idx in groups.items():
+            nh, nw, _, Mi = D.resize_geometry(h, w, ds.imgsz)
+            for c0 in range(0, len(idx), 1024):
+                part = idx[c0 : c0 + 1024]
+                src = torch.from_numpy(np.stack([np.ascontiguousarray(raw[i][0]) for i in part])).to(self.device)
+                out = torch.empty(len(part), nh, nw, 3, dtype=torch.uint8, device=self.device)
+                rec = np.zeros((len(part), REC), np.int64)
+                recf = rec.view(np.float64)
+                recf[:, 0:6] = (Mi[0, 0], Mi[0, 1], Mi[0, 2], Mi[1, 0], Mi[1, 1], Mi[1, 2])
+                recf[:, 6] = 1.0
+                rec[:, 7:13] = (0, 1, w, h, 0, 0)
+                rec[:, 16:24] = np.stack([np.arange(len(part)) * (h * w * 3), np.full(len(part), w), np.zeros(len(part), np.int64), np.zeros(len(part), np.int64),
+                                          np.full(len(part), w), np.full(len(part), h), np.zeros(len(part), np.int64), np.zeros(len(part), np.int64)], 1)
+                recd = torch.from_numpy(rec).to(self.device)
+                if (nh, nw) == (h, w):
+                    out.copy_(src)
+                else:
+                    hiplib.launch(hiplib.make_op(hiplib.OP_AUGMENT, hiplib.MSL_F32, p=(src.data_ptr(), recd.data_ptr(), 0, 0, out.data_ptr()), i={0: len(part), 1: nh, 2: nw}), st)
+                flat = out.reshape(len(part), -1)
+                for j, i in enumerate(part):
+                    buf[self.off[i] : self.off[i] + nh * nw * 3] = flat[j]
+                torch.cuda.synchronize(self.device)  # src / recd are released after the launch has consumed them
+        return buf
 
 
 class DeviceAugmenter:

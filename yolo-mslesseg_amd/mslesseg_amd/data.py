@@ -65,17 +65,25 @@ def warp_affine(img: np.ndarray, M: np.ndarray, out_hw: Tuple[int, int], border:
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
+def resize_geometry(h: int, w: int, size: int):
+    """Long side → `size`, aspect kept [UPSTREAM BaseDataset.load_image]: → (nh, nw, M 2x3, Mi 3x3); the inverse in closed form, so that the host
+    restatement and the device resize (augment.SliceCache) use the very same coefficients."""
+    r = size / max(h, w)
+    nh, nw = (h, w) if r == 1 else (max(int(round(h * r)), 1), max(int(round(w * r)), 1))
+    sx, sy = nw / w, nh / h
+    M = np.array([[sx, 0, (sx - 1) * 0.5], [0, sy, (sy - 1) * 0.5]], dtype=np.float64)
+    Mi = np.array([[1.0 / sx, 0.0, -M[0, 2] / sx], [0.0, 1.0 / sy, -M[1, 2] / sy], [0.0, 0.0, 1.0]])
+    return nh, nw, M, Mi
+
+
 def resize_keep_ratio(img: np.ndarray, size: int) -> np.ndarray:
     h, w = img.shape[:2]
-    r = size / max(h, w)
-    if r == 1:
+    if size == max(h, w):
         return img
-    nh, nw = max(int(round(h * r)), 1), max(int(round(w * r)), 1)
-    M = np.array([[nw / w, 0, (nw / w - 1) * 0.5], [0, nh / h, (nh / h - 1) * 0.5]], dtype=np.float64)
+    nh, nw, M, Mi = resize_geometry(h, w, size)
     if img.shape[2] == 3 and np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2]):
-        return np.repeat(warp_affine(img[..., :1], M, (nh, nw), border=0), 3, axis=2)  # grey slices: one channel warped, same bytes
-    return warp_affine(img, M, (nh, nw), border=0)
-
+        return np.repeat(warp_affine(img[..., :1], M, (nh, nw), border=0, Mi=Mi), 3, axis=2)  # grey slices: one channel warped, same bytes
+    return warp_affine(img, M, (nh, nw), border=0, Mi=Mi)
 
 
 # ------------------------------------------------------------------------------------------------- label geometry (shared by the per-sample
@@ -127,44 +135,61 @@ def flatten_instances(inst):
 
 
 # ------------------------------------------------------------------------------------------------- dataset
-class SegDataset:
-    """Images are cached in RAM as uint8 [H,W,3] resized so that the long side is IMGSZ (cache=True, REF train.py:362)."""
+class _SliceDataset:
+    """Raw slices + normalised polygons; the long-side-`imgsz` resize happens where it is cheap: on the device when the trainer caches the
+    dataset in HBM (augment.SliceCache reads `raw`), lazily on the host otherwise (`get`, memoised)."""
+
+    def __init__(self, imgsz: int):
+        self.imgsz = imgsz
+        self.raw: List[Tuple[np.ndarray, list]] = []  # (uint8 [h,w,3] RGB as read, [(cls, normalised polygon)])
+        self._resized: Dict[int, np.ndarray] = {}
+
+    def __len__(self):
+        return len(self.raw)
+
+    def resized_shape(self, i) -> Tuple[int, int]:
+        h, w = self.raw[i][0].shape[:2]
+        nh, nw, _, _ = resize_geometry(h, w, self.imgsz)
+        return nh, nw
+
+    def get(self, i):
+        if i not in self._resized:
+            self._resized[i] = resize_keep_ratio(self.raw[i][0], self.imgsz)
+        img = self._resized[i]
+        h, w = img.shape[:2]
+        return img, [(c, p * np.array([w, h], dtype=np.float32)) for c, p in self.raw[i][1]]  # polygons in pixels
+
+
+class SegDataset(_SliceDataset):
+    """`images/*.png` + `labels/*.txt` of one split, read into RAM (cache=True, REF train.py:362)."""
 
     def __init__(self, root, imgsz: int = IMGSZ):
+        super().__init__(imgsz)
         root = Path(root)
         self.im_files = sorted((root / "images").glob("*.png"))
         if not self.im_files:
             raise FileNotFoundError(f"no PNG images under {root / 'images'}")
-        self.imgsz = imgsz
-        self.items = []
         from .pngio import read_bgr
 
         for f in self.im_files:
             rgb = np.ascontiguousarray(read_bgr(f)[..., ::-1])
             inst = L.read_label_file(root / "labels" / (f.stem + ".txt"))
-            self.items.append((resize_keep_ratio(rgb, imgsz), [(c, p.copy()) for c, p in inst]))
-
-    def __len__(self):
-        return len(self.items)
-
-    def get(self, i):
-        img, inst = self.items[i]
-        h, w = img.shape[:2]
-        return img, [(c, p * np.array([w, h], dtype=np.float32)) for c, p in inst]  # polygons in pixels
+            self.raw.append((rgb, [(c, p.copy()) for c, p in inst]))
 
 
-class VolumeSliceDataset:
+class VolumeSliceDataset(_SliceDataset):
     """The dataset `extraer_dataset` would stage for one patient volume, built in memory: per plane the lesion-bearing slices
     (`volume.select_slices` = Paciente.indices_a_usar), each rendered like `plt.imsave(corte.T, cmap="gray", origin="lower")` + `cv2.imread`
     (`volume.slice_as_png_array`), its GT mask cut the same way and traced into polygons like `convert_segment_masks_to_yolo_seg` writes them
-    (normalised, 6 decimals) [REF scripts/extraer_dataset.py:174-227, utils/Paciente.py:281-295].  Items are what `SegDataset` caches."""
+    (normalised, 6 decimals) [REF scripts/extraer_dataset.py:174-227, utils/Paciente.py:281-295]."""
 
     def __init__(self, flair: np.ndarray, mask: np.ndarray, planes=("axial", "coronal", "sagital"), num_cortes=None, mejora=None, imgsz: int = IMGSZ,
                  keep=None):
         from . import volume as V
         from .enhance import aplicar_mejora
 
-        self.imgsz, self.items, self.index = imgsz, [], []
+        super().__init__(imgsz)
+        self.index = []
         for plano in planes:
             for i in V.select_slices(mask, plano, num_cortes):
                 if keep is not None and not keep(plano, i):
@@ -176,16 +201,8 @@ class VolumeSliceDataset:
                 for c in L.find_external_contours(m):
                     if len(c) >= 3:
                         inst.append((0, np.stack([np.round(c[:, 0] / w, 6), np.round(c[:, 1] / h, 6)], 1).astype(np.float32)))
-                self.items.append((resize_keep_ratio(np.ascontiguousarray(png[..., ::-1]), imgsz), inst))
+                self.raw.append((np.ascontiguousarray(png[..., ::-1]), inst))
                 self.index.append((plano, i))
-
-    def __len__(self):
-        return len(self.items)
-
-    def get(self, i):
-        img, inst = self.items[i]
-        h, w = img.shape[:2]
-        return img, [(c, p * np.array([w, h], dtype=np.float32)) for c, p in inst]
 
 
 class SyntheticSegDataset:
