@@ -169,12 +169,17 @@ class SegDataset(_SliceDataset):
         self.im_files = sorted((root / "images").glob("*.png"))
         if not self.im_files:
             raise FileNotFoundError(f"no PNG images under {root / 'images'}")
+        from concurrent.futures import ThreadPoolExecutor
+
         from .pngio import read_bgr
 
-        for f in self.im_files:
+        def load(f):
             rgb = np.ascontiguousarray(read_bgr(f)[..., ::-1])
             inst = L.read_label_file(root / "labels" / (f.stem + ".txt"))
-            self.raw.append((rgb, [(c, p.copy()) for c, p in inst]))
+            return rgb, [(c, p.copy()) for c, p in inst]
+
+        with ThreadPoolExecutor(max_workers=8) as ex:  # zlib and the NumPy filters release the GIL; order = sorted file order
+            self.raw = list(ex.map(load, self.im_files))
 
 
 class VolumeSliceDataset(_SliceDataset):
