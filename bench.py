@@ -421,15 +421,21 @@ def train_e2e_bench(args, dev, rank, world, state, B):
 
     class Repeat:
         def __init__(self, ds, k):
-            self.ds, self.k = ds, k
+            self.ds, self.k, self.imgsz = ds, k, ds.imgsz
+            self.raw = [ds.raw[i % len(ds)] for i in range(len(ds) * k)] if not args.host_augment else None  # raw slices: resized on the device
 
         def __len__(self):
             return len(self.ds) * self.k
+
+        def resized_shape(self, i):
+            return self.ds.resized_shape(i % len(self.ds))
 
         def get(self, i):
             return self.ds.get(i % len(self.ds))
 
     ds = Repeat(base, 8)
+    if args.host_augment:
+        del ds.raw
     y = YOLO.__new__(YOLO)
     y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
     y.dtype = y.train_dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
