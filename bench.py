@@ -9,7 +9,10 @@ one batch of synthetic slices already resident in HBM: weight pack → HIP forwa
 → HIP backward → [all-reduce of the flat gradient over ranks] → gradient clip + fused AdamW + EMA.  Nothing is skipped.
 Slices shard over ranks (data parallel); the only collective is the one gradient all-reduce → "scaling": "weak".
 `--mode predict` times the inference leg instead (LetterBox → net → NMS → masks → merged uint8 slices); in train mode a short
-predict run is reported alongside under "infer".  Rank 0 prints ONE JSON line.  The oracle is imported only for cpu_baseline.
+predict run in both arithmetic modes (fp32 = the exact default of YOLO() predict, bf16 = the throughput mode) is reported under "infer".
+`--mode train-e2e` feeds the same step from the data feeder on real FLAIR slices (mosaic on) and reports the resident-batch rate of the same
+trainer beside it; `--mode replicas` runs independent trainings without a collective (the reference's fold x plane jobs); `--scale s` switches to
+YOLO11s-seg (BASELINE configs[2]).  Rank 0 prints ONE JSON line.  The oracle is imported only for cpu_baseline.
 """
 import argparse
 import json

@@ -1,4 +1,6 @@
-"""Training data: YOLO-seg datasets as the reference lays them out, host-side augmentation, batch collation.
+"""Training data: YOLO-seg datasets as the reference lays them out, and the NumPy restatement of the augmentation + batch collation that the
+device feeder (augment.py) is checked against byte for byte.  The trainer uses the device feeder; this path stays selectable
+(`device_augment=False`) and is what `bench.py --mode train-e2e --host-augment` measures (24 slices/s against 4 400).
 
 Dataset layout consumed [REF yolo_mslesseg/scripts/train.py:221-338]: a YAML with absolute `train:` / `val:` dirs, each holding
 `images/<stem>.png` and `labels/<stem>.txt` (class + normalised polygon per line).  Augmentation follows the resolved

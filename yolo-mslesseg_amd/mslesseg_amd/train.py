@@ -6,7 +6,12 @@
 Resolved hyper-parameters are those frozen in the reference's args.yaml [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/
 fold1/args.yaml]: imgsz 640, nbs 64, seed 0, warmup 3 epochs, close_mosaic 10, weight_decay 5e-4, optimizer 'auto' → AdamW
 lr0 = round(0.002*5/(4+nc), 6), beta1 0.9, warm-up from 0 for every group — the schedule the 25 results.csv files pin
-(tests/test_oracle_pins.py KAT #1).  Gradient clip 10, ModelEMA(0.9999, tau 2000) [UPSTREAM engine/trainer.py].
+(tests/test_oracle_pins.py KAT #1; beyond 10 000 iterations 'auto' takes SGD + Nesterov, lr 0.01, which no run of the reference reaches).
+Gradient clip 10, ModelEMA(0.9999, tau 2000) [UPSTREAM engine/trainer.py].
+
+Data: the slice cache of `cache=True` lives in HBM and every batch is augmented there (augment.py: mosaic, scale / translate warp, value gain,
+flip, mask rasterisation — two launches, one batch ahead on a side stream); a host thread only draws the random numbers and does the label
+geometry.  Validation: once per epoch, eval mode, EMA weights, the whole held-out fold — val/* losses and box / mask P, R, mAP from one pass.
 
 One process per GPU.  Data parallelism = ONE RCCL all-reduce(SUM) of the flat gradient buffer per optimizer step
 (ultralytics scales the loss by world_size and lets DDP average: the same sum); BatchNorm statistics stay per-rank
