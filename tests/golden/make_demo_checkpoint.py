@@ -2,7 +2,8 @@
 """Train YOLO11n-seg on the lesion slices of the reference's demo patient P39 (the only real FLAIR volume available here) and write the
 checkpoint the trained-weights parity tests use (tests/golden/demo_p39_n.pt).
 
-    python scripts/train_demo_checkpoint.py --precision bf16 --epochs 40 --out gpurun_out/demo_ckpt        (GPU box)
+    python tests/golden/make_demo_checkpoint.py --precision bf16 --epochs 80 --batch 16 --augment 1 --out gpurun_out/demo_ckpt   (GPU box;
+    then copy gpurun_out/demo_ckpt/demo_p39_n_bf16.pt to tests/golden/demo_p39_n.pt)
 
 The dataset is what `extraer_dataset` stages for that patient [REF scripts/extraer_dataset.py:174-227]: every lesion-bearing slice of the
 three planes (101 axial + 147 coronal + 113 sagittal), rendered like `plt.imsave` + `cv2.imread`, polygons traced from the GT mask — built
@@ -16,7 +17,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 for p in (str(ROOT), str(ROOT / "yolo-mslesseg_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -80,7 +80,7 @@ def test_s_train_forward_backward_fp32_matches_oracle_autograd(s_state):
 def test_s_trainer_step_bf16_640_batch16_against_fp32_engine():
     """The benchmarked shape family at scale s: 640x640, batch 16, bf16 kernels (LDS 3x3 / persistent / streaming 1x1 / transposed-read wgrad at
     the s widths) against the fp32 engine from the same seeded initial weights.  An UNTRAINED network amplifies the bf16 rounding of its
-    activations from layer to layer (measured against the oracle's autograd at 640x640, scripts/dev_grad_diag.py s_init: fp32 engine cosine
+    activations from layer to layer (measured against the oracle's autograd at 640x640, tests/tools/dev_grad_diag.py s_init: fp32 engine cosine
     0.999999, bf16 engine 0.82 — already 0.93 one layer below the probe), so the whole-network bound here is loose; the s-width kernels are
     checked one by one against PyTorch references in tests/test_gpu_ops.py (the "YOLO11s-seg widths" cases) and the fp32 engine above."""
     from mslesseg_amd import data as D

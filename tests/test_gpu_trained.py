@@ -1,5 +1,5 @@
 """Parity on a TRAINED network and real FLAIR slices (-m gpu): the checkpoint tests/golden/demo_p39_n.pt was trained by this library's own
-trainer on the lesion slices of the reference's demo patient P39 (scripts/train_demo_checkpoint.py; 80 epochs, mosaic augmentation from the
+trainer on the lesion slices of the reference's demo patient P39 (tests/golden/make_demo_checkpoint.py; 80 epochs, mosaic augmentation from the
 device feeder, bf16 train engine, every 5th slice held out: mask mAP50 0.75 on those; weights stored bf16-exact) and is the well-conditioned counterpart of the calibrated-random test weights.
 
 north_star tolerance (BASELINE.json): bit-exact indices after NMS, reconstructed-volume Dice within 1e-4 of the CPU reference.

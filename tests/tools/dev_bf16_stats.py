@@ -2,7 +2,7 @@
 import sys
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path[:0] = [str(ROOT), str(ROOT / "yolo-mslesseg_amd")]
 from mslesseg_amd import engine as E
 from mslesseg_amd.hiplib import MSL_BF16, MSL_F32

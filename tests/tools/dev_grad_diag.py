@@ -6,7 +6,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path[:0] = [str(ROOT), str(ROOT / "yolo-mslesseg_amd"), str(ROOT / "tests")]
 from mslesseg_amd.hiplib import MSL_BF16, MSL_F32  # noqa: E402
 from test_gpu_train import _oracle_run, _probe, _run_plan  # noqa: E402

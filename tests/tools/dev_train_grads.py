@@ -2,7 +2,7 @@
 import sys
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path[:0] = [str(ROOT), str(ROOT / "yolo-mslesseg_amd"), str(ROOT / "tests")]
 import test_gpu_train as T
 from mslesseg_amd.hiplib import MSL_F32

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Engines (fp32 / bf16 / mixed) against the CPU oracle on a TRAINED checkpoint and real FLAIR slices (run on the GPU box).
 
-    python scripts/precision_report.py --ckpt tests/golden/demo_p39_n.pt --out gpurun_out/precision.json [--stride 1] [--modes fp32,bf16]
+    python tests/tools/precision_report.py --ckpt tests/golden/demo_p39_n.pt --out gpurun_out/precision.json [--stride 1] [--modes fp32,bf16]
 
 For every plane of demo patient P39: the reference's slice set (`volume.select_slices`), rendered slices, then per engine
   kept-index agreement with the oracle (identical ordered list / same set / count), bytes of the merged re-oriented mask that differ,
@@ -13,7 +13,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 for p in (str(ROOT), str(ROOT / "yolo-mslesseg_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -636,7 +636,7 @@ class TrainPlan(graph.Visitor):
         if res is not None and out is not None and res.t is out.t and res.co == out.co:
             # the walk asks for `out = res + dw(x)` in place (Attention: x = attn + pe(v) over the attention output).  Training must keep the
             # attention output: its backward needs O itself (D_i = dO_i . O_i); overwriting it fed O + pe(v) to MSL_OP_ATTENTION_BWD and corrupted
-            # the qkv gradient and everything upstream of C2PSA (found with scripts/dev_grad_diag.py at 400 tokens) — a buffer of its own instead.
+            # the qkv gradient and everything upstream of C2PSA (found with tests/tools/dev_grad_diag.py at 400 tokens) — a buffer of its own instead.
             out = None
         y = out if out is not None else self._new(x.H, x.W, C)
         z = self._new(x.H, x.W, C)
