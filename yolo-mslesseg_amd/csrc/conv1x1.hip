@@ -31,13 +31,18 @@ struct C1Args {
                       // pixel (y, x) goes to channel c of pixel (2y + dy, 2x + dx) of the 2H x 2W output (same contract as conv_igemm's store mode 1)
 };
 
-template <int NCP, bool STATS, int PT>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
+// F32: fp32 tensors (the parity engine, the default of predict): the same stream with 16-byte fragments of 4 floats and four
+// v_mfma_f32_16x16x4_f32 per K-step of 16 (lane group g holds channels 4g..4g+3 of the step, MFMA i contracts element i of every group — the
+// k-permutation conv_igemm uses, an exact fp32 fma chain).  The generic kernel these layers used before has no LDS staging: 2-4 TB/s.
+template <int NCP, bool STATS, int PT, bool F32 = false>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
 __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 waves: 8 when the weight matrix is large, so that fewer LDS copies of it buy more pixels in flight per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4, NW = blockDim.x >> 6;
-  const int KS = a.Kpad >> 5;
-  const int pitch = a.Kpad * 2 + 16, cps = pitch >> 4;  // bytes / 16-byte chunks per LDS row (x pixels and weight rows alike)
+  constexpr int ES = F32 ? 4 : 2, EPC = 16 / ES, KSTEP = F32 ? 16 : 32;   // element bytes, elements per 16-byte chunk, channels per K-step
+  static_assert(!(F32 && STATS), "the statistics epilogue is the bf16 training path");
+  const int KS = a.Kpad / KSTEP;
+  const int pitch = a.Kpad * ES + 16, cps = pitch >> 4;  // bytes / 16-byte chunks per LDS row (x pixels and weight rows alike)
   constexpr int SP = PT * 16;                                        // pixels per slice
   const int w_bytes = ((NCP * 32 * cps + 63) & ~63) * 16;            // LDS regions are whole 64-chunk DMA pieces
   const int slice_chunks = SP * cps, slice_bytes = ((slice_chunks + 63) & ~63) * 16;
@@ -46,17 +51,17 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 
   // ---- weights → LDS (rows >= w_rows and the pad chunk read the zero page)
   {
-    const int total = NCP * 32 * cps, kchunks = a.Kpad >> 3;
+    const int total = NCP * 32 * cps, kchunks = a.Kpad / EPC;
     for (int c0 = threadIdx.x & ~63; c0 < total; c0 += blockDim.x) {
       const int cidx = c0 + lane, row = cidx / cps, ch = cidx - row * cps;
       const bool ok = cidx < total && row < a.w_rows && ch < kchunks;
-      const char* src = ok ? a.w + ((long)row * a.Kpad + ch * 8) * 2 : (const char*)c1_zero_page;
+      const char* src = ok ? a.w + ((long)row * a.Kpad + ch * EPC) * ES : (const char*)c1_zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_w + (long)c0 * 16), 16, 0, 0);
     }
   }
   const long tiles = (a.M + SP - 1) / SP;
   const long stride = (long)gridDim.x * NW;
-  const int xchunks = a.Cin >> 3;
+  const int xchunks = a.Cin / EPC;
 
   auto stage = [&](long tile, int buf) __attribute__((always_inline)) {
     unsigned char* dst = s_x + buf * slice_bytes;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
     for (int c0 = 0; c0 < slice_chunks; c0 += 64) {
       const int cidx = c0 + lane, px = cidx / cps, ch = cidx - px * cps;
       const bool ok = cidx < slice_chunks && ch < xchunks && p0 + px < a.M;
-      const char* src = ok ? a.x + ((p0 + px) * a.x_cs + a.x_co + ch * 8) * 2 : (const char*)c1_zero_page;
+      const char* src = ok ? a.x + ((p0 + px) * a.x_cs + a.x_co + ch * EPC) * ES : (const char*)c1_zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + c0 * 16), 16, 0, 0);
     }
   };
@@ -97,18 +102,34 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[pt][c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < KS; ++ks) {
-      const int kb = (ks * 32 + 8 * g) * 2;
-      bf16x8 bfr[PT];
+      const int kb = (ks * KSTEP + EPC * g) * ES;  // 16 bytes per lane either way
+      if constexpr (F32) {
+        f32x4 bfr[PT];
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const bf16x8*)(xs + (pt * 16 + li) * pitch + kb);
+        for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const f32x4*)(xs + (pt * 16 + li) * pitch + kb);
 #pragma unroll
-      for (int c = 0; c < NCP; ++c)
+        for (int c = 0; c < NCP; ++c)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const bf16x8 af = *(const bf16x8*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb);
+          for (int m = 0; m < 2; ++m) {
+            const f32x4 af = *(const f32x4*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb);
 #pragma unroll
-          for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
-        }
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[pt][i], acc[pt][c][m], 0, 0, 0);
+          }
+      } else {
+        bf16x8 bfr[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const bf16x8*)(xs + (pt * 16 + li) * pitch + kb);
+#pragma unroll
+        for (int c = 0; c < NCP; ++c)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const bf16x8 af = *(const bf16x8*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
+          }
+      }
     }
     // ---- epilogue: lane (li, g) holds channels c*32 + 8g .. +7 of pixel p0 + 16*pt + li
 #pragma unroll
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
         }
         if (a.res) {
           float rv[8];
-          ldv<false, 8>(a.res, p * a.res_cs + a.res_co + c0, rv);
+          ldv<F32, 8>(a.res, p * a.res_cs + a.res_co + c0, rv);
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] += rv[r];
         }
@@ -151,7 +172,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
           const int r = (int)(p - n * a.H * a.W), oy = r / a.W, ox = r - oy * a.W;
           oi = ((n * (2 * a.H) + 2 * oy + (q >> 1)) * (2 * a.W) + 2 * ox + (q & 1)) * a.y_cs + a.y_co + (c0 - q * C4);
         }
-        if (a.out_f32) stv<true, 8>(a.y, oi, v);
+        if (F32 || a.out_f32) stv<true, 8>(a.y, oi, v);
         else stv<false, 8>(a.y, oi, v);
       }
     }
@@ -188,8 +209,8 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 }
 
 // ---- host
-static size_t c1_lds(int ncp, int Kpad, int pt, int nw = 4) {
-  const int cps = (Kpad * 2 + 16) / 16;
+static size_t c1_lds(int ncp, int Kpad, int pt, int nw = 4, int es = 2) {
+  const int cps = (Kpad * es + 16) / 16;
   return (size_t)(((ncp * 32 * cps + 63) & ~63) + 2 * nw * ((pt * 16 * cps + 63) & ~63)) * 16;
 }
 static const size_t C1_LDS_MAX = 150 * 1024;
@@ -197,22 +218,26 @@ static const size_t C1_LDS_MAX = 150 * 1024;
 // Eligibility test used by msl_launch_conv (bf16, 1x1, stride 1, pad 0, plain store, everything a multiple of 8, weights + rings fit in LDS)
 bool msl_conv1x1_eligible(const msl_op& op) {
   const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
-  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || (op.i[20] != 0 && op.i[20] != 1)) return false;
+  const bool f32 = op.dtype == MSL_F32;
+  if ((op.dtype != MSL_BF16 && !f32) || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || (op.i[20] != 0 && op.i[20] != 1)) return false;
   if (op.i[20] == 1 && (Cout % 32 || op.p[3] || op.p[5])) return false;  // pixel-shuffle store: whole 8-channel runs per quadrant, no residual / statistics
-  if (Cin % 8 || Cout % 8 || Kpad % 32 || Kpad < Cin || Cout > 256) return false;
-  if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) return false;
+  if (f32 && op.p[5]) return false;                                       // the statistics epilogue is bf16 only
+  if (Cin % (f32 ? 4 : 8) || Cout % 8 || Kpad % (f32 ? 16 : 32) || Kpad < Cin || Cout > 256) return false;
+  if ((op.i[10] | op.i[11]) & (f32 ? 3 : 7)) return false;
+  if ((op.i[12] | op.i[13]) & 7) return false;
   if (op.p[3] && ((op.i[14] | op.i[15]) & 7)) return false;
-  return c1_lds((Cout + 31) / 32, Kpad, 1) <= C1_LDS_MAX;
+  return c1_lds((Cout + 31) / 32, Kpad, 1, 4, f32 ? 4 : 2) <= C1_LDS_MAX;
 }
 
-template <int NCP, bool STATS, int PT>
+template <int NCP, bool STATS, int PT, bool F32 = false>
 static int c1_launch(const C1Args& a, hipStream_t s) {
+  constexpr int ES = F32 ? 4 : 2;
   // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
-  const int nw = (c1_lds(NCP, a.Kpad, PT, 4) * 3 > 160 * 1024 && c1_lds(NCP, a.Kpad, PT, 8) <= C1_LDS_MAX) ? 8 : 4;
-  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw);
+  const int nw = (c1_lds(NCP, a.Kpad, PT, 4, ES) * 3 > 160 * 1024 && c1_lds(NCP, a.Kpad, PT, 8, ES) <= C1_LDS_MAX) ? 8 : 4;
+  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const long tiles = (a.M + PT * 16 - 1) / (PT * 16);
@@ -221,9 +246,14 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   if (per_cu < 1) per_cu = 1;
   long blocks = (tiles + nw - 1) / nw;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
+  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
   MSL_CHECK_LAUNCH("conv1x1");
   return MSL_OK;
+}
+template <int NCP>
+static int c1_launch_f32(const C1Args& a, hipStream_t s) {
+  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true>(a, s);
+  return c1_launch<NCP, false, 1, true>(a, s);
 }
 template <int NCP, bool STATS>
 static int c1_launch_pt(const C1Args& a, hipStream_t s) {
@@ -247,6 +277,14 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + (a.shuffle ? a.Cout / 4 : a.Cout) <= a.y_cs, "conv1x1: bad dims / views");
   MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
+  if (op.dtype == MSL_F32) {
+#define C1F(N) case N: return c1_launch_f32<N>(a, s)
+    switch (ncp) {
+      C1F(1); C1F(2); C1F(3); C1F(4);
+      C1F(5); C1F(6); C1F(7); C1F(8);
+    }
+#undef C1F
+  }
 #define C1(N) case N: return a.acc ? c1_launch_pt<N, true>(a, s) : c1_launch_pt<N, false>(a, s)
 #define C1N(N) case N: return c1_launch_pt<N, false>(a, s)
   switch (ncp) {
