@@ -65,12 +65,19 @@ def dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # MSLESSEG_DIST_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (several ranks share a GPU, the
+    # collective stages through host memory); the measured configuration is always RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("MSLESSEG_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend == "gloo" else local
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
@@ -93,7 +100,7 @@ def timed(step, args, dev, world, dist):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
