@@ -607,8 +607,6 @@ def main():
             if not args.no_roofline and args.target_kept > 0:
                 # the same leg with the class bias left alone: every noise slice then keeps max_det = 300 instances (NMS and mask assembly saturated) —
                 # the tuned ~12-instance workload above is the realistic one (MS slices carry a handful of lesions), this is its worst case
-                del eng
-                torch.cuda.empty_cache()
                 sargs = argparse.Namespace(**{**vars(args), "target_kept": 0.0})
                 seng, simgs, _, _, _ = predict_setup(sargs, dev, rank, state, B)
                 for i in range(8):
@@ -620,7 +618,8 @@ def main():
                 sdt = (time.perf_counter() - t0) / 5
                 line["saturated_nms"] = {"value": round(B / sdt, 2), "unit": "slices/s (1 GPU)", "ms_per_step": round(sdt * 1e3, 3),
                                          "mean_kept_instances_per_slice": round(float(seng.plan(B, S, S).keep_cnt.float().mean().item()), 1)}
-                eng = seng
+                del seng, simgs
+                torch.cuda.empty_cache()
             line["slice_extract"] = None if args.no_roofline else slice_extract_bench(dev, host_sample=not args.no_cpu_baseline)
             line["volume_plane"] = None if args.no_roofline else volume_plane_bench(eng, dev)
     if rank == 0:
