@@ -177,3 +177,24 @@ def test_slice_to_png_array_shape_and_range(demo_volumes):
     img = P.slice_to_png_array(P.take_slice(fl, "axial", 90))
     assert img.shape == (218, 182, 3) and img.dtype == np.uint8 and img.max() == 255 and img.min() == 0
     assert (img[..., 0] == img[..., 1]).all()
+
+
+def test_fused_parameter_counts_equal_upstream_model_summaries():
+    """A second pin of the layer table, independent of the unfused counts: ultralytics prints "YOLO11n-seg summary (fused): 265 layers, 2,868,664
+    parameters" and "YOLO11s-seg summary (fused): 265 layers, 10,097,776 parameters" for the COCO (nc=80) models [UPSTREAM, recalled from the
+    published model summaries — the package is not in this image].  Fusing folds every BatchNorm into its conv: the affine pair (2C parameters)
+    becomes one bias (C), so fused = unfused - sum of BatchNorm channels.  Both the oracle network and the product's spec table must reproduce
+    the two numbers, which fixes the channel widths AND which of the 100 conv-like layers carry a BatchNorm."""
+    import torch
+
+    from mslesseg_amd import params
+    from oracle import yolo11seg as Y
+
+    for scale, want in (("n", 2_868_664), ("s", 10_097_776)):
+        specs = params.param_specs(scale, 80)
+        bn_channels = sum(s["cout"] for s in specs.values() if s["kind"] == "conv" and s["bn"])
+        assert params.count_params(scale, 80) - bn_channels == want
+        m = Y.build(scale, 80)
+        unfused = sum(p.numel() for p in m.parameters())
+        bn = sum(mod.num_features for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+        assert unfused - bn == want, (scale, unfused, bn)
