@@ -408,8 +408,23 @@ def volume_plane_bench(eng, dev):
         out = V.predict_volume(m, vol, "axial")
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
-    return {"ms_per_plane_volume": round(dt * 1e3, 2), "slices_per_s_incl_upload_extract_insert": round(182 / dt, 1), "slices": 182,
-            "note": "host float64 volume -> device plane volume; upload 58 MB + MSL_OP_SLICE_EXTRACT + LetterBox + net + NMS + masks + merge + insert"}
+    res = {"ms_per_plane_volume": round(dt * 1e3, 2), "slices_per_s_incl_upload_extract_insert": round(182 / dt, 1), "slices": 182,
+           "note": "host float64 volume -> device plane volume; upload 58 MB + MSL_OP_SLICE_EXTRACT + LetterBox + net + NMS + masks + merge + insert"}
+    # BASELINE configs[3]: the whole patient — axial + coronal + sagittal predictions of every slice (582), reconstruct, 3-plane consensus, Dice
+    # against a ground-truth volume — what generar_predicciones x 3 + reconstruir_volumen x 3 + generar_consenso + eval do per patient
+    gt = torch.from_numpy((rng.random((182, 218, 182)) < 0.01).astype(np.uint8)).to(dev)
+    models = {pl: m for pl in ("axial", "coronal", "sagital")}
+    V.predict_consensus(models, vol, umbral=2)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        cons, _ = V.predict_consensus(models, vol, umbral=2)
+        d, _ = V.dice(gt, cons)
+    torch.cuda.synchronize(dev)
+    dt3 = (time.perf_counter() - t0) / 3
+    res["patient_three_planes_consensus_dice"] = {"ms_per_patient": round(dt3 * 1e3, 2), "slices": 582, "slices_per_s": round(582 / dt3, 1),
+                                                  "note": "BASELINE configs[3]: 3 x (upload + extract + predict + insert) + consensus + Dice on the device, from the host volume"}
+    return res
 
 
 def train_e2e_bench(args, dev, rank, world, state, B):

@@ -207,7 +207,8 @@ def extract_slices(vol_dev: torch.Tensor, shape, plano: str, indices, mejora: Op
     return out
 
 
-def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Iterable[int]] = None, batch: int = 128, mejora: Optional[str] = None) -> torch.Tensor:
+def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Iterable[int]] = None, batch: int = 128, mejora: Optional[str] = None,
+                   src: Optional[torch.Tensor] = None) -> torch.Tensor:
     """FLAIR volume → float32 {0,1} volume of `plano` predictions on device (slices never predicted stay 0).
     Whole-volume batched replacement of generar_predicciones + reconstruir_volumen for one plane.  `mejora` ∈ {None, "HE", "CLAHE", "GC",
     "LT"} applies the reference's enhancement variant to every slice before it is rendered [REF Paciente.py:195-222]."""
@@ -215,7 +216,8 @@ def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Itera
     dev = eng.device
     idx = list(range(flair.shape[PLANE_AXIS[plano]])) if indices is None else [int(i) for i in indices]
     vol = torch.zeros(flair.shape, dtype=torch.float32, device=dev)
-    src = upload_volume(flair, dev)  # the slices are cut, enhanced and rendered on the device (MSL_OP_SLICE_EXTRACT): no per-slice host work
+    if src is None:  # (`src`: the volume already in HBM — the three planes of a patient share one upload)
+        src = upload_volume(flair, dev)  # the slices are cut, enhanced and rendered on the device (MSL_OP_SLICE_EXTRACT): no per-slice host work
     for b0 in range(0, len(idx), batch):
         chunk = idx[b0 : b0 + batch]
         imgs = extract_slices(src, flair.shape, plano, chunk, mejora)
@@ -225,8 +227,9 @@ def predict_volume(model, flair: np.ndarray, plano: str, indices: Optional[Itera
 
 
 def predict_consensus(models: Dict[str, object], flair: np.ndarray, umbral: int = 2, indices: Optional[Dict[str, Iterable[int]]] = None):
-    """Three plane models → (consensus uint8 volume on device, per-plane float32 volumes)."""
-    vols = {pl: predict_volume(models[pl], flair, pl, None if indices is None else indices.get(pl)) for pl in ("axial", "coronal", "sagital")}
+    """Three plane models → (consensus uint8 volume on device, per-plane float32 volumes); the FLAIR volume is uploaded once."""
+    src = upload_volume(flair, models["axial"]._get_engine().device)
+    vols = {pl: predict_volume(models[pl], flair, pl, None if indices is None else indices.get(pl), src=src) for pl in ("axial", "coronal", "sagital")}
     return consensus(vols["axial"], vols["coronal"], vols["sagital"], umbral), vols
 
 
