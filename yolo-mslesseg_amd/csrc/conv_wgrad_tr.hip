@@ -21,7 +21,6 @@
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
-__device__ __attribute__((aligned(16))) unsigned wg_zero_page[4];  // source of padding for LDS-DMA gathers (per translation unit: no RDC)
 
 struct WgTrArgs {
   const char* x;
@@ -79,56 +78,84 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
 #pragma unroll
       for (int j = 0; j < TCI; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](long tile, unsigned char* buf) __attribute__((always_inline)) {
+  // ---- staging.  Everything that depends on the lane (which pixel / channel chunk of the tile a lane copies in each of its LDS-DMA
+  // pieces) is fixed for the whole run of tiles: byte offsets from the tile origin and (row, column) are computed once; per tile only the
+  // origin moves, and it is wave-uniform — it goes into the base of a buffer descriptor (SGPRs), so a piece costs one
+  // `buffer_load_dwordx4 … offen lds` and, on tiles that touch an image edge, a handful of compares.  Lanes that must read zero (padding
+  // chunks, channels beyond the tensor, pixels outside the image) get an offset beyond `num_records`: the bounds check of the buffer load
+  // returns 0 to LDS without a memory access.  (The previous form rebuilt every lane's 64-bit address per piece and tile: ~50 instructions
+  // per piece, more issue slots than the tile's MFMAs.)
+  constexpr int ZK = (C::Z_PIECES + 7) / 8, XK = (C::X_PIECES + 7) / 8;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned zoff[ZK], zrc[ZK], xoff[XK], xrc[XK];
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) {
+    const int cidx = (wave + 8 * k) * 64 + lane, slot = cidx / C::CPZ, ch = cidx - slot * C::CPZ;
+    const bool ok = slot < C::Z_SLOTS && ch < ZC && cob * 64 + ch * 8 < a.Cout;
+    const int row = TAPS == 1 ? 0 : slot >> 5, col = TAPS == 1 ? slot : slot & 31;
+    zoff[k] = ok ? (unsigned)(((row * a.Wo + col) * a.z_cs + ch * 8) * 2) : OOB;
+    zrc[k] = ((unsigned)row << 16) | (unsigned)col;
+  }
+#pragma unroll
+  for (int k = 0; k < XK; ++k) {
+    const int cidx = (wave + 8 * k) * 64 + lane, slot = cidx / C::CPX, ch = cidx - slot * C::CPX;
+    const bool ok = slot < C::X_SLOTS && ch < XC && cib * 64 + ch * 8 < a.Cin;
+    int r = 0, c = slot;
+    if constexpr (TAPS != 1) {
+      r = slot / ROWP;
+      c = slot - r * ROWP;
+      if constexpr (S == 2) c = c < C::HALF ? 2 * c : 2 * (c - C::HALF) + 1;  // parity-split image → halo column
+    }
+    xoff[k] = ok ? (unsigned)(((r * a.W + c) * a.x_cs + ch * 8) * 2) : OOB;
+    xrc[k] = ((unsigned)r << 16) | (unsigned)c;
+  }
+  constexpr int XCOLS = S == 1 ? ROWP : 2 * C::HALF;  // halo columns staged
+
+  // tile → (image, origin): tiles of an image are walked column-major — vertical neighbours share 2 of the 6 (4-row tile) halo rows of x and are
+  // staged back to back, so the shared rows are still in L2 (row-major order revisits them tiles_x tiles later — 200 KB per workgroup, x 32
+  // workgroups per XCD, more than its 4 MB L2).  1x1: the pixels are a flat list, a "row" is just 32 consecutive ones.
+  auto stage = [&](int tile, unsigned char* buf) __attribute__((always_inline)) {
     unsigned char* s_z = buf;
     unsigned char* s_x = buf + C::Z_PIECES * 1024;
-    int n, oy0, ox0;
-    long p0 = 0;
+    long zpix, xpix;
+    int zr_lim, zc_lim, y_lo = 0, x_lo = 0;
+    bool z_in, x_in;
     if constexpr (TAPS == 1) {
-      p0 = tile * (TH * TW);  // 1x1: the pixels are a flat list, a "row" is just 32 consecutive ones
-      n = 0; oy0 = 0; ox0 = 0;
+      zpix = xpix = (long)tile * (TH * TW);
+      const long left = a.M - zpix;
+      zr_lim = 1; zc_lim = left < TH * TW ? (int)left : TH * TW;
+      z_in = x_in = left >= TH * TW;
     } else {
-      // tiles of an image are walked column-major: vertical neighbours share 2 of the 6 (4-row tile) halo rows of x and are staged back to back,
-      // so the shared rows are still in L2 (row-major order revisits them tiles_x tiles later — 200 KB per workgroup, x 32 workgroups per XCD,
-      // more than its 4 MB L2)
-      const int tyi = (int)(tile % a.tiles_y);
-      const long tq = tile / a.tiles_y;
-      const int txi = (int)(tq % a.tiles_x);
-      n = (int)(tq / a.tiles_x);
-      oy0 = tyi * TH; ox0 = txi * TW;
+      const int tyi = tile % a.tiles_y, tq = tile / a.tiles_y;
+      const int txi = tq % a.tiles_x, n = tq / a.tiles_x;
+      const int oy0 = tyi * TH, ox0 = txi * TW;
+      zpix = ((long)n * a.Ho + oy0) * a.Wo + ox0;
+      zr_lim = a.Ho - oy0; zc_lim = a.Wo - ox0;
+      z_in = zr_lim >= TH && zc_lim >= TW;
+      y_lo = oy0 * S - C::PAD; x_lo = ox0 * S - C::PAD;
+      xpix = ((long)n * a.H + y_lo) * a.W + x_lo;  // may lie before the image (top / left edge): only lanes that pass the edge test use it
+      x_in = y_lo >= 0 && x_lo >= 0 && y_lo + C::ROWS <= a.H && x_lo + XCOLS <= a.W;
     }
-    for (int pc = wave; pc < C::Z_PIECES; pc += 8) {
-      const int cidx = pc * 64 + lane, slot = cidx / C::CPZ, ch = cidx - slot * C::CPZ;
-      bool ok = slot < C::Z_SLOTS && ch < ZC && cob * 64 + ch * 8 < a.Cout;
-      long pix;
-      if constexpr (TAPS == 1) {
-        pix = p0 + slot;
-        ok = ok && pix < a.M;
-      } else {
-        const int oy = oy0 + (slot >> 5), ox = ox0 + (slot & 31);
-        ok = ok && oy < a.Ho && ox < a.Wo;
-        pix = ((long)n * a.Ho + oy) * a.Wo + ox;
-      }
-      const char* src = ok ? a.dz + (pix * a.z_cs + a.z_co + cob * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_z + pc * 1024), 16, 0, 0);
+    const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dz + (zpix * a.z_cs + a.z_co + cob * 64) * 2), 0, OOB, 0x00020000);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (xpix * a.x_cs + a.x_co + cib * 64) * 2), 0, OOB, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) {
+      const int pc = wave + 8 * k;
+      if (pc >= C::Z_PIECES) break;  // wave-uniform
+      unsigned vo = zoff[k];
+      if (!z_in) vo = ((int)(zrc[k] >> 16) < zr_lim && (int)(zrc[k] & 0xffff) < zc_lim) ? vo : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (__attribute__((address_space(3))) void*)(s_z + pc * 1024), 16, (int)vo, 0, 0, 0);
     }
-    for (int pc = wave; pc < C::X_PIECES; pc += 8) {
-      const int cidx = pc * 64 + lane, slot = cidx / C::CPX, ch = cidx - slot * C::CPX;
-      bool ok = slot < C::X_SLOTS && ch < XC && cib * 64 + ch * 8 < a.Cin;
-      long pix;
-      if constexpr (TAPS == 1) {
-        pix = p0 + slot;
-        ok = ok && pix < a.M;
-      } else {
-        const int r = slot / ROWP;
-        int c = slot - r * ROWP;
-        if constexpr (S == 2) c = c < C::HALF ? 2 * c : 2 * (c - C::HALF) + 1;  // parity-split image → halo column
-        const int iy = oy0 * S + r - C::PAD, ix = ox0 * S + c - C::PAD;
-        ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        pix = ((long)n * a.H + iy) * a.W + ix;
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+      const int pc = wave + 8 * k;
+      if (pc >= C::X_PIECES) break;
+      unsigned vo = xoff[k];
+      if (!x_in) {
+        if constexpr (TAPS == 1) vo = (int)(xrc[k] & 0xffff) < zc_lim ? vo : OOB;
+        else vo = ((unsigned)((int)(xrc[k] >> 16) + y_lo) < (unsigned)a.H && (unsigned)((int)(xrc[k] & 0xffff) + x_lo) < (unsigned)a.W) ? vo : OOB;
       }
-      const char* src = ok ? a.x + (pix * a.x_cs + a.x_co + cib * 64 + ch * 8) * 2 : (const char*)wg_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_x + pc * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(s_x + pc * 1024), 16, (int)vo, 0, 0, 0);
     }
   };
 
@@ -191,15 +218,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
     }
   };
 
-  const long tile0 = (long)blockIdx.x * a.tiles_per_block;
-  long tile_end = tile0 + a.tiles_per_block;
-  if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+  const int tile0 = (int)blockIdx.x * a.tiles_per_block;
+  int tile_end = tile0 + a.tiles_per_block;
+  if (tile_end > (int)a.total_tiles) tile_end = (int)a.total_tiles;
   if (tile0 < tile_end) {
     stage(tile0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (long tile = tile0; tile < tile_end; ++tile) {  // block-uniform trip count
+    for (int tile = tile0; tile < tile_end; ++tile) {  // block-uniform trip count
       if (tile + 1 < tile_end) stage(tile + 1, smem + (cur ^ 1) * C::BUF);
       if (wave_active) compute(smem + cur * C::BUF);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
