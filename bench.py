@@ -241,8 +241,19 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             return 2.0 * I[0] * I[1] * I[2] * I[6] * 9 * I[3]
         return 2.0 * I[0] * I[4] * I[5] * I[6] * I[16]
 
+    es = 2 if args.dtype == "bf16" else 4
+
+    def conv_bytes(op, wgrad=False):
+        """Algorithmic HBM bytes of one launch: every input activation read once, every output written once (weights and
+        the partial-sum scratch are noise next to the activations); an accumulating input gradient also reads what it adds to."""
+        I = op.i
+        a_in, a_out = I[0] * I[1] * I[2] * I[3] * es, I[0] * I[4] * I[5] * I[6] * es
+        if wgrad:
+            return float(a_in + a_out * (2 if I[19] else 1))  # x and dz (fp32 dz: twice the bytes)
+        return float(a_in + a_out * (2 if op.p[3] else 1))
+
     wg_ms, wg_fl, cv_ms, cv_fl = 0.0, 0.0, 0.0, 0.0
-    cands = []  # every MFMA launch as (ms, flops, kernel label, dtype, tag, op); the longest is the "dominant kernel", the top 3 are replayed for PMC
+    cands = []  # every MFMA launch as (ms, flops, kernel label, dtype, tag, op); the top 3 by time are replayed for PMC
     for tag, what, kind, ms, it in rows:
         I = it.i if what == "op" else None
         if kind == hiplib.OP_CONV_WGRAD:
@@ -268,12 +279,31 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             mode = "input gradient, transposed-conv gather" if I[22] else ("input gradient" if tag == "bwd" else "forward")
             cands.append((ms, fl, f"{kn}<{args.dtype}> ({mode})", args.dtype, tag, it))
     cands.sort(key=lambda c: -c[0])
-    ms, fl, kname, kdt, tag, op = cands[0]
+
+    def roof_ms(c):  # time of the launch on the ideal machine: the slower of its two roofs
+        by = conv_bytes(c[5], c[5].kind == hiplib.OP_CONV_WGRAD)
+        return max(c[1] / (PEAK[c[3]] * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3
+
+    # dominant kernel = the launch with the most work by the roofline (the largest ideal time), not the one that happens to be slowest today
+    ms, fl, kname, kdt, tag, op = max(cands, key=roof_ms)
     peak = PEAK[kdt]
     ach = fl / (ms * 1e-3) / 1e12
+    by = conv_bytes(op, op.kind == hiplib.OP_CONV_WGRAD)
+    ach_gbs = by / (ms * 1e-3) / 1e9
+    hbm_bound = by / (PEAK_HBM_GBS * 1e9) > fl / (peak * 1e12)
     I = op.i
     total = sum(r[3] for r in rows)
-    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+    lms, lfl, lname, ldt, _, lop = cands[0]
+    lby = conv_bytes(lop, lop.kind == hiplib.OP_CONV_WGRAD)
+    roof = {"bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_gbs if hbm_bound else ach, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach_gbs / PEAK_HBM_GBS if hbm_bound else ach / peak, 4), "traffic": None,
+            "mfma_tflops": round(ach, 2), "mfma_frac": round(ach / peak, 4), "hbm_gbs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / PEAK_HBM_GBS, 4),
+            "arithmetic_intensity_flop_per_byte": round(fl / by, 1), "ridge_flop_per_byte": round(peak * 1e12 / (PEAK_HBM_GBS * 1e9), 1),
+            "algorithmic_gbytes_per_launch": round(by / 1e9, 4),
+            "dominant_rule": "the MFMA launch with the largest roofline time max(flop / peak, bytes / 8 TB/s); 'bound' names the roof that sets it",
+            "longest_launch": {"kernel": lname, "launch_ms": round(lms, 4), "mfma_frac": round(lfl / (lms * 1e-3) / 1e12 / PEAK[ldt], 4),
+                               "hbm_frac": round(lby / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                               "shape": {"N": lop.i[0], "H": lop.i[1], "W": lop.i[2], "Cin": lop.i[3], "Ho": lop.i[4], "Wo": lop.i[5], "Cout": lop.i[6], "k": lop.i[7], "stride": lop.i[8]}},
             "kernel": kname, "kernel_dtype": kdt, "launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "launch_shape": {"N": I[0], "H": I[1], "W": I[2], "Cin": I[3], "Ho": I[4], "Wo": I[5], "Cout": I[6], "k": I[7], "stride": I[8]},
             "all_wgrad": {"tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2), "frac": round(wg_fl / (wg_ms * 1e-3) / 1e12 / PEAK[args.dtype], 4), "ms": round(wg_ms, 3)},

@@ -48,6 +48,9 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
   const int slice_chunks = SP * cps, slice_bytes = ((slice_chunks + 63) & ~63) * 16;
   unsigned char* s_w = smem;
   unsigned char* s_x = smem + w_bytes + wave * 2 * slice_bytes;      // this wave's ring: 2 slices
+  float* s_bias = (float*)(smem + w_bytes + NW * 2 * slice_bytes);    // [NCP * 32]: read per slice with ds_read — a global load in the loop makes hipcc
+                                                                      // wait vmcnt(0), i.e. for the next slice's DMA and the previous stores, before every store group
+  for (int i = threadIdx.x; i < NCP * 32; i += blockDim.x) s_bias[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;
 
   // ---- weights → LDS (rows >= w_rows and the pad chunk read the zero page)
   {
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
       const int cidx = c0 + lane, row = cidx / cps, ch = cidx - row * cps;
       const bool ok = cidx < total && row < a.w_rows && ch < kchunks;
       const char* src = ok ? a.w + ((long)row * a.Kpad + ch * EPC) * ES : (const char*)c1_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(s_w + (long)c0 * 16), 16, 0, 0);
+      msl_glds16(src, msl_lds_addr(s_w + (long)c0 * 16));
     }
   }
   const long tiles = (a.M + SP - 1) / SP;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
       const int cidx = c0 + lane, px = cidx / cps, ch = cidx - px * cps;
       const bool ok = cidx < slice_chunks && ch < xchunks && p0 + px < a.M;
       const char* src = ok ? a.x + ((p0 + px) * a.x_cs + a.x_co + ch * EPC) * ES : (const char*)c1_zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + c0 * 16), 16, 0, 0);
+      msl_glds16(src, msl_lds_addr(dst + c0 * 16));  // asm form: the builtin makes hipcc wait vmcnt(0) before LDS reads it cannot prove disjoint (msl_common.h)
     }
   };
 
@@ -90,8 +93,14 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
   __syncthreads();  // weights visible to every wave (the only workgroup barrier before the epilogue)
   int buf = 0;
   const int arow = 8 * (li >> 2) + (li & 3);  // A-operand row permutation: MFMA row 4g+r of tile m ↔ channel 8g + 4m + r
+  // store instructions of one full slice (issued AFTER the next slice's DMA): they may stay in flight across the wait at the top of the loop —
+  // waiting for their acknowledgement too put a store round trip into every iteration of every wave
+  const int ns = PT * NCP * ((F32 || a.out_f32) ? 2 : 1);
+  bool prev_full = false;
   for (; tile < tiles; tile += stride) {  // wave-uniform
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slice (and its previous stores) have landed
+    if (prev_full && !a.res) msl_wait_vmcnt(ns);  // this wave's slice has landed (vmcnt counts in order: at most the ns stores issued after its DMA remain)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prev_full = (tile + 1) * SP <= a.M;  // a ragged slice skips stores: then the count above would not cover the DMA
     if (tile + stride < tiles) stage(tile + stride, buf ^ 1);
     const unsigned char* xs = s_x + buf * slice_bytes;
     f32x4 acc[PT][NCP][2];
@@ -151,9 +160,9 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
             s2[c][r >> 2][r & 3] = fmaf(vr, vr, s2[c][r >> 2][r & 3]);
           }
         }
-        if (a.bias) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += a.bias[c0 + r];
+        {
+          const float4 b0 = *(const float4*)(s_bias + c0), b1 = *(const float4*)(s_bias + c0 + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
         if (a.act) {
 #pragma unroll
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 // ---- host
 static size_t c1_lds(int ncp, int Kpad, int pt, int nw = 4, int es = 2) {
   const int cps = (Kpad * es + 16) / 16;
-  return (size_t)(((ncp * 32 * cps + 63) & ~63) + 2 * nw * ((pt * 16 * cps + 63) & ~63)) * 16;
+  return (size_t)(((ncp * 32 * cps + 63) & ~63) + 2 * nw * ((pt * 16 * cps + 63) & ~63)) * 16 + (size_t)ncp * 32 * 4;  // weights | rings | bias
 }
 static const size_t C1_LDS_MAX = 150 * 1024;
 

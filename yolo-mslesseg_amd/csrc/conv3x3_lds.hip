@@ -57,14 +57,14 @@ __device__ __forceinline__ int halo_byte(int s, int g) { return ((s >> 2) << 8) 
 // Epilogue of one pixel for a lane: the lane's 4*COT accumulator values are CONSECUTIVE output channels starting at co0 (weight rows are
 // packed in that order, include/mslesseg_hip.h op.i[25]): bias, optional statistics of the stored values, SiLU, residual, 16-byte stores.
 template <bool F32, int COT>
-__device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co0, const f32x4 (&accp)[COT], float (&s1)[COT][4], float (&s2)[COT][4]) {
+__device__ __forceinline__ void store_pixel_b(const Conv3Args& a, long pix, int co0, const f32x4 (&accp)[COT], float (&s1)[COT][4], float (&s2)[COT][4],
+                                              const float (&bias)[COT * 4]) {  // bias = a.bias[co0 .. co0 + 4 * COT) held in registers
   if (co0 >= a.Cout) return;  // Cout = 8: the upper half of the single 16-row block is zero padding
   float v[COT * 4];
 #pragma unroll
-  for (int c = 0; c < COT; ++c) {
-    const float4 b4 = *(const float4*)(a.bias + co0 + c * 4);
-    v[c * 4 + 0] = accp[c][0] + b4.x; v[c * 4 + 1] = accp[c][1] + b4.y; v[c * 4 + 2] = accp[c][2] + b4.z; v[c * 4 + 3] = accp[c][3] + b4.w;
-  }
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[c * 4 + r] = accp[c][r] + bias[c * 4 + r];
   if (a.acc) {
 #pragma unroll
     for (int c = 0; c < COT; ++c)
@@ -99,6 +99,29 @@ __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co
       if (a.out_f32) stv<true, 8>(a.y, oi + h * 8, v8); else stv<F32, 8>(a.y, oi + h * 8, v8);
     }
   }
+}
+
+template <int COT>
+__device__ __forceinline__ void load_bias(const Conv3Args& a, int co0, float (&bias)[COT * 4]) {  // once per kernel, before the store loop (see conv3x3_pers_kernel)
+#pragma unroll
+  for (int c = 0; c < COT; ++c) {
+    const float4 b4 = co0 < a.Cout ? *(const float4*)(a.bias + co0 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias[c * 4 + 0] = b4.x; bias[c * 4 + 1] = b4.y; bias[c * 4 + 2] = b4.z; bias[c * 4 + 3] = b4.w;
+  }
+#pragma unroll
+  for (int i = 0; i < COT * 4; ++i) asm volatile("" ::"v"(bias[i]));
+}
+
+template <bool F32, int COT>
+__device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co0, const f32x4 (&accp)[COT], float (&s1)[COT][4], float (&s2)[COT][4]) {
+  if (co0 >= a.Cout) return;
+  float bias[COT * 4];
+#pragma unroll
+  for (int c = 0; c < COT; ++c) {
+    const float4 b4 = *(const float4*)(a.bias + co0 + c * 4);
+    bias[c * 4 + 0] = b4.x; bias[c * 4 + 1] = b4.y; bias[c * 4 + 2] = b4.z; bias[c * 4 + 3] = b4.w;
+  }
+  store_pixel_b<F32, COT>(a, pix, co0, accp, s1, s2, bias);
 }
 
 template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3>
@@ -235,6 +258,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   for (int c = 0; c < COT; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
+  float bias_r[COT * 4];
+  load_bias<COT>(a, cob * COB + g * (4 * COT), bias_r);
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     f32x4 accp[COT];
 #pragma unroll
     for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
-    store_pixel<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2);
+    store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r);
   }
   if (a.acc) {  // block-uniform: fold over the 16 pixel lanes, over the 4 waves (LDS), then one fp64 atomic per channel and statistic
     __syncthreads();  // every wave is done with the staged tiles
@@ -334,8 +359,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   {
     const char* wsrc = a.w + (long)cob * NCH * W_BYTES + lane * 16;
     for (int pc = wave8; pc < NCH * W_BYTES / 1024; pc += 8)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + pc * 1024),
-                                       (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
+      msl_glds16(wsrc + pc * 1024, msl_lds_addr(s_w + pc * 1024));
   }
 
   // ---- tile-independent part of the staging gather: halo (row, col) and byte offset of this lane's 16 bytes for each of its pieces
@@ -389,6 +413,25 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
         a2[t2][ks] = *(const uint4*)(a.w2 + ((long)ch2 * 64 + 16 * g + 8 * ks) * 2);
       }
   }
+  // bias of this lane's output channels, loaded once: a load inside the tile loop makes hipcc wait (in order) for every older vector-memory
+  // operation — including the next unit's LDS-DMA
+  float bias_r[COT * 4], bias2_r[8];
+  {
+    load_bias<COT>(a, cob * COB + g * (4 * COT), bias_r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias2_r[i] = 0.f;
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 b4 = *(const float4*)(a.bias2 + g * 8 + h * 4);
+        bias2_r[h * 4 + 0] = b4.x; bias2_r[h * 4 + 1] = b4.y; bias2_r[h * 4 + 2] = b4.z; bias2_r[h * 4 + 3] = b4.w;
+      }
+    }
+    // a use before the loop (load_bias has one too): hipcc then waits for these loads here, not at their first use inside the loop — where
+    // its `vmcnt(0)` would also wait, on every tile, for the stores of the previous pixel group
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(bias2_r[i]));
+  }
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   // staging state: the tile whose units are being staged
   const char* st_img = a.x;
@@ -418,8 +461,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
       const int pc = wave + 4 * j;
       if (pc < T::PIECES) {
         const char* src = st_off[j] >= 0 ? st_img + st_off[j] + cc * (CHUNK * ES) : (const char*)msl_zero_page;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+        msl_glds16(src, msl_lds_addr(dst + pc * 1024));
       }
     }
   };
@@ -472,8 +514,8 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int c = ks * 2 + h;
-            const float4 b4 = *(const float4*)(a.bias + g * 16 + c * 4);
-            v[h * 4 + 0] = acc[c][p][0] + b4.x; v[h * 4 + 1] = acc[c][p][1] + b4.y; v[h * 4 + 2] = acc[c][p][2] + b4.z; v[h * 4 + 3] = acc[c][p][3] + b4.w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[h * 4 + r] = acc[c][p][r] + bias_r[c * 4 + r];
           }
           if (a.act == 1) {
 #pragma unroll
@@ -491,8 +533,8 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2[t2][ks]), __builtin_bit_cast(bf16x8, bq[ks]), d, 0, 0, 0);
-          const float4 b4 = *(const float4*)(a.bias2 + g * 8 + t2 * 4);
-          o[t2 * 4 + 0] = d[0] + b4.x; o[t2 * 4 + 1] = d[1] + b4.y; o[t2 * 4 + 2] = d[2] + b4.z; o[t2 * 4 + 3] = d[3] + b4.w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[t2 * 4 + r] = d[r] + bias2_r[t2 * 4 + r];
         }
         if (a.act == 1) {
 #pragma unroll
@@ -503,7 +545,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
         f32x4 accp[COT];
 #pragma unroll
         for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
-        store_pixel<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2);
+        store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r);
       }
 #pragma unroll
       for (int c = 0; c < COT; ++c) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -513,15 +555,17 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   // ---- steps: at step s group 0 computes unit s, group 1 unit s - DELAY; buffer parity = s & 1 for both
   auto step = [&](int sidx, auto par) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // every wave's pieces of the current unit have landed, and everyone is done reading the buffer refilled next
+    // every wave's pieces of the current unit have landed (each wave waited for its own after the previous step's MFMAs), and everyone is done
+    // reading the buffer refilled next.  The bare barrier: __syncthreads() fences with vmcnt(0), which would also wait for the acknowledgement
+    // of the stores the previous step's epilogue has just issued — once per step, for all eight waves.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int u = sidx - DELAY * grp, un = u + 1;
     if (un >= 0 && un < my_units) stage(un, ring_g + (PAR ^ 1) * IN_BYTES);
-    if (u >= 0 && u < my_units) {
-      const int cc = NCH == 2 ? (u & 1) : 0;
-      compute(cc, ring_g + PAR * IN_BYTES);
-      if (cc == NCH - 1) epilogue(u / NCH);
-    }
+    const bool live = u >= 0 && u < my_units;
+    const int cc = NCH == 2 ? (u & 1) : 0;
+    if (live) compute(cc, ring_g + PAR * IN_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA issued above had the MFMAs to land; waited for BEFORE the epilogue so that its stores stay in flight
+    if (live && cc == NCH - 1) epilogue(u / NCH);
   };
   step(-1, std::integral_constant<int, 1>{});
   for (int sidx = 0; sidx < steps + DELAY; sidx += 2) {
@@ -685,6 +729,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2dgrad_lds_kernel(Conv3Args a) {
   }
   // ---- epilogue: the 2 x 2 output pixels of every gradient pixel (+ what the gradient view already holds)
   float s1[COT][4], s2[COT][4];  // unused (no statistics here): store_pixel's signature
+  float bias_r[COT * 4];
+  load_bias<COT>(a, cob * COB + g * (4 * COT), bias_r);
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int Y = Y0 + wave * 2 + (p >> 1), X = X0 + (p & 1) * 16 + lp;
@@ -696,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2dgrad_lds_kernel(Conv3Args a) {
       f32x4 accp[COT];
 #pragma unroll
       for (int c = 0; c < COT; ++c) accp[c] = acc[k][c][p];
-      store_pixel<false, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2);
+      store_pixel_b<false, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r);
     }
   }
 }

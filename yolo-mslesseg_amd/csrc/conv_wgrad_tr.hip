@@ -31,7 +31,16 @@ struct WgTrArgs {
   int tiles_x, tiles_y, tiles_per_block;
   long total_tiles, M;
   float* scratch;  // [gridDim.x][Cout][K] per-workgroup partial sums (NULL: flush with atomics)
+#ifdef WG_STAMPS
+  unsigned long long* dbg;  // diagnostic build (scripts/dev_wgrad_stamps.hip): [workgroup][wave][8] cycle sums per loop phase
+#endif
 };
+#ifdef WG_STAMPS
+unsigned long long* wg_dbg_ptr = nullptr;
+#define WG_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WG_STAMP(k)
+#endif
 
 // bytes per LDS slot for C 16-byte channel chunks: data + padding such that the 4 slots x 32 bytes one transposed read touches
 // per 16 lanes fall into distinct banks
@@ -58,7 +67,39 @@ struct WgCfg {
   static constexpr int ACTIVE = WCO * WCI * WR;
 };
 
-template <int TAPS, int S, int ZC, int XC>
+// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor base + voff) to LDS bytes [lds_addr, lds_addr + 1024).  Issued as an asm statement on
+// purpose: after the builtin form hipcc waits `vmcnt(0)` before the next LDS read it cannot prove disjoint (SIInsertWaitcnts tracks LDS-DMA
+// as one pseudo-register) — i.e. right after the next tile's DMA is issued, before the current tile's first fragment read, which serialises
+// the "double-buffered" loop into DMA latency + MFMAs.  The asm form is invisible to that pass; landing is awaited by hand (wg_wait_vmcnt +
+// barrier) before a buffer is read.
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg_i32x4 wg_rsrc(const void* p) {  // raw buffer over [p, p + 2 GiB): offsets with bit 31 set read as zero
+  const unsigned long u = (unsigned long)p;
+  wg_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+  r.z = (int)0x80000000u;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void wg_dma16(wg_i32x4 rsrc, unsigned lds_addr, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate); n > 20 waits for everything
+__device__ __forceinline__ void wg_wait_vmcnt(int n) {
+#define WG_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    WG_VM(1) WG_VM(2) WG_VM(3) WG_VM(4) WG_VM(5) WG_VM(6) WG_VM(7) WG_VM(8) WG_VM(9) WG_VM(10)
+    WG_VM(11) WG_VM(12) WG_VM(13) WG_VM(14) WG_VM(15) WG_VM(16) WG_VM(17) WG_VM(18) WG_VM(19) WG_VM(20)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef WG_VM
+}
+
+template <int TAPS, int S, int ZC, int XC, int D>
 __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
   typedef WgCfg<TAPS, S, ZC, XC> C;
   constexpr int TH = C::TH, TW = C::TW, PZ = C::PZ, PX = C::PX, ROWP = C::ROWP, TCO = C::TCO, TCI = C::TCI, RPW = C::RPW, KD = C::KD;
@@ -136,15 +177,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       xpix = ((long)n * a.H + y_lo) * a.W + x_lo;  // may lie before the image (top / left edge): only lanes that pass the edge test use it
       x_in = y_lo >= 0 && x_lo >= 0 && y_lo + C::ROWS <= a.H && x_lo + XCOLS <= a.W;
     }
-    const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dz + (zpix * a.z_cs + a.z_co + cob * 64) * 2), 0, OOB, 0x00020000);
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (xpix * a.x_cs + a.x_co + cib * 64) * 2), 0, OOB, 0x00020000);
+    const wg_i32x4 rz = wg_rsrc(a.dz + (zpix * a.z_cs + a.z_co + cob * 64) * 2);
+    const wg_i32x4 rx = wg_rsrc(a.x + (xpix * a.x_cs + a.x_co + cib * 64) * 2);
+    const unsigned lz = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)s_z, lx = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)s_x;
 #pragma unroll
     for (int k = 0; k < ZK; ++k) {
       const int pc = wave + 8 * k;
       if (pc >= C::Z_PIECES) break;  // wave-uniform
       unsigned vo = zoff[k];
       if (!z_in) vo = ((int)(zrc[k] >> 16) < zr_lim && (int)(zrc[k] & 0xffff) < zc_lim) ? vo : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (__attribute__((address_space(3))) void*)(s_z + pc * 1024), 16, (int)vo, 0, 0, 0);
+      wg_dma16(rz, __builtin_amdgcn_readfirstlane(lz + pc * 1024), vo);
     }
 #pragma unroll
     for (int k = 0; k < XK; ++k) {
@@ -155,7 +197,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
         if constexpr (TAPS == 1) vo = (int)(xrc[k] & 0xffff) < zc_lim ? vo : OOB;
         else vo = ((unsigned)((int)(xrc[k] >> 16) + y_lo) < (unsigned)a.H && (unsigned)((int)(xrc[k] & 0xffff) + x_lo) < (unsigned)a.W) ? vo : OOB;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(s_x + pc * 1024), 16, (int)vo, 0, 0, 0);
+      wg_dma16(rx, __builtin_amdgcn_readfirstlane(lx + pc * 1024), vo);
     }
   };
 
@@ -221,19 +263,48 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
   const int tile0 = (int)blockIdx.x * a.tiles_per_block;
   int tile_end = tile0 + a.tiles_per_block;
   if (tile_end > (int)a.total_tiles) tile_end = (int)a.total_tiles;
+  // ---- ring of D staged tiles: D - 1 are in flight while one is multiplied (a tile's DMA takes 2-3 us from issue to landing when every CU
+  // streams — longer than its MFMAs — so one tile in flight leaves the loop latency-bound).  A wave knows its pieces of tile i+1 have landed
+  // when at most the pieces of the stages it issued later are outstanding (vmcnt counts in order); the barrier then covers the other waves'.
+  // The barrier is the bare instruction: __syncthreads() carries a fence that waits for vmcnt(0), i.e. for the whole ring.
+  const int np = (C::Z_PIECES - wave + 7) / 8 + (C::X_PIECES - wave + 7) / 8;  // LDS-DMA instructions this wave issues per staged tile
   if (tile0 < tile_end) {
-    stage(tile0, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int tile = tile0; tile < tile_end; ++tile) {  // block-uniform trip count
-      if (tile + 1 < tile_end) stage(tile + 1, smem + (cur ^ 1) * C::BUF);
-      if (wave_active) compute(smem + cur * C::BUF);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (tile0 + d < tile_end) stage(tile0 + d, smem + d * C::BUF);
+    {
+      int later = tile_end - 1 - tile0;
+      later = later < D - 2 ? later : D - 2;
+      wg_wait_vmcnt(np * later);
+      asm volatile("s_barrier" ::: "memory");
     }
+    int cur = 0;
+#ifdef WG_STAMPS
+    unsigned long long stamp[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+    for (int tile = tile0; tile < tile_end; ++tile) {  // block-uniform trip count
+      const int nb = cur == 0 ? D - 1 : cur - 1;  // = (cur + D - 1) % D: the buffer tile - 1 was read from
+      if (tile + D - 1 < tile_end) stage(tile + D - 1, smem + nb * C::BUF);
+      WG_STAMP(0)
+      if (wave_active) compute(smem + cur * C::BUF);
+      WG_STAMP(1)
+      int later = tile_end - 2 - tile;
+      later = later < D - 2 ? later : D - 2;
+      wg_wait_vmcnt(later > 0 ? np * later : 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WG_STAMP(2)
+      asm volatile("s_barrier" ::: "memory");
+      WG_STAMP(3)
+      cur = cur + 1 == D ? 0 : cur + 1;
+    }
+#ifdef WG_STAMPS
+    if (a.dbg && lane == 0) {
+      unsigned long long* d = a.dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+      d[0] = stamp[0]; d[1] = stamp[1]; d[2] = stamp[2]; d[3] = stamp[3]; d[4] = (unsigned long long)(tile_end - tile0);
+    }
+#endif
   }
+  __syncthreads();
   // ---- waves that split the tile rows hold partial sums of the same outputs: fold them into wave row 0 through LDS
   if constexpr (C::WR > 1) {
     constexpr int TG = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);  // taps per round (bounds the LDS footprint: <= 49 KB)
@@ -336,18 +407,36 @@ int msl_reduce_partials(const float* scratch, float* dst, long size, int nb, hip
   return MSL_OK;
 }
 
+template <int TAPS, int S, int ZC, int XC, int D>
+static int launch_tr_d(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
+  typedef WgCfg<TAPS, S, ZC, XC> C;
+  constexpr int RED = (C::WR - 1) * C::WCO * C::WCI * (TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1)) * C::TCO * C::TCI * 4 * 256;  // cross-wave fold
+  constexpr int LDS = D * C::BUF > RED ? D * C::BUF : RED;
+  static_assert(LDS <= 160 * 1024, "tile ring does not fit in LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TAPS, S, ZC, XC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS, S, ZC, XC, D>), dim3((unsigned)gx, (unsigned)ny), dim3(512), LDS, s, a);
+  return MSL_OK;
+}
+
 template <int TAPS, int S, int ZC, int XC>
 static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
   typedef WgCfg<TAPS, S, ZC, XC> C;
-  constexpr int RED = (C::WR - 1) * C::WCO * C::WCI * (TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1)) * C::TCO * C::TCI * 4 * 256;  // cross-wave fold
-  constexpr int LDS = 2 * C::BUF > RED ? 2 * C::BUF : RED;
-  static_assert(LDS <= 160 * 1024, "tile does not fit in LDS twice");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TAPS, S, ZC, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
+  constexpr int FIT = 160 * 1024 / C::BUF;  // staged tiles the CU's LDS holds
+  constexpr int DMAX = FIT >= 4 ? 4 : (FIT >= 3 ? 3 : 2);
+  constexpr int DDEF = DMAX >= 3 ? 3 : 2;  // measured: 3 staged tiles beat 2 on the bandwidth-bound shapes by up to 1.5x, 4 adds nothing
+  static int depth = -1;
+  if (depth < 0) {
+    const char* e = getenv("MSL_WGRAD_DEPTH");  // experiment switch
+    depth = e ? atoi(e) : DDEF;
   }
-  hipLaunchKernelGGL((conv_wgrad_tr_kernel<TAPS, S, ZC, XC>), dim3((unsigned)gx, (unsigned)ny), dim3(512), LDS, s, a);
+  const int d = depth > DMAX ? DMAX : (depth < 2 ? 2 : depth);
+  if constexpr (DMAX >= 4) { if (d == 4) launch_tr_d<TAPS, S, ZC, XC, 4>(a, ny, gx, s); }
+  if constexpr (DMAX >= 3) { if (d == 3) launch_tr_d<TAPS, S, ZC, XC, 3>(a, ny, gx, s); }
+  if (d == 2) launch_tr_d<TAPS, S, ZC, XC, 2>(a, ny, gx, s);
   if (a.scratch) msl_reduce_partials(a.scratch, a.dw, (long)a.Cout * a.K, (int)gx, s);
   MSL_CHECK_LAUNCH("conv_wgrad_tr");
   return MSL_OK;
@@ -392,13 +481,16 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
     a.total_tiles = (long)a.N * a.tiles_y * a.tiles_x;
   }
   const int ny = ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
-  long want = (256 + ny - 1) / ny;  // one 8-wave workgroup per CU: each holds two staged tiles in LDS
+  long want = 256 / ny;  // one 8-wave workgroup per CU (its ring of staged tiles takes the LDS): never more workgroups than CUs, a second round doubles the time
   if (want < 1) want = 1;
   long tpb = (a.total_tiles + want - 1) / want;
   if (tpb < 1) tpb = 1;
   a.tiles_per_block = (int)tpb;
   const long gx = (a.total_tiles + tpb - 1) / tpb;
   a.scratch = (float*)op.p[5];
+#ifdef WG_STAMPS
+  a.dbg = wg_dbg_ptr;
+#endif
   if (a.scratch) MSL_REQUIRE(gx * a.Cout * a.K <= (long)op.i[21] && ((uintptr_t)a.scratch & 15) == 0, "conv_wgrad_tr: scratch too small (%ld floats needed) or misaligned", gx * a.Cout * a.K);
   const int zc = wg_chunks(a.Cout), xc = wg_chunks(a.Cin);
   if (k == 3 && stride == 1) return launch_tr_c<9, 1>(a, zc, xc, ny, gx, s);

@@ -134,6 +134,32 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // SiLU = x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each): 5 VALU instead of the ~15 of an IEEE division.
+// One LDS-DMA piece as an asm statement: each lane's 16 bytes at `gsrc` go to LDS bytes [lds_addr + 16 * lane, +16) (lds_addr wave-uniform).
+// Use this — not __builtin_amdgcn_global_load_lds — wherever a DMA is meant to stay in flight across LDS reads of ANOTHER buffer: hipcc's
+// waitcnt pass tracks LDS-DMA as one pseudo-register and puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint,
+// which turns a double-buffered loop into "DMA latency + compute" (seen in the .s of conv_wgrad_tr and conv3x3_pers: the wait sat between the
+// next tile's DMA issue and the current tile's first fragment read).  The asm form is invisible to that pass: await landing by hand
+// (`s_waitcnt vmcnt(N)`, then a barrier) before the buffer is read.  M0 is saved and restored around the statement.
+__device__ __forceinline__ void msl_glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate): waits until at most the n youngest vector-memory operations
+// of the wave are outstanding (loads, stores and LDS-DMA count together, in issue order).  n > 32 waits for everything.
+__device__ __forceinline__ void msl_wait_vmcnt(int n) {
+#define MSL_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    MSL_VM(1) MSL_VM(2) MSL_VM(3) MSL_VM(4) MSL_VM(5) MSL_VM(6) MSL_VM(7) MSL_VM(8) MSL_VM(9) MSL_VM(10) MSL_VM(11) MSL_VM(12) MSL_VM(13) MSL_VM(14) MSL_VM(15) MSL_VM(16)
+    MSL_VM(17) MSL_VM(18) MSL_VM(19) MSL_VM(20) MSL_VM(21) MSL_VM(22) MSL_VM(23) MSL_VM(24) MSL_VM(25) MSL_VM(26) MSL_VM(27) MSL_VM(28) MSL_VM(29) MSL_VM(30) MSL_VM(31) MSL_VM(32)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef MSL_VM
+}
+__device__ __forceinline__ unsigned msl_lds_addr(const void* p) {  // byte address inside the workgroup's LDS of a wave-uniform __shared__ pointer
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // op launchers (one per translation unit)
