@@ -103,6 +103,25 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
     prev_full = (tile + 1) * SP <= a.M;  // a ragged slice skips stores: then the count above would not cover the DMA
     if (tile + stride < tiles) stage(tile + stride, buf ^ 1);
     const unsigned char* xs = s_x + buf * slice_bytes;
+    // residual (bf16: an input gradient that adds to what its view already holds): fetched here, before the MFMAs, into registers.  Loaded in the
+    // store loop, each group's load made hipcc wait — in order — for the next slice's DMA and for the previous group's stores.
+    constexpr bool RPRE = !F32 && !STATS;  // (the statistics form is the raw forward conv of training: its residual is added by BN_ACT)
+    uint4 rpre[RPRE ? PT : 1][RPRE ? NCP : 1];
+    if constexpr (RPRE) {
+      if (a.res) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          long p = tile * SP + pt * 16 + li;
+          p = p < a.M ? p : a.M - 1;  // every lane loads from a valid address (clamped) and discards what it does not need: a load under a per-lane
+                                      // condition is branched around and waited for with vmcnt(0) one by one
+#pragma unroll
+          for (int c = 0; c < NCP; ++c) {
+            const int c0 = c * 32 + 8 * g;
+            rpre[pt][c] = *(const uint4*)((const unsigned short*)a.res + p * a.res_cs + a.res_co + (c0 < a.Cout ? c0 : 0));
+          }
+        }
+      }
+    }
     f32x4 acc[PT][NCP][2];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
@@ -170,7 +189,15 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
         }
         if (a.res) {
           float rv[8];
-          ldv<F32, 8>(a.res, p * a.res_cs + a.res_co + c0, rv);
+          if constexpr (!RPRE) {
+            ldv<F32, 8>(a.res, p * a.res_cs + a.res_co + c0, rv);
+          } else {
+            const uint4 t = rpre[pt][c];
+            rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
+            rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
+            rv[4] = __uint_as_float(t.z << 16); rv[5] = __uint_as_float(t.z & 0xffff0000u);
+            rv[6] = __uint_as_float(t.w << 16); rv[7] = __uint_as_float(t.w & 0xffff0000u);
+          }
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] += rv[r];
         }

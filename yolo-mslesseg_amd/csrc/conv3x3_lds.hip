@@ -58,7 +58,8 @@ __device__ __forceinline__ int halo_byte(int s, int g) { return ((s >> 2) << 8) 
 // packed in that order, include/mslesseg_hip.h op.i[25]): bias, optional statistics of the stored values, SiLU, residual, 16-byte stores.
 template <bool F32, int COT>
 __device__ __forceinline__ void store_pixel_b(const Conv3Args& a, long pix, int co0, const f32x4 (&accp)[COT], float (&s1)[COT][4], float (&s2)[COT][4],
-                                              const float (&bias)[COT * 4]) {  // bias = a.bias[co0 .. co0 + 4 * COT) held in registers
+                                              const float (&bias)[COT * 4],  // bias = a.bias[co0 .. co0 + 4 * COT) held in registers
+                                              const uint4* rpre = nullptr) {  // bf16, COT >= 2: the residual's 8-channel runs of this pixel, already in registers
   if (co0 >= a.Cout) return;  // Cout = 8: the upper half of the single 16-row block is zero padding
   float v[COT * 4];
 #pragma unroll
@@ -92,7 +93,15 @@ __device__ __forceinline__ void store_pixel_b(const Conv3Args& a, long pix, int 
       for (int r = 0; r < 8; ++r) v8[r] = v[h * 8 + r];
       if (a.res) {
         float rv[8];
-        ldv<F32, 8>(a.res, ri + h * 8, rv);
+        if (!F32 && rpre) {
+          const uint4 t = rpre[h];
+          rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
+          rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
+          rv[4] = __uint_as_float(t.z << 16); rv[5] = __uint_as_float(t.z & 0xffff0000u);
+          rv[6] = __uint_as_float(t.w << 16); rv[7] = __uint_as_float(t.w & 0xffff0000u);
+        } else {
+          ldv<F32, 8>(a.res, ri + h * 8, rv);
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) v8[r] += rv[r];
       }
@@ -495,6 +504,30 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
     }
   };
 
+  // residual of a tile (bf16, full 64-channel blocks: an input gradient that adds to what its view holds), fetched BEFORE the tile's last chunk of
+  // MFMAs into registers.  Loaded inside the store loop, every run's load is followed by hipcc's vmcnt(0): a round trip, plus the acknowledgement
+  // of the previous run's stores, per 8 channels.  Every lane loads (clamped coordinates); lanes outside the image discard.
+  constexpr bool RPRE = !F32 && !FUSE && COT >= 2;
+  uint4 rpre[RPRE ? PT : 1][RPRE ? COT / 2 : 1];
+  auto prefetch_res = [&](int k) __attribute__((always_inline)) {
+    if constexpr (RPRE) {
+      int t = tbase + gi + k * G2;
+      const int n = t / tiles_per_img;
+      t -= n * tiles_per_img;
+      const int tyi = t / a.tiles_x, txi = t - tyi * a.tiles_x;
+      const int co0 = cob * COB + g * (4 * COT);
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        int oy = tyi * T::TH + wave * 2 + (p >> 1), ox = txi * T::TW + (p & 1) * 16 + lp;
+        oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+        const long pix = ((long)n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+        for (int h = 0; h < COT / 2; ++h)
+          rpre[p][h] = *(const uint4*)((const unsigned short*)a.res + pix * a.res_cs + a.res_co + (co0 < a.Cout ? co0 : 0) + h * 8);
+      }
+    }
+  };
+
   auto epilogue = [&](int k) __attribute__((always_inline)) {  // tile k of this group: bias + SiLU (+ residual) → store; statistics into registers; accumulators reset
     int t = tbase + gi + k * G2;
     const int n = t / tiles_per_img;
@@ -545,7 +578,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
         f32x4 accp[COT];
 #pragma unroll
         for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
-        store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r);
+        store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r, RPRE ? rpre[p] : nullptr);
       }
 #pragma unroll
       for (int c = 0; c < COT; ++c) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -563,6 +596,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
     if (un >= 0 && un < my_units) stage(un, ring_g + (PAR ^ 1) * IN_BYTES);
     const bool live = u >= 0 && u < my_units;
     const int cc = NCH == 2 ? (u & 1) : 0;
+    if (live && cc == NCH - 1 && a.res) prefetch_res(u / NCH);
     if (live) compute(cc, ring_g + PAR * IN_BYTES);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA issued above had the MFMAs to land; waited for BEFORE the epilogue so that its stores stay in flight
     if (live && cc == NCH - 1) epilogue(u / NCH);

@@ -19,6 +19,37 @@
 // same-address RETURNING atomics, ~150 ns each, 4x slower than the separate finalize launch; and summing the copies in
 // every BN_ACT workgroup — the 2C x slots fp64 loads outweigh the small layers' own traffic.)
 // =========================================================================================================
+// Raw V-element loads for the streaming loops: the registers are converted where they are USED, so that a whole batch of loads (and the next
+// batch, issued before the current one is stored) is in flight per thread.  ldv() converts at the load, which pins hipcc's wait right behind it.
+template <bool F32, int V> struct RawV;
+template <> struct RawV<false, 8> { uint4 t; };
+template <> struct RawV<false, 4> { uint2 t; };
+template <> struct RawV<true, 4> { float4 t; };
+template <> struct RawV<true, 8> { float4 t, u; };
+template <bool F32, int V>
+__device__ __forceinline__ RawV<F32, V> ldraw(const void* p, long i) {
+  RawV<F32, V> r;
+  if constexpr (!F32 && V == 8) r.t = *(const uint4*)((const unsigned short*)p + i);
+  else if constexpr (!F32) r.t = *(const uint2*)((const unsigned short*)p + i);
+  else if constexpr (V == 4) r.t = *(const float4*)((const float*)p + i);
+  else { r.t = *(const float4*)((const float*)p + i); r.u = *(const float4*)((const float*)p + i + 4); }
+  return r;
+}
+template <bool F32, int V>
+__device__ __forceinline__ void cvtraw(const RawV<F32, V>& r, float (&v)[V]) {
+  if constexpr (!F32) {
+    v[0] = __uint_as_float(r.t.x << 16); v[1] = __uint_as_float(r.t.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.t.y << 16); v[3] = __uint_as_float(r.t.y & 0xffff0000u);
+    if constexpr (V == 8) {
+      v[4] = __uint_as_float(r.t.z << 16); v[5] = __uint_as_float(r.t.z & 0xffff0000u);
+      v[6] = __uint_as_float(r.t.w << 16); v[7] = __uint_as_float(r.t.w & 0xffff0000u);
+    }
+  } else {
+    v[0] = r.t.x; v[1] = r.t.y; v[2] = r.t.z; v[3] = r.t.w;
+    if constexpr (V == 8) { v[4] = r.u.x; v[5] = r.u.y; v[6] = r.u.z; v[7] = r.u.w; }
+  }
+}
+
 typedef float f2_t __attribute__((ext_vector_type(2)));
 #define MSL_MAX_SLOTS 16
 // V = channels per thread: 8 (one 16-byte access of bf16) when the channel count and the views allow it, else 4
@@ -230,31 +261,47 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z,
     if (fin.acc) { mu[r] = ks[2 * (c + r)]; is[r] = ks[2 * (c + r) + 1]; } else { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; }
     ga[r] = gamma[c + r]; be[r] = beta[c + r];
   }
+  // pixel of (k, u) = p0 + (k + u) * PL.  Batches of U pixel groups: the loads of batch k + 1 are issued (every lane, clamped to the last pixel —
+  // a load under a per-lane condition is branched around and waited for one by one) before batch k is computed and stored, so a thread always has
+  // U (2U with a residual) 16-byte loads in flight and never waits for its own stores.
   const long p0 = (long)blockIdx.x * PL * PPT + pl;
-  constexpr int U = V == 8 ? 2 : 4;
+  constexpr int U = 4;  // PPT is a multiple of 4
+  RawV<F32, V> za[U], ra[U], zb[U], rb[U];
+  auto issue = [&](int k, RawV<F32, V> (&zz)[U], RawV<F32, V> (&rr)[U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long p = p0 + (long)(k + u) * PL;
+      p = p < M ? p : M - 1;
+      zz[u] = ldraw<F32, V>(z, p * z_cs + z_co + c);
+    }
+    if (res) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        long p = p0 + (long)(k + u) * PL;
+        p = p < M ? p : M - 1;
+        rr[u] = ldraw<F32, V>(res, p * r_cs + r_co + c);
+      }
+    }
+  };
+  issue(0, za, ra);
   for (int k = 0; k < PPT; k += U) {
-    float v[U][V], rv[U][V];
+    if (k + U < PPT) issue(k + U, zb, rb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long p = p0 + (long)(k + u) * PL;
-      if (p < M) {
-        ldv<F32, V>(z, p * z_cs + z_co + c, v[u]);
-        if (res) ldv<F32, V>(res, p * r_cs + r_co + c, rv[u]);
+      float v[V], rv[V];
+      cvtraw<F32, V>(za[u], v);
+      if (res) cvtraw<F32, V>(ra[u], rv);
+#pragma unroll
+      for (int r = 0; r < V; ++r) {
+        const float t = fmaf(ga[r], (v[r] - mu[r]) * is[r], be[r]);  // same expression as the backward's zhat: no cancellation against the mean
+        v[r] = act ? silu_f(t) : t;
+        if (res) v[r] += rv[r];
       }
+      if (p < M) stv<F32, V>(y, p * y_cs + y_co + c, v);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long p = p0 + (long)(k + u) * PL;
-      if (p < M) {
-#pragma unroll
-        for (int r = 0; r < V; ++r) {
-          const float t = fmaf(ga[r], (v[u][r] - mu[r]) * is[r], be[r]);  // same expression as the backward's zhat: no cancellation against the mean
-          v[u][r] = act ? silu_f(t) : t;
-          if (res) v[u][r] += rv[u][r];
-        }
-        stv<F32, V>(y, p * y_cs + y_co + c, v[u]);
-      }
-    }
+    for (int u = 0; u < U; ++u) { za[u] = zb[u]; ra[u] = rb[u]; }
   }
 }
 
@@ -329,38 +376,47 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
     k2[r] = ks[2 * (c + r) + 1] * invM;
   }
   const long p0 = (long)blockIdx.x * PL * PPT + pl;  // pixel of (k,u) = p0 + (k+u)*PL: every load instruction covers PL consecutive pixels
-  constexpr int U = V == 8 ? 2 : 4;
+  constexpr int U = 4;  // batches of U pixel groups, software-pipelined like bn_act_kernel: 2U loads of the next batch in flight while this one is stored
+  RawV<F32, V> ga_[U], za_[U], gb_[U], zb_[U];
+  auto issue = [&](int k, RawV<F32, V> (&gg)[U], RawV<F32, V> (&zz)[U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long p = p0 + (long)(k + u) * PL;
+      p = p < M ? p : M - 1;
+      gg[u] = ldraw<F32, V>(dy, p * dy_cs + dy_co + c);
+      zz[u] = ldraw<F32, V>(z, p * z_cs + z_co + c);
+    }
+  };
+  issue(0, ga_, za_);
   for (int k = 0; k < PPT; k += U) {
-    float g[U][V], v[U][V];
+    if (k + U < PPT) issue(k + U, gb_, zb_);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long p = p0 + (long)(k + u) * PL;
-      if (p < M) { ldv<F32, V>(dy, p * dy_cs + dy_co + c, g[u]); ldv<F32, V>(z, p * z_cs + z_co + c, v[u]); }
-    }
+      float g[V], v[V];
+      cvtraw<F32, V>(ga_[u], g);
+      cvtraw<F32, V>(za_[u], v);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long p = p0 + (long)(k + u) * PL;
-      if (p < M) {
-#pragma unroll
-        for (int r = 0; r < V; r += 2) {  // float pairs → packed fp32 ops (see chan_reduce_kernel)
-          const f2_t z2 = {v[u][r], v[u][r + 1]}, mu2 = {mu[r], mu[r + 1]}, is2 = {is[r], is[r + 1]}, ga2 = {ga[r], ga[r + 1]};
-          const f2_t zh = (z2 - mu2) * is2;
-          f2_t gg = {g[u][r], g[u][r + 1]};
-          if (act) {
-            const f2_t be2 = {be[r], be[r + 1]};
-            const f2_t uu = ga2 * zh + be2;
-            const f2_t t = uu * -1.44269504088896f;
-            const f2_t den = (f2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-            const f2_t sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            gg = gg * (sg * (uu * (1.0f - sg) + 1.0f));
-          }
-          const f2_t k02 = {k0[r], k0[r + 1]}, k22 = {k2[r], k2[r + 1]};
-          const f2_t o = ga2 * is2 * (gg - k02 - zh * k22);
-          v[u][r] = o.x; v[u][r + 1] = o.y;
+      for (int r = 0; r < V; r += 2) {  // float pairs → packed fp32 ops (see chan_reduce_kernel)
+        const f2_t z2 = {v[r], v[r + 1]}, mu2 = {mu[r], mu[r + 1]}, is2 = {is[r], is[r + 1]}, ga2 = {ga[r], ga[r + 1]};
+        const f2_t zh = (z2 - mu2) * is2;
+        f2_t gg = {g[r], g[r + 1]};
+        if (act) {
+          const f2_t be2 = {be[r], be[r + 1]};
+          const f2_t uu = ga2 * zh + be2;
+          const f2_t t = uu * -1.44269504088896f;
+          const f2_t den = (f2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+          const f2_t sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+          gg = gg * (sg * (uu * (1.0f - sg) + 1.0f));
         }
-        stv<F32, V>(dz, p * dz_cs + dz_co + c, v[u]);
+        const f2_t k02 = {k0[r], k0[r + 1]}, k22 = {k2[r], k2[r + 1]};
+        const f2_t o = ga2 * is2 * (gg - k02 - zh * k22);
+        v[r] = o.x; v[r + 1] = o.y;
       }
+      if (p < M) stv<F32, V>(dz, p * dz_cs + dz_co + c, v);
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ga_[u] = gb_[u]; za_[u] = zb_[u]; }
   }
 }
 
