@@ -480,6 +480,10 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
     a.tiles_y = (a.Ho + TH - 1) / TH;
     a.total_tiles = (long)a.N * a.tiles_y * a.tiles_x;
   }
+  // the staging offsets are 32-bit: byte offsets from a tile's origin inside its halo / gradient tile, and the tile index itself
+  MSL_REQUIRE(a.total_tiles < (1L << 31) && ((long)(2 * TH + 2) * a.W + 80) * a.x_cs * 2 < (1L << 31) && ((long)TH * a.Wo + 32) * a.z_cs * 2 < (1L << 31) &&
+                  (long)TH * 32 * (a.x_cs > a.z_cs ? a.x_cs : a.z_cs) * 2 < (1L << 31),
+              "conv_wgrad_tr: image rows too long for 32-bit staging offsets");
   const int ny = ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
   long want = 256 / ny;  // one 8-wave workgroup per CU (its ring of staged tiles takes the LDS): never more workgroups than CUs, a second round doubles the time
   if (want < 1) want = 1;
