@@ -588,6 +588,26 @@ def main():
             if not args.no_infer and world == 1:
                 del tr, dbatch
                 torch.cuda.empty_cache()
+                if B == 128 and args.mode == "train":
+                    # the same step at the batch the reference's call `model.train(batch=-1)` resolves to in this library (train.py: 256 slices per GPU)
+                    tr2, db2, _ = train_setup(args, dev, rank, world, state, 256)
+
+                    def step2():
+                        tr2.forward_backward(db2)
+                        tr2.optimizer_step(tr2.lr0)
+
+                    for _ in range(3):
+                        step2()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(8):
+                        step2()
+                    torch.cuda.synchronize(dev)
+                    d2 = (time.perf_counter() - t0) / 8
+                    line["batch_256"] = {"value": round(256 / d2, 2), "unit": "slices/s (1 GPU)", "ms_per_step": round(d2 * 1e3, 3), "per_gpu_batch": 256,
+                                         "note": "what batch=-1 resolves to; the headline `value` stays at batch 128 (north_star: batch >= 128) for continuity with round 1"}
+                    del tr2, db2
+                    torch.cuda.empty_cache()
                 line["infer"] = {}
                 # the inference leg in both arithmetic modes: fp32 = the default of YOLO() predict (exact parity with the CPU path: identical NMS
                 # indices and mask bytes, tests/test_gpu_trained.py), bf16 = the opt-in throughput mode
