@@ -63,6 +63,8 @@ CONV_CASES = [
     (1, 50, 50, 64, 48, 1, 1, 64, 0, 48, 0, 0, 1, 0),      # Cout = 48: half-filled output group; dgrad-like (no act, accumulate)
     (1, 30, 30, 32, 64, 1, 1, 32, 0, 64, 0, 0, 0, 1),      # fp32 output (box head)
     (1, 20, 20, 128, 96, 1, 1, 128, 0, 96, 0, 1, 0, 0),
+    (4, 79, 81, 64, 64, 1, 1, 64, 0, 64, 0, 0, 1, 0),      # accumulate (residual prefetched before the MFMAs) over many slices per wave, ragged last slice
+    (3, 61, 67, 32, 256, 1, 1, 32, 0, 256, 0, 1, 1, 0),    # 8 output groups with residual: 16-pixel slices, stores left in flight across the loop-top wait
     (2, 20, 20, 384, 128, 1, 1, 384, 0, 128, 0, 1, 0, 0),  # too wide for LDS → generic kernel
     # YOLO11s-seg widths (BASELINE configs[2])
     (1, 20, 20, 768, 256, 1, 1, 768, 0, 256, 0, 1, 0, 0),    # model.13.cv1 at scale s: K = 768 from the neck concat
@@ -121,6 +123,7 @@ LDS3_CASES = [
     (1, 20, 20, 8, 32, 2, 8, 0, 32, 0, 0, 0, 1),         # stride 2, fp32 output
     (2, 30, 45, 16, 8, 1, 16, 0, 8, 0, 1, 0, 0),         # Cout = 8: one 16-row block, upper half zero (C3k2 bottleneck of the 160² level)
     (1, 17, 33, 32, 8, 1, 32, 0, 24, 8, 1, 1, 0),        # Cout = 8 into a concat slice with residual
+    (6, 96, 100, 64, 64, 1, 64, 0, 64, 0, 0, 1, 0),      # input-gradient-like accumulate over several tiles per wave group (persistent form: residual prefetch per tile), ragged columns
     # YOLO11s-seg widths (BASELINE configs[2]): 4 / 8 / 16 channel chunks, 2-8 output blocks
     (1, 24, 40, 128, 128, 1, 128, 0, 128, 0, 1, 1, 0),   # proto.cv2 / bottlenecks at scale s
     (1, 20, 20, 256, 256, 2, 256, 0, 256, 0, 1, 0, 0),   # model.5 at scale s
