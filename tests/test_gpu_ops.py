@@ -66,6 +66,12 @@ CONV_CASES = [
     (4, 79, 81, 64, 64, 1, 1, 64, 0, 64, 0, 0, 1, 0),      # accumulate (residual prefetched before the MFMAs) over many slices per wave, ragged last slice
     (3, 61, 67, 32, 256, 1, 1, 32, 0, 256, 0, 1, 1, 0),    # 8 output groups with residual: 16-pixel slices, stores left in flight across the loop-top wait
     (2, 20, 20, 384, 128, 1, 1, 384, 0, 128, 0, 1, 0, 0),  # too wide for LDS → generic kernel
+    # tiled 1x1 GEMM (bf16; weights too wide for the streaming kernel's LDS, >= 8192 pixels): 128 x 128 tiles, K chunks of 64
+    (16, 40, 40, 384, 128, 1, 1, 384, 0, 128, 0, 1, 0, 0),   # model.16-like: 6 whole chunks, one channel tile
+    (7, 37, 41, 256, 256, 1, 1, 384, 128, 448, 64, 1, 1, 0),  # ragged pixel count, concat slices both ways, residual, two channel tiles
+    (6, 40, 40, 320, 320, 1, 1, 320, 0, 320, 0, 0, 1, 0),    # K tail (320 = 5 chunks), Cout = 320: a partial third channel tile; accumulate
+    (5, 40, 48, 512, 384, 1, 1, 512, 0, 384, 0, 0, 0, 1),    # fp32 output, 8 chunks, three channel tiles
+    (24, 20, 20, 288, 256, 1, 1, 288, 0, 256, 0, 1, 0, 0),   # K = 288: the last chunk holds 32 channels
     # YOLO11s-seg widths (BASELINE configs[2])
     (1, 20, 20, 768, 256, 1, 1, 768, 0, 256, 0, 1, 0, 0),    # model.13.cv1 at scale s: K = 768 from the neck concat
     (1, 10, 10, 1024, 512, 1, 1, 1024, 0, 512, 0, 1, 0, 0),  # SPPF.cv2 at scale s: K = 1024, Cout = 512 (2 x 256)

@@ -244,6 +244,205 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions whose weight matrix does not fit LDS next to the per-wave rings (K >= 256 with 256 outputs, K = 384 / 512: the C3k2 / C2PSA /
+// SPPF output convs of the 40² and 20² levels and their input gradients): a plain tiled GEMM  D[co][p] = W[co][k] * X[k][p].
+// Workgroup = 128 pixels x 128 output channels, 4 waves as 2 x 2 (64 pixels x 64 channels each: 4 pixel tiles x 2 channel groups of 32 → 16
+// accumulator tiles, every fragment read feeds 2-4 MFMAs); K in chunks of 64 channels, both operand tiles staged by LDS-DMA into a 2-deep ring
+// (rows of 144 bytes like the streaming kernel: 128 data + 16 pad), one barrier per chunk, the next chunk in flight under the MFMAs.  The lane-
+// dependent half of every source address is computed once; tile origin and chunk go into a buffer descriptor's base and scalar offset; lanes that
+// must read zero (rows beyond M / the weight rows, channels beyond Cin / Kpad, the pad chunk) carry an out-of-range offset (see conv_wgrad_tr.hip).
+// Epilogue as the streaming kernel's (permuted A rows → 8 consecutive channels per lane, one 16-byte store), bias from LDS, residual prefetched.
+// These layers ran through conv_igemm_kernel before (no staging pipeline, loads under per-lane conditions): 45-110 us each at batch 128.
+typedef int c1_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c1_i32x4 c1_rsrc(const void* p) {
+  const unsigned long u = (unsigned long)p;
+  c1_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+  r.z = (int)0x80000000u;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void c1_dma16(c1_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
+}
+
+struct G1Args {
+  const char* x; const char* w; const float* bias; const char* res; char* y;
+  long M;
+  int Cin, Cout, Kpad, w_rows, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, ntn;
+};
+
+__global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
+  constexpr int BM = 128, BN = 128, BK = 64, PITCH = BK * 2 + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
+  constexpr int PIECES = BM * CPR / 64;                                               // 18 per operand tile
+  constexpr int TILE = PIECES * 1024, STAGE = 2 * TILE;
+  constexpr int KP = (PIECES + 3) / 4;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_bias = (float*)(smem + 2 * STAGE);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4, wm = wave & 1, wn = wave >> 1;
+  const int tn = blockIdx.x % a.ntn;
+  const long tm = blockIdx.x / a.ntn;
+  const long p0 = tm * BM;
+  const int n0 = tn * BN;
+  for (int i = threadIdx.x; i < BN; i += 256) s_bias[i] = (a.bias && n0 + i < a.Cout) ? a.bias[n0 + i] : 0.f;
+
+  // residual of this lane's 8 store groups (bf16 views), requested first
+  uint4 rpre[4][2];
+  if (a.res) {
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      long p = p0 + wm * 64 + pt * 16 + li;
+      p = p < a.M ? p : a.M - 1;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int c0 = n0 + wn * 64 + c * 32 + 8 * g;
+        rpre[pt][c] = *(const uint4*)((const unsigned short*)a.res + p * a.res_cs + a.res_co + (c0 < a.Cout ? c0 : 0));
+      }
+    }
+  }
+
+  // lane-dependent staging offsets, fixed over the K loop (piece pc = wave + 4k covers LDS bytes [pc * 1024, +1024) of the tile image)
+  unsigned xo[KP], wo[KP], chn[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const int cidx = (wave + 4 * k) * 64 + lane, row = cidx / CPR, ch = cidx - row * CPR;
+    const bool data = row < BM && ch < CPR - 1;
+    xo[k] = (data && p0 + row < a.M) ? (unsigned)(row * a.x_cs * 2 + ch * 16) : OOB;
+    wo[k] = (data && n0 + row < a.w_rows) ? (unsigned)(row * a.Kpad * 2 + ch * 16) : OOB;
+    chn[k] = (unsigned)ch * 8;
+  }
+  const c1_i32x4 rx = c1_rsrc(a.x + (p0 * a.x_cs + a.x_co) * 2);
+  const c1_i32x4 rw = c1_rsrc(a.w + (long)n0 * a.Kpad * 2);
+  const unsigned lbase = msl_lds_addr(smem);
+  const int nk = (a.Kpad + BK - 1) / BK;
+
+  auto stage = [&](int kc, int buf) __attribute__((always_inline)) {
+    const unsigned lw = lbase + buf * STAGE, lx = lw + TILE;
+    const unsigned soff = (unsigned)kc * (BK * 2);
+    const int xleft = a.Cin - kc * BK, wleft = a.Kpad - kc * BK;  // channels of this chunk that exist (x) / are stored (packed weights)
+    const bool tail = xleft < BK || wleft < BK;                    // only the last chunk can be partial
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int pc = wave + 4 * k;
+      if (pc >= PIECES) break;
+      unsigned vx = xo[k], vw = wo[k];
+      if (tail) {
+        vx = (int)chn[k] < xleft ? vx : OOB;
+        vw = (int)chn[k] < wleft ? vw : OOB;
+      }
+      c1_dma16(rw, __builtin_amdgcn_readfirstlane(lw + pc * 1024), vw, soff);
+      c1_dma16(rx, __builtin_amdgcn_readfirstlane(lx + pc * 1024), vx, soff);
+    }
+  };
+
+  f32x4 acc[4][2][2];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[pt][c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int arow = 8 * (li >> 2) + (li & 3);  // A-operand row permutation: MFMA row 4g+r of tile m ↔ channel 8g + 4m + r (conv1x1_kernel)
+
+  stage(0, 0);
+  for (int kc = 0; kc < nk; ++kc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of chunk kc (and, first time round, the residual) have landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone's have, and everyone is done reading the buffer refilled next
+    if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
+    const unsigned char* sw_ = smem + (kc & 1) * STAGE;
+    const unsigned char* sx_ = sw_ + TILE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int kb = (ks * 32 + 8 * g) * 2;
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) bfr[pt] = *(const bf16x8*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x8 af = *(const bf16x8*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
+        }
+    }
+  }
+  // ---- epilogue: lane (li, g) holds channels n0 + wn*64 + c*32 + 8g .. +7 of pixel p0 + wm*64 + 16*pt + li
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    const long p = p0 + wm * 64 + pt * 16 + li;
+    if (p >= a.M) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cl = wn * 64 + c * 32 + 8 * g, c0 = n0 + cl;
+      if (c0 >= a.Cout) continue;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[pt][c][0][r]; v[4 + r] = acc[pt][c][1][r]; }
+      {
+        const float4 b0 = *(const float4*)(s_bias + cl), b1 = *(const float4*)(s_bias + cl + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (a.act) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+      }
+      if (a.res) {
+        const uint4 t = rpre[pt][c];
+        v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
+        v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
+        v[4] += __uint_as_float(t.z << 16); v[5] += __uint_as_float(t.z & 0xffff0000u);
+        v[6] += __uint_as_float(t.w << 16); v[7] += __uint_as_float(t.w & 0xffff0000u);
+      }
+      const long oi = p * a.y_cs + a.y_co + c0;
+      if (a.out_f32) stv<true, 8>(a.y, oi, v);
+      else stv<false, 8>(a.y, oi, v);
+    }
+  }
+}
+
+// Eligibility (msl_launch_conv tries this after the streaming kernel): bf16 1x1 / stride 1 / pad 0, plain store, no statistics, 8-aligned views,
+// enough pixels to fill the chip with 128-pixel tiles.
+bool msl_gemm1x1_eligible(const msl_op& op) {
+  const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
+  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0 || op.p[5] || !op.p[1]) return false;
+  if (Cin % 8 || Cout % 8 || Kpad % 32 || Kpad < Cin || Cin < 64) return false;
+  if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) return false;
+  if (op.p[3] && ((op.i[14] | op.i[15]) & 7)) return false;
+  const long M = (long)op.i[0] * op.i[1] * op.i[2];
+  return M >= 128 * 64 && (long)128 * op.i[10] * 2 < (1L << 31) && (long)128 * Kpad * 2 < (1L << 31);
+}
+
+int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
+  G1Args a;
+  a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2]; a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];
+  a.M = (long)op.i[0] * op.i[1] * op.i[2];
+  a.Cin = op.i[3]; a.Cout = op.i[6]; a.Kpad = op.i[17];
+  a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
+  a.act = op.i[18]; a.out_f32 = op.i[19];
+  a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
+  MSL_REQUIRE(a.x && a.w && a.y && msl_gemm1x1_eligible(op), "gemm1x1: bad args");
+  MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs && (!a.res || a.res_co + a.Cout <= a.res_cs), "gemm1x1: bad dims / views");
+  a.ntn = (a.Cout + 127) / 128;
+  const long tiles = (a.M + 127) / 128 * a.ntn;
+  MSL_REQUIRE(tiles < (1L << 31), "gemm1x1: too many tiles");
+  constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm1x1_kernel, dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  MSL_CHECK_LAUNCH("gemm1x1");
+  return MSL_OK;
+}
+
 // ---- host
 static size_t c1_lds(int ncp, int Kpad, int pt, int nw = 4, int es = 2) {
   const int cps = (Kpad * es + 16) / 16;

@@ -83,7 +83,16 @@ __device__ __forceinline__ void store_pixel_b(const Conv3Args& a, long pix, int 
   const long ri = pix * a.res_cs + a.res_co + co0, oi = pix * a.y_cs + a.y_co + co0;
   if constexpr (COT == 1) {
     float (&v4)[4] = v;
-    if (a.res) { float rv[4]; ld4<F32>(a.res, ri, rv); for (int r = 0; r < 4; ++r) v4[r] += rv[r]; }
+    if (a.res) {
+      float rv[4];
+      if (!F32 && rpre) {  // bf16: the 4-channel run already in registers (.x, .y)
+        rv[0] = __uint_as_float(rpre[0].x << 16); rv[1] = __uint_as_float(rpre[0].x & 0xffff0000u);
+        rv[2] = __uint_as_float(rpre[0].y << 16); rv[3] = __uint_as_float(rpre[0].y & 0xffff0000u);
+      } else {
+        ld4<F32>(a.res, ri, rv);
+      }
+      for (int r = 0; r < 4; ++r) v4[r] += rv[r];
+    }
     if (a.out_f32) st4<true>(a.y, oi, v4); else st4<F32>(a.y, oi, v4);
   } else {
 #pragma unroll
@@ -107,6 +116,21 @@ __device__ __forceinline__ void store_pixel_b(const Conv3Args& a, long pix, int 
       }
       if (a.out_f32) stv<true, 8>(a.y, oi + h * 8, v8); else stv<F32, 8>(a.y, oi + h * 8, v8);
     }
+  }
+}
+
+// bf16 residual of one pixel for this lane (runs of 8 channels; COT = 1: one run of 4 in .x/.y), from a clamped — always valid — address.
+// Fetched for all pixels of a tile BEFORE the store loop: loaded inside it, every run is followed by hipcc's vmcnt(0), a round trip plus
+// the acknowledgement of the previous run's stores.
+template <int COT>
+__device__ __forceinline__ void load_res_bf16(const Conv3Args& a, long pix, int co0, uint4 (&rp)[COT >= 2 ? COT / 2 : 1]) {
+  const unsigned short* r = (const unsigned short*)a.res + pix * a.res_cs + a.res_co + (co0 < a.Cout ? co0 : 0);
+  if constexpr (COT == 1) {
+    const uint2 t = *(const uint2*)r;
+    rp[0] = make_uint4(t.x, t.y, 0u, 0u);
+  } else {
+#pragma unroll
+    for (int h = 0; h < COT / 2; ++h) rp[h] = *(const uint4*)(r + h * 8);
   }
 }
 
@@ -269,6 +293,18 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
   float bias_r[COT * 4];
   load_bias<COT>(a, cob * COB + g * (4 * COT), bias_r);
+  uint4 rpre[F32 ? 1 : PT][COT >= 2 ? COT / 2 : 1];
+  if constexpr (!F32) {
+    if (a.res) {
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
+        oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+        const long pix = a.lat < 0 ? ((long)n * a.Ho + oy) * a.Wo + ox : ((long)n * a.full_h + 2 * oy + (a.lat & 1)) * a.full_w + 2 * ox + (a.lat >> 1);
+        load_res_bf16<COT>(a, pix, cob * COB + g * (4 * COT), rpre[p]);
+      }
+    }
+  }
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
@@ -277,7 +313,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     f32x4 accp[COT];
 #pragma unroll
     for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
-    store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r);
+    store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r, F32 ? nullptr : rpre[p]);
   }
   if (a.acc) {  // block-uniform: fold over the 16 pixel lanes, over the 4 waves (LDS), then one fp64 atomic per channel and statistic
     __syncthreads();  // every wave is done with the staged tiles
@@ -768,6 +804,15 @@ __global__ __launch_bounds__(256, 2) void conv_s2dgrad_lds_kernel(Conv3Args a) {
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int Y = Y0 + wave * 2 + (p >> 1), X = X0 + (p & 1) * 16 + lp;
+    uint4 rpre[4][COT >= 2 ? COT / 2 : 1];  // the residual of the 2 x 2 output pixels, requested together (see load_res_bf16)
+    if (a.res) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int oy = 2 * Y + (k >> 1), ox = 2 * X + (k & 1);
+        oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
+        load_res_bf16<COT>(a, ((long)n * a.Ho + oy) * a.Wo + ox, cob * COB + g * (4 * COT), rpre[k]);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int oy = 2 * Y + (k >> 1), ox = 2 * X + (k & 1);
@@ -776,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2dgrad_lds_kernel(Conv3Args a) {
       f32x4 accp[COT];
 #pragma unroll
       for (int c = 0; c < COT; ++c) accp[c] = acc[k][c][p];
-      store_pixel_b<false, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r);
+      store_pixel_b<false, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r, rpre[k]);
     }
   }
 }

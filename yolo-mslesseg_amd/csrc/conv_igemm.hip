@@ -246,6 +246,7 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
       return MSL_OK;
     }
   }
+  if (msl_gemm1x1_eligible(op)) return msl_launch_gemm1x1(op, s);  // wide 1x1 whose weights do not fit the streaming kernel's LDS: tiled GEMM (conv1x1.hip)
   MSL_REQUIRE(!op.p[5], "conv: the BatchNorm-statistics epilogue (p[5]) exists only in the 1x1 streaming kernel and this op is not eligible for it");
   ConvArgs a;
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2];

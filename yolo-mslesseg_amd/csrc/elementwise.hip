@@ -188,15 +188,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
                                                      int y_cs, int y_co, int res_cs, int res_co, int act, int gsz,
                                                      int gstride, int goff, int flip, int omap) {
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [10][C]: 9 taps (already flipped if asked) + bias
-  for (int i = threadIdx.x; i < 10 * C; i += 256) {
-    const int t = i / C, ch = i - t * C;
-    sw[i] = t < 9 ? w[(flip ? 8 - t : t) * C + ch] : bias[ch];
-  }
-  __syncthreads();
   const int CV = C / V, Wp = (W + 1) >> 1;
-  const long t = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  const long t_ = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   const long total = (long)N * H * Wp * CV;
-  if (t >= total) return;
+  const long t = t_ < total ? t_ : total - 1;  // surplus threads of the last workgroup shadow its last item until the barrier, then leave
   const int c = (int)(t % CV) * V;
   const long pr = t / CV;
   const int xp = (int)(pr % Wp);
@@ -207,6 +202,33 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   const int cmap = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
   const int cin = omap ? c : cmap;    // channel map on the input side (Attention.pe forward) ...
   const int cdst = omap ? cmap : c;   // ... or on the output/residual side (its backward: gradient lands in the v slots of qkv)
+  // the whole 3 x 4 input window (and the residual) is requested up front, every lane from a valid — clamped — address: 12 independent
+  // 16-byte loads in flight.  Loads under the edge conditions were branched around one by one, each followed by vmcnt(0): twelve
+  // dependent round trips per thread.  Which taps COUNT is still decided by the edge tests below; the arithmetic order is unchanged.
+  const long p0 = ((long)n * H + iy) * W + x0;
+  RawV<F32, V> win[3][4], rr0, rr1;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int yy = iy - 1 + ky;
+    yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int xx = x0 - 1 + j;
+      xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+      win[ky][j] = ldraw<F32, V>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin);
+    }
+  }
+  if (res) {
+    rr0 = ldraw<F32, V>(res, p0 * res_cs + res_co + cdst);
+    rr1 = ldraw<F32, V>(res, (two ? p0 + 1 : p0) * res_cs + res_co + cdst);
+  }
+  // the filter bank goes to LDS while the window is in flight
+  for (int i = threadIdx.x; i < 10 * C; i += 256) {
+    const int tp = i / C, ch = i - tp * C;
+    sw[i] = tp < 9 ? w[(flip ? 8 - tp : tp) * C + ch] : bias[ch];
+  }
+  __syncthreads();
+  if (t_ >= total) return;
   float acc0[V], acc1[V];
 #pragma unroll
   for (int r = 0; r < V; ++r) { acc0[r] = sw[9 * C + c + r]; acc1[r] = acc0[r]; }
@@ -216,14 +238,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
     if ((unsigned)yy >= (unsigned)H) continue;
     float col[4][V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int xx = x0 - 1 + j;
-      if ((unsigned)xx < (unsigned)W) ldv<F32, V>(x, (((long)n * H + yy) * W + xx) * x_cs + x_co + cin, col[j]);
-      else {
-#pragma unroll
-        for (int r = 0; r < V; ++r) col[j][r] = 0.f;
-      }
-    }
+    for (int j = 0; j < 4; ++j) cvtraw<F32, V>(win[ky][j], col[j]);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const float* wr = sw + (ky * 3 + kx) * C + c;
@@ -236,18 +251,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
       }
     }
   }
-  const long p0 = ((long)n * H + iy) * W + x0;
   if (act) {
 #pragma unroll
     for (int r = 0; r < V; ++r) { acc0[r] = silu_f(acc0[r]); acc1[r] = silu_f(acc1[r]); }
   }
   if (res) {
     float rv[V];
-    ldv<F32, V>(res, p0 * res_cs + res_co + cdst, rv);
+    cvtraw<F32, V>(rr0, rv);
 #pragma unroll
     for (int r = 0; r < V; ++r) acc0[r] += rv[r];
     if (two) {
-      ldv<F32, V>(res, (p0 + 1) * res_cs + res_co + cdst, rv);
+      cvtraw<F32, V>(rr1, rv);
 #pragma unroll
       for (int r = 0; r < V; ++r) acc1[r] += rv[r];
     }

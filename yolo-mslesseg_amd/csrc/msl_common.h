@@ -114,6 +114,37 @@ __device__ __forceinline__ void stv(void* p, long i, const float (&v)[V]) {
 }
 
 
+// Raw V-element loads for the streaming loops: the registers are converted where they are USED, so that a whole batch of loads (and the next
+// batch, issued before the current one is stored) is in flight per thread.  ldv() converts at the load, which pins hipcc's wait right behind it.
+template <bool F32, int V> struct RawV;
+template <> struct RawV<false, 8> { uint4 t; };
+template <> struct RawV<false, 4> { uint2 t; };
+template <> struct RawV<true, 4> { float4 t; };
+template <> struct RawV<true, 8> { float4 t, u; };
+template <bool F32, int V>
+__device__ __forceinline__ RawV<F32, V> ldraw(const void* p, long i) {
+  RawV<F32, V> r;
+  if constexpr (!F32 && V == 8) r.t = *(const uint4*)((const unsigned short*)p + i);
+  else if constexpr (!F32) r.t = *(const uint2*)((const unsigned short*)p + i);
+  else if constexpr (V == 4) r.t = *(const float4*)((const float*)p + i);
+  else { r.t = *(const float4*)((const float*)p + i); r.u = *(const float4*)((const float*)p + i + 4); }
+  return r;
+}
+template <bool F32, int V>
+__device__ __forceinline__ void cvtraw(const RawV<F32, V>& r, float (&v)[V]) {
+  if constexpr (!F32) {
+    v[0] = __uint_as_float(r.t.x << 16); v[1] = __uint_as_float(r.t.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.t.y << 16); v[3] = __uint_as_float(r.t.y & 0xffff0000u);
+    if constexpr (V == 8) {
+      v[4] = __uint_as_float(r.t.z << 16); v[5] = __uint_as_float(r.t.z & 0xffff0000u);
+      v[6] = __uint_as_float(r.t.w << 16); v[7] = __uint_as_float(r.t.w & 0xffff0000u);
+    }
+  } else {
+    v[0] = r.t.x; v[1] = r.t.y; v[2] = r.t.z; v[3] = r.t.w;
+    if constexpr (V == 8) { v[4] = r.u.x; v[5] = r.u.y; v[6] = r.u.z; v[7] = r.u.w; }
+  }
+}
+
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Handing XCD x the x-th contiguous eighth
 // of the blocks keeps neighbouring blocks — which share halo rows of a 3x3 stencil — on one L2 instead of every XCD fetching them from HBM.
 __device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblocks) {
@@ -165,6 +196,8 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // op launchers (one per translation unit)
 int msl_launch_conv(const msl_op& op, hipStream_t s);
 int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s);
+bool msl_gemm1x1_eligible(const msl_op& op);
+int msl_launch_gemm1x1(const msl_op& op, hipStream_t s);
 int msl_launch_stem(const msl_op& op, hipStream_t s);
 int msl_launch_dwconv(const msl_op& op, hipStream_t s);
 int msl_launch_sppf_pool(const msl_op& op, hipStream_t s);

@@ -19,37 +19,6 @@
 // same-address RETURNING atomics, ~150 ns each, 4x slower than the separate finalize launch; and summing the copies in
 // every BN_ACT workgroup — the 2C x slots fp64 loads outweigh the small layers' own traffic.)
 // =========================================================================================================
-// Raw V-element loads for the streaming loops: the registers are converted where they are USED, so that a whole batch of loads (and the next
-// batch, issued before the current one is stored) is in flight per thread.  ldv() converts at the load, which pins hipcc's wait right behind it.
-template <bool F32, int V> struct RawV;
-template <> struct RawV<false, 8> { uint4 t; };
-template <> struct RawV<false, 4> { uint2 t; };
-template <> struct RawV<true, 4> { float4 t; };
-template <> struct RawV<true, 8> { float4 t, u; };
-template <bool F32, int V>
-__device__ __forceinline__ RawV<F32, V> ldraw(const void* p, long i) {
-  RawV<F32, V> r;
-  if constexpr (!F32 && V == 8) r.t = *(const uint4*)((const unsigned short*)p + i);
-  else if constexpr (!F32) r.t = *(const uint2*)((const unsigned short*)p + i);
-  else if constexpr (V == 4) r.t = *(const float4*)((const float*)p + i);
-  else { r.t = *(const float4*)((const float*)p + i); r.u = *(const float4*)((const float*)p + i + 4); }
-  return r;
-}
-template <bool F32, int V>
-__device__ __forceinline__ void cvtraw(const RawV<F32, V>& r, float (&v)[V]) {
-  if constexpr (!F32) {
-    v[0] = __uint_as_float(r.t.x << 16); v[1] = __uint_as_float(r.t.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.t.y << 16); v[3] = __uint_as_float(r.t.y & 0xffff0000u);
-    if constexpr (V == 8) {
-      v[4] = __uint_as_float(r.t.z << 16); v[5] = __uint_as_float(r.t.z & 0xffff0000u);
-      v[6] = __uint_as_float(r.t.w << 16); v[7] = __uint_as_float(r.t.w & 0xffff0000u);
-    }
-  } else {
-    v[0] = r.t.x; v[1] = r.t.y; v[2] = r.t.z; v[3] = r.t.w;
-    if constexpr (V == 8) { v[4] = r.u.x; v[5] = r.u.y; v[6] = r.u.z; v[7] = r.u.w; }
-  }
-}
-
 typedef float f2_t __attribute__((ext_vector_type(2)));
 #define MSL_MAX_SLOTS 16
 // V = channels per thread: 8 (one 16-byte access of bf16) when the channel count and the views allow it, else 4
