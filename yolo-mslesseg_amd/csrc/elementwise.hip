@@ -186,17 +186,36 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
                                                      const float* __restrict__ bias, const void* __restrict__ res,
                                                      void* __restrict__ y, int N, int H, int W, int C, int x_cs, int x_co,
                                                      int y_cs, int y_co, int res_cs, int res_co, int act, int gsz,
-                                                     int gstride, int goff, int flip, int omap) {
+                                                     int gstride, int goff, int flip, int omap, unsigned total) {
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [10][C]: 9 taps (already flipped if asked) + bias
-  const int CV = C / V, Wp = (W + 1) >> 1;
-  const long t_ = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-  const long total = (long)N * H * Wp * CV;
-  const long t = t_ < total ? t_ : total - 1;  // surplus threads of the last workgroup shadow its last item until the barrier, then leave
-  const int c = (int)(t % CV) * V;
-  const long pr = t / CV;
-  const int xp = (int)(pr % Wp);
-  const long q = pr / Wp;
-  const int iy = (int)(q % H), n = (int)(q / H);
+  // the filter bank goes to LDS once per workgroup; the workgroup then walks over chunks of 256 (pixel pair, channel group) items.  XCD x
+  // (= blockIdx % 8) takes the x-th contiguous eighth of the chunks, so the rows a 3x3 stencil shares stay in one L2.
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) sw[tp * C + ch] = w[(flip ? 8 - tp : tp) * C + ch];
+    sw[9 * C + ch] = bias[ch];
+  }
+  __syncthreads();
+  const unsigned CV = C / V, Wp = (W + 1) >> 1;
+  const unsigned nchunks = (total + 255) >> 8;
+  unsigned ck0 = blockIdx.x, ck1 = nchunks, ckstep = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    const unsigned per = (nchunks + 7) >> 3, xcd = blockIdx.x & 7;
+    ck0 = xcd * per + (blockIdx.x >> 3);
+    ck1 = xcd * per + per < nchunks ? xcd * per + per : nchunks;
+    ckstep = gridDim.x >> 3;
+  }
+  const bool cv_pow2 = (CV & (CV - 1)) == 0;
+  const int cv_sh = 31 - __builtin_clz(CV);
+  for (unsigned ck = ck0; ck < ck1; ck += ckstep) {
+  const unsigned t = ck * 256 + threadIdx.x;
+  if (t >= total) continue;
+  // 32-bit index arithmetic (a flat 64-bit index cost three 64-bit divisions per thread: ~450 instructions, three times the kernel's FMAs)
+  const unsigned pr = cv_pow2 ? t >> cv_sh : t / CV;
+  const int c = (int)(t - pr * CV) * V;
+  const unsigned q = pr / Wp;
+  const int xp = (int)(pr - q * Wp);
+  const int n = (int)(q / (unsigned)H), iy = (int)(q - (unsigned)n * (unsigned)H);
   const int x0 = 2 * xp;
   const bool two = x0 + 1 < W;
   const int cmap = gsz ? (c / gsz) * gstride + goff + (c % gsz) : c;
@@ -222,13 +241,6 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
     rr0 = ldraw<F32, V>(res, p0 * res_cs + res_co + cdst);
     rr1 = ldraw<F32, V>(res, (two ? p0 + 1 : p0) * res_cs + res_co + cdst);
   }
-  // the filter bank goes to LDS while the window is in flight
-  for (int i = threadIdx.x; i < 10 * C; i += 256) {
-    const int tp = i / C, ch = i - tp * C;
-    sw[i] = tp < 9 ? w[(flip ? 8 - tp : tp) * C + ch] : bias[ch];
-  }
-  __syncthreads();
-  if (t_ >= total) return;
   float acc0[V], acc1[V];
 #pragma unroll
   for (int r = 0; r < V; ++r) { acc0[r] = sw[9 * C + c + r]; acc1[r] = acc0[r]; }
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   }
   stv<F32, V>(y, p0 * y_cs + y_co + cdst, acc0);
   if (two) stv<F32, V>(y, (p0 + 1) * y_cs + y_co + cdst, acc1);
+  }
 }
 
 int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
@@ -284,9 +297,13 @@ int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
   const bool v8 = C % 8 == 0 && ((x_cs | x_co | y_cs | y_co) & 7) == 0 && (!op.p[3] || ((res_cs | res_co) & 7) == 0) && (!gsz || ((gsz | gstride | goff) & 7) == 0);
   const int V = v8 ? 8 : 4;
   const long total = (long)N * H * ((W + 1) / 2) * (C / V);
-  const unsigned grid = (unsigned)((total + 255) / 256);
+  MSL_REQUIRE(total < (1L << 31), "dwconv: too many items for 32-bit indexing");
+  long nchunks = (total + 255) / 256;
+  long nwg = nchunks < 256 * 8 ? nchunks : 256 * 8;  // persistent: up to 8 workgroups per CU, each stages the filter bank once
+  if (nwg >= 8) nwg &= ~7L;                          // multiple of 8: the XCD-aware chunk order
+  const unsigned grid = (unsigned)nwg;
   const size_t lds = (size_t)10 * C * 4;
-#define DW(F, VV) hipLaunchKernelGGL((dwconv_kernel<F, VV>), dim3(grid), dim3(256), lds, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap)
+#define DW(F, VV) hipLaunchKernelGGL((dwconv_kernel<F, VV>), dim3(grid), dim3(256), lds, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap, (unsigned)total)
   if (op.dtype == MSL_F32) { if (v8) DW(true, 8); else DW(true, 4); } else { if (v8) DW(false, 8); else DW(false, 4); }
 #undef DW
   MSL_CHECK_LAUNCH("dwconv");

@@ -449,20 +449,23 @@ int msl_launch_f64_drain(const msl_op& op, hipStream_t s) {
 // Elementwise / scatter helpers of the backward pass
 // =========================================================================================================
 // ADD_VIEW: dst += src (views of equal shape; src may be fp32 while dst is the op dtype)
-template <bool F32>
+template <bool F32, int V>
 __global__ __launch_bounds__(256) void add_view_kernel(void* __restrict__ dst, const void* __restrict__ src, long M, int C, int d_cs, int d_co,
-                                                       int s_cs, int s_co, int src_f32, int overwrite) {
-  const int C4 = C >> 2;
+                                                       int s_cs, int s_co, int src_f32, int overwrite, int shift) {
+  const int CV = C / V;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= M * C4) return;
-  const int c = (int)(t % C4) * 4;
-  const long p = t / C4;
-  float a[4] = {0, 0, 0, 0}, b[4];
-  if (!overwrite) ld4<F32>(dst, p * d_cs + d_co + c, a);
-  if (src_f32) ld4<true>(src, p * s_cs + s_co + c, b); else ld4<F32>(src, p * s_cs + s_co + c, b);
+  if (t >= M * CV) return;
+  // (pixel, channel group) of the flat index: a shift when C / V is a power of two (shift >= 0) — the 64-bit divide it replaces was most of the kernel
+  const long p = shift >= 0 ? t >> shift : t / CV;
+  const int c = (int)(t - p * CV) * V;
+  float a[V], b[V];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) a[r] += b[r];
-  st4<F32>(dst, p * d_cs + d_co + c, a);
+  for (int r = 0; r < V; ++r) a[r] = 0.f;
+  if (!overwrite) ldv<F32, V>(dst, p * d_cs + d_co + c, a);
+  if (src_f32) ldv<true, V>(src, p * s_cs + s_co + c, b); else ldv<F32, V>(src, p * s_cs + s_co + c, b);
+#pragma unroll
+  for (int r = 0; r < V; ++r) a[r] += b[r];
+  stv<F32, V>(dst, p * d_cs + d_co + c, a);
 }
 // p 0 dst, 1 src ; i 0 N,1 H,2 W,3 C,10 d_cs,11 d_co,12 s_cs,13 s_co,19 src_f32, 20 overwrite (dst = src)
 int msl_launch_add_view(const msl_op& op, hipStream_t s) {
@@ -470,10 +473,15 @@ int msl_launch_add_view(const msl_op& op, hipStream_t s) {
   const int C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && C % 4 == 0 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 &&
                   op.i[11] + C <= op.i[10] && op.i[13] + C <= op.i[12], "add_view: bad args");
-  const long total = M * (C / 4);
+  const bool v8 = C % 8 == 0 && ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) == 0;
+  const int CV = C / (v8 ? 8 : 4);
+  int shift = -1;
+  if ((CV & (CV - 1)) == 0) { shift = 0; while ((1 << shift) < CV) ++shift; }
+  const long total = M * CV;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (op.dtype == MSL_F32) hipLaunchKernelGGL(add_view_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[19], op.i[20]);
-  else hipLaunchKernelGGL(add_view_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[19], op.i[20]);
+#define AV(F, V) hipLaunchKernelGGL((add_view_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], op.p[1], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[19], op.i[20], shift)
+  if (op.dtype == MSL_F32) { if (v8) AV(true, 8); else AV(true, 4); } else { if (v8) AV(false, 8); else AV(false, 4); }
+#undef AV
   MSL_CHECK_LAUNCH("add_view");
   return MSL_OK;
 }
@@ -482,14 +490,16 @@ int msl_launch_add_view(const msl_op& op, hipStream_t s) {
 template <bool F32>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(void* __restrict__ dx, const void* __restrict__ dy, int N, int H, int W, int C, int x_cs,
                                                              int x_co, int y_cs, int y_co) {
-  const int C4 = C >> 2;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)N * H * W * C4) return;
-  const int c = (int)(t % C4) * 4;
-  const long p = t / C4;
-  const int x = (int)(p % W);
-  const long q = p / W;
-  const int y = (int)(q % H), n = (int)(q / H);
+  // workgroup = 256 consecutive (pixel, channel quad) items of one image row: (n, y) from the block index with scalar arithmetic, one 32-bit
+  // divide per thread (three 64-bit ones before)
+  const int C4 = C >> 2, row_items = W * C4;
+  const unsigned bpr = gridDim.x / (unsigned)(N * H);
+  const int rowi = (int)(blockIdx.x / bpr), n = rowi / H, y = rowi - n * H;
+  const int t = (int)(blockIdx.x - (unsigned)rowi * bpr) * 256 + threadIdx.x;
+  if (t >= row_items) return;
+  const int x = (int)((unsigned)t / (unsigned)C4);
+  const int c = (t - x * C4) * 4;
+  const long p = ((long)n * H + y) * W + x;
   float a[4];
   ld4<F32>(dx, p * x_cs + x_co + c, a);
 #pragma unroll
@@ -506,8 +516,9 @@ int msl_launch_upsample2x_bwd(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
   MSL_REQUIRE(op.p[0] && op.p[1] && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0,
               "upsample2x_bwd: bad args");
-  const long total = (long)N * H * W * (C / 4);
-  dim3 grid((unsigned)((total + 255) / 256));
+  const long nblocks = (long)N * H * (((long)W * (C / 4) + 255) / 256);
+  MSL_REQUIRE(nblocks < (1L << 31), "upsample2x_bwd: too many workgroups");
+  dim3 grid((unsigned)nblocks);
   if (op.dtype == MSL_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<true>, grid, dim3(256), 0, s, op.p[0], op.p[1], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
   else hipLaunchKernelGGL(upsample2x_bwd_kernel<false>, grid, dim3(256), 0, s, op.p[0], op.p[1], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
   MSL_CHECK_LAUNCH("upsample2x_bwd");
