@@ -18,6 +18,22 @@
 
 __device__ __attribute__((aligned(16))) unsigned c1_zero_page[4];
 
+typedef int c1_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c1_i32x4 c1_rsrc(const void* p) {
+  const unsigned long u = (unsigned long)p;
+  c1_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+  r.z = (int)0x80000000u;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void c1_dma16(c1_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
+}
+
 struct C1Args {
   const char* x;
   const char* w;      // packed GEMM rows [Cout_pad16][Kpad] bf16
@@ -66,9 +82,34 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
   const long stride = (long)gridDim.x * NW;
   const int xchunks = a.Cin / EPC;
 
+  // lane-dependent half of the staging addresses, fixed over all slices: byte offset of this lane's 16 bytes from the slice's first pixel for each
+  // of the slice's pieces (or "reads zero").  A full slice then costs one scalar base + one buffer_load ... lds per piece; the per-piece divide
+  // by the runtime row pitch that this replaces was ~50 instructions per KiB staged — as many issue slots as the slice's MFMAs and epilogue.
+  constexpr int MAXP = (STATS && NCP >= 7) ? 5 : 17;  // pieces per slice for every shape the LDS budget admits (32 pixels x 33 chunks, 16 x 65); the widest statistics
+                                                      // forms have no registers to spare: 5 pieces (K <= 128 at 16-pixel slices), else the per-piece path below
+  constexpr unsigned OOB = 0x80000000u;
+  const int npieces = (slice_chunks + 63) >> 6;
+  unsigned xo[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int cidx = k * 64 + lane, px = cidx / cps, ch = cidx - px * cps;
+    xo[k] = (cidx < slice_chunks && ch < xchunks) ? (unsigned)((px * a.x_cs + ch * EPC) * ES) : OOB;
+  }
+  const unsigned lds_ring = msl_lds_addr(s_x);
+
   auto stage = [&](long tile, int buf) __attribute__((always_inline)) {
     unsigned char* dst = s_x + buf * slice_bytes;
     const long p0 = tile * SP;
+    if (npieces <= MAXP && p0 + SP <= a.M) {  // wave-uniform: a full slice (all but the tensor's last one)
+      const c1_i32x4 rx = c1_rsrc(a.x + (p0 * a.x_cs + a.x_co) * ES);
+      const unsigned l0 = lds_ring + buf * slice_bytes;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        if (k >= npieces) break;
+        c1_dma16(rx, __builtin_amdgcn_readfirstlane(l0 + k * 1024), xo[k], 0u);
+      }
+      return;
+    }
     for (int c0 = 0; c0 < slice_chunks; c0 += 64) {
       const int cidx = c0 + lane, px = cidx / cps, ch = cidx - px * cps;
       const bool ok = cidx < slice_chunks && ch < xchunks && p0 + px < a.M;
@@ -254,22 +295,6 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 // must read zero (rows beyond M / the weight rows, channels beyond Cin / Kpad, the pad chunk) carry an out-of-range offset (see conv_wgrad_tr.hip).
 // Epilogue as the streaming kernel's (permuted A rows → 8 consecutive channels per lane, one 16-byte store), bias from LDS, residual prefetched.
 // These layers ran through conv_igemm_kernel before (no staging pipeline, loads under per-lane conditions): 45-110 us each at batch 128.
-typedef int c1_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ c1_i32x4 c1_rsrc(const void* p) {
-  const unsigned long u = (unsigned long)p;
-  c1_i32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
-  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
-  r.z = (int)0x80000000u;
-  r.w = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ void c1_dma16(c1_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
-}
-
 struct G1Args {
   const char* x; const char* w; const float* bias; const char* res; char* y;
   long M;
