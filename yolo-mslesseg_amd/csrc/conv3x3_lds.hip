@@ -369,7 +369,7 @@ static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
 // its next unit, then runs the MFMAs of the current one; the second group runs one unit behind (two-chunk case), so the VALU-heavy
 // epilogue of one group (stores, SiLU, statistics: about as many issue cycles as the tile's MFMAs) overlaps the other group's MFMAs
 // on the same SIMDs.  BatchNorm statistics stay in registers over all tiles of a wave and are folded once at the end of the kernel.
-template <bool F32, int COT, int NCH, bool FUSE = false>
+template <bool F32, int COT, int NCH, bool FUSE = false, int RING = 2>  // RING: staged units per wave group (2, or 3 where a unit holds few MFMAs and the LDS allows)
 __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int total_tiles, int steps) {
   using T = Tile3<1, 2>;
   constexpr int ES = F32 ? 4 : 2;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
     }
   }
   // ---- fragment addresses (chunk- and tile-independent)
-  unsigned char* ring_g = s_ring + grp * 2 * IN_BYTES;
+  unsigned char* ring_g = s_ring + grp * RING * IN_BYTES;
   // rows wave*2 .. wave*2+3 of the halo x 3 column shifts; the second 16-pixel half of a row is +1024 B (16 slots = 4 image rows of
   // 256 B, rotation unchanged), folded into the ds_read offset
   int baddr[4][3];
@@ -621,27 +621,34 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
     }
   };
 
-  // ---- steps: at step s group 0 computes unit s, group 1 unit s - DELAY; buffer parity = s & 1 for both
-  auto step = [&](int sidx, auto par) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par)::value;
+  // ---- steps: at step s group 0 computes unit s, group 1 unit s - DELAY; unit u lives in ring buffer u % RING, RING - 1 units are staged ahead
+  static_assert(RING == 2 || DELAY == 0, "a ring deeper than 2 is for the one-chunk layers");
+  const int np_wave = (T::PIECES - wave + 3) / 4;  // LDS-DMA pieces this wave issues per staged unit (wave-uniform)
+  int ub = ((1 - RING - DELAY * grp) % RING + RING) % RING;  // ring buffer of unit u = sidx - DELAY * grp (u % RING, also while u < 0), advanced every step
+  auto step = [&](int sidx) __attribute__((always_inline)) {
     // every wave's pieces of the current unit have landed (each wave waited for its own after the previous step's MFMAs), and everyone is done
     // reading the buffer refilled next.  The bare barrier: __syncthreads() fences with vmcnt(0), which would also wait for the acknowledgement
     // of the stores the previous step's epilogue has just issued — once per step, for all eight waves.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const int u = sidx - DELAY * grp, un = u + 1;
-    if (un >= 0 && un < my_units) stage(un, ring_g + (PAR ^ 1) * IN_BYTES);
+    const int u = sidx - DELAY * grp, un = u + RING - 1;
+    int np = 0;
+    if (un >= 0 && un < my_units) {
+      const int nb = ub == 0 ? RING - 1 : ub - 1;  // = (ub + RING - 1) % RING: the buffer unit u - 1 was read from
+      stage(un, ring_g + nb * IN_BYTES);
+      np = np_wave;
+    }
     const bool live = u >= 0 && u < my_units;
     const int cc = NCH == 2 ? (u & 1) : 0;
     if (live && cc == NCH - 1 && a.res) prefetch_res(u / NCH);
-    if (live) compute(cc, ring_g + PAR * IN_BYTES);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA issued above had the MFMAs to land; waited for BEFORE the epilogue so that its stores stay in flight
+    if (live) compute(cc, ring_g + ub * IN_BYTES);
+    // unit u + 1 must have landed before the next barrier: with a ring of 2 that is the DMA issued above (it had the MFMAs to land); with a ring
+    // of 3 the one issued a step ago — only the pieces just issued may stay outstanding.  Waited for BEFORE the epilogue so that its stores stay in flight.
+    if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else msl_wait_vmcnt(np);
     if (live && cc == NCH - 1) epilogue(u / NCH);
+    ub = ub + 1 == RING ? 0 : ub + 1;
   };
-  step(-1, std::integral_constant<int, 1>{});
-  for (int sidx = 0; sidx < steps + DELAY; sidx += 2) {
-    step(sidx, std::integral_constant<int, 0>{});
-    step(sidx + 1, std::integral_constant<int, 1>{});
-  }
+  for (int sidx = 1 - RING; sidx < steps + DELAY; ++sidx) step(sidx);
 
   if (a.acc) {  // fold the statistics: 16 pixel lanes (DPP), the 8 waves (LDS), then one fp64 atomic per channel and statistic
     __syncthreads();
@@ -671,14 +678,14 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   }
 }
 
-template <bool F32, int COT, int NCH, bool FUSE = false>
+template <bool F32, int COT, int NCH, bool FUSE = false, int RING = 2>
 static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<1, 2>;
-  constexpr int LDS = NCH * 9 * 4 * COT * 16 * 16 + 4 * T::PIECES * 1024;
+  constexpr int LDS = NCH * 9 * 4 * COT * 16 * 16 + 2 * RING * T::PIECES * 1024;
   static_assert(LDS <= 160 * 1024, "conv3x3_pers: LDS");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH, FUSE, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   const long tiles = (long)a.N * a.tiles_y * a.tiles_x;
@@ -688,7 +695,7 @@ static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   long busiest = (tiles + 2 * wgs - 1) / (2 * wgs);  // tiles of the busiest wave group
   if ((wgs & 7) == 0) { const long per = (tiles + 7) / 8, g2 = wgs / 4; busiest = (per + g2 - 1) / g2; }
   const int steps = (int)busiest * NCH;
-  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH, FUSE>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
+  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH, FUSE, RING>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
   MSL_CHECK_LAUNCH("conv3x3_pers");
   return MSL_OK;
 }
@@ -938,14 +945,17 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
       return launch3p<false, 4, 2, true>(a, cout_blocks, s);
     }
     if (stride == 1 && rw == 2 && nch <= 2 && fits && (pays || op.i[23] == -9) && op.i[23] != -8) {
-#define L3P(F, NCH_)                                                       \
-  do {                                                                     \
-    if (cot == 4) return launch3p<F, 4, NCH_>(a, cout_blocks, s);          \
-    if (cot == 2) return launch3p<F, 2, NCH_>(a, cout_blocks, s);          \
-    return launch3p<F, 1, NCH_>(a, cout_blocks, s);                        \
+#define L3P(F, NCH_, R1)                                                           \
+  do {                                                                             \
+    if (cot == 4) return launch3p<F, 4, NCH_>(a, cout_blocks, s);                  \
+    if (cot == 2) return launch3p<F, 2, NCH_, false, R1>(a, cout_blocks, s);       \
+    return launch3p<F, 1, NCH_, false, R1>(a, cout_blocks, s);                     \
   } while (0)
-      if (f32) { if (nch == 2) L3P(true, 2); else L3P(true, 1); }
-      else     { if (nch == 2) L3P(false, 2); else L3P(false, 1); }
+      // (a ring of 3 staged units for the one-chunk layers with <= 32 output channels per block — RING = 3 fits their LDS — measured no
+      // faster than 2: 160² 8→16 0.0706 vs 0.0716 ms, `scripts/dev_conv3x3_ab.py`; these layers stage 64 bytes per pixel slot for 16 or 32 valid
+      // ones, their pace is the LDS-DMA issue count, not the round trip)
+      if (f32) { if (nch == 2) L3P(true, 2, 2); else L3P(true, 1, 2); }
+      else     { if (nch == 2) L3P(false, 2, 2); else L3P(false, 1, 2); }
 #undef L3P
     }
   }
