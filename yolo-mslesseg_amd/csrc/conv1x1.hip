@@ -297,10 +297,12 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
 // These layers ran through conv_igemm_kernel before (no staging pipeline, loads under per-lane conditions): 45-110 us each at batch 128.
 struct G1Args {
   const char* x; const char* w; const float* bias; const char* res; char* y;
+  double* acc;  // optional BatchNorm accumulator f64[slots][2*Cout] (train-mode raw convs: sums of the stored values, as the streaming kernel's epilogue)
   long M;
-  int Cin, Cout, Kpad, w_rows, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, ntn;
+  int Cin, Cout, Kpad, w_rows, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, ntn, slots;
 };
 
+template <bool STATS>
 __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   constexpr int BM = 128, BN = 128, BK = 64, PITCH = BK * 2 + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
   constexpr int PIECES = BM * CPR / 64;                                               // 18 per operand tile
@@ -399,6 +401,13 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
     }
   }
   // ---- epilogue: lane (li, g) holds channels n0 + wn*64 + c*32 + 8g .. +7 of pixel p0 + wm*64 + 16*pt + li
+  float s1[STATS ? 2 : 1][8], s2[STATS ? 2 : 1][8];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
+  }
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt) {
     const long p = p0 + wm * 64 + pt * 16 + li;
@@ -410,6 +419,14 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[pt][c][0][r]; v[4 + r] = acc[pt][c][1][r]; }
+      if constexpr (STATS) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float vr = bf16_bits_to_f32(f32_to_bf16_bits(v[r]));  // statistics of the values actually stored
+          s1[c][r] += vr;
+          s2[c][r] = fmaf(vr, vr, s2[c][r]);
+        }
+      }
       {
         const float4 b0 = *(const float4*)(s_bias + cl), b1 = *(const float4*)(s_bias + cl + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -430,13 +447,36 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
       else stv<false, 8>(a.y, oi, v);
     }
   }
+  if constexpr (STATS) {
+    // fold: the 16 pixel lanes (DPP row sums), the two waves that share a channel half (LDS), then one fp64 atomic per channel and statistic
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done with the operand tiles
+    float* red = (float*)smem;  // [2 pixel halves][2 statistics][128 channels]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float t1 = row16_sum(s1[c][r]), t2 = row16_sum(s2[c][r]);
+        if (li == 0) {
+          const int ch = wn * 64 + c * 32 + 8 * g + r;
+          red[(wm * 2 + 0) * 128 + ch] = t1;
+          red[(wm * 2 + 1) * 128 + ch] = t2;
+        }
+      }
+    __syncthreads();
+    double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * a.Cout;
+    for (int i = threadIdx.x; i < 256; i += 256) {
+      const int st = i >> 7, ch = i & 127;
+      if (n0 + ch < a.Cout) atomicAdd(dst + 2 * (n0 + ch) + st, (double)(red[st * 128 + ch] + red[(2 + st) * 128 + ch]));
+    }
+  }
 }
 
 // Eligibility (msl_launch_conv tries this after the streaming kernel): bf16 1x1 / stride 1 / pad 0, plain store, no statistics, 8-aligned views,
 // enough pixels to fill the chip with 128-pixel tiles.
 bool msl_gemm1x1_eligible(const msl_op& op) {
   const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
-  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0 || op.p[5] || !op.p[1]) return false;
+  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0 || !op.p[1]) return false;
+  if (op.p[5] && (op.i[19] || op.p[3] || op.i[18] || op.i[23] > 16)) return false;  // statistics epilogue: raw bf16 convs (no activation / residual / fp32 output), <= 16 slots
   if (Cin % 8 || Cout % 8 || Kpad % 32 || Kpad < Cin || Cin < 64) return false;
   if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) return false;
   if (op.p[3] && ((op.i[14] | op.i[15]) & 7)) return false;
@@ -452,6 +492,7 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   a.x_cs = op.i[10]; a.x_co = op.i[11]; a.y_cs = op.i[12]; a.y_co = op.i[13]; a.res_cs = op.i[14]; a.res_co = op.i[15];
   a.act = op.i[18]; a.out_f32 = op.i[19];
   a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
+  a.acc = (double*)op.p[5]; a.slots = op.i[23] > 0 ? op.i[23] : 1;
   MSL_REQUIRE(a.x && a.w && a.y && msl_gemm1x1_eligible(op), "gemm1x1: bad args");
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs && (!a.res || a.res_co + a.Cout <= a.res_cs), "gemm1x1: bad dims / views");
   a.ntn = (a.Cout + 127) / 128;
@@ -460,10 +501,12 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     attr = true;
   }
-  hipLaunchKernelGGL(gemm1x1_kernel, dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  if (a.acc) hipLaunchKernelGGL(gemm1x1_kernel<true>, dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL(gemm1x1_kernel<false>, dim3((unsigned)tiles), dim3(256), LDS, s, a);
   MSL_CHECK_LAUNCH("gemm1x1");
   return MSL_OK;
 }

@@ -377,11 +377,14 @@ class TrainPlan(graph.Visitor):
         kpad = m["Kpad"]
         # wider outputs would need the 16-pixel slices AND 2 x 8 sums per output group in registers: occupancy drops and the epilogue costs more
         # than the separate statistics pass (measured at 64→256 @80²: 0.25 ms fused vs 0.16 + 0.04 ms)
-        if x.C % 8 or cout % 8 or kpad % 32 or cout > 128 or any(v % 8 for v in (x.cs, x.co, z.cs, z.co)):
+        if x.C % 8 or cout % 8 or kpad % 32 or any(v % 8 for v in (x.cs, x.co, z.cs, z.co)):
             return False
         cps = (kpad * 2 + 16) // 16
-        lds = ((((cout + 31) // 32) * 32 * cps + 63) // 64 * 64 + 8 * ((16 * cps + 63) // 64 * 64)) * 16
-        return lds <= 150 * 1024
+        lds = ((((cout + 31) // 32) * 32 * cps + 63) // 64 * 64 + 8 * ((16 * cps + 63) // 64 * 64)) * 16 + ((cout + 31) // 32) * 32 * 4
+        if lds <= 150 * 1024:  # the streaming kernel takes it (msl_conv1x1_eligible)
+            return cout <= 128
+        # too wide for the streaming kernel's LDS: the tiled GEMM (msl_gemm1x1_eligible), whose statistics epilogue is one fold per 128 x 128 tile
+        return x.C >= 64 and self.N * x.H * x.W >= 128 * 64
 
     def _conv_op(self, x: View, y: View, wt, bias_ptr, m, k, s, pad, act=0, res: Optional[View] = None, out_f32=False, store_mode=0, dgrad=0, cout=None, stats_acc=None):
         cout = y.C if cout is None else cout
