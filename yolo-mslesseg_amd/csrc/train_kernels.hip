@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
     }
   };
   if (pl < PL) {
-    constexpr int U = 4;
+    constexpr int U = 4;  // pixel groups per batch of loads (8 — sixteen 16-byte loads per thread in flight — measured the same: 3.165 vs 3.179 ms per step)
     const long step = (long)gridDim.x * PL;
     long p = (long)blockIdx.x * PL + pl;
     for (; p + (U - 1) * step < M; p += U * step) {
@@ -133,7 +133,9 @@ static int reduce_grid(long M, int C, int slots, int V, long wide_cap = 512) {
   long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);  // >= 16 pixels per thread before another block (and its atomics) pays off
   // measured (batch 128): for the two-stream BatchNorm reductions 256-512 workgroups beat 768 / 1024 / 2048 / 4096 — each one ends in a fold +
   // fp64 atomics; the single-stream column sum (fp32 head gradients, 4 channels per thread) prefers 1024
-  const long cap = slots > 1 ? wide_cap : 256;
+  static long env_cap = -1;  // experiment switch: MSL_REDUCE_CAP
+  if (env_cap < 0) { const char* e = getenv("MSL_REDUCE_CAP"); env_cap = e ? atol(e) : 0; }
+  const long cap = slots > 1 ? (env_cap > 0 ? env_cap : wide_cap) : 256;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
