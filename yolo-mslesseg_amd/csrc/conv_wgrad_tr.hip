@@ -485,11 +485,18 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
                   (long)TH * 32 * (a.x_cs > a.z_cs ? a.x_cs : a.z_cs) * 2 < (1L << 31),
               "conv_wgrad_tr: image rows too long for 32-bit staging offsets");
   const int ny = ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
-  // workgroups over all channel blocks.  One per CU (256) is fastest for a launch replayed alone; in the training step, where the weight gradients run on
-  // their own lanes beside the bandwidth-bound main chain, 192 or 128 give the faster STEP (23.79 ms against 24.05 at 256, 24.01 at 96): every workgroup
-  // writes a partial matrix (up to 147 KB) that a reduction launch reads back — 7 GB per step at 256 — and the CUs left free serve the main chain.
-  static int wgs_total = -1;  // MSL_WGRAD_WGS overrides (measurements)
-  if (wgs_total < 0) { const char* e = getenv("MSL_WGRAD_WGS"); wgs_total = e ? atoi(e) : 192; if (wgs_total < 1) wgs_total = 192; }
+  // workgroups over all channel blocks.  One per CU (256) is fastest for a launch replayed alone; in the training step, where the weight gradients run
+  // on their own lanes beside the bandwidth-bound main chain, fewer give the faster STEP for the layers whose partial matrices (one per workgroup, up to
+  // 147 KB, written and read back by the reduction launch: 7 GB per step at 256 everywhere) weigh against their own input: 23.79 ms against 24.05 with
+  // 192 or 128 everywhere, 24.01 at 96.  Rule: 256 where the operands are > 8x the partials (the 160² levels), else 128.
+  static int wgs_env = -1;  // MSL_WGRAD_WGS overrides (measurements)
+  if (wgs_env < 0) { const char* e = getenv("MSL_WGRAD_WGS"); wgs_env = e ? atoi(e) : 0; }
+  int wgs_total = wgs_env;
+  if (wgs_total <= 0) {
+    const double operands = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout);
+    const double partials256 = 256.0 * 4.0 * (a.Cout < 64 ? a.Cout : 64) * (a.Cin < 64 ? a.Cin : 64) * k * k;
+    wgs_total = operands > 8.0 * partials256 ? 256 : 128;
+  }
   long want = wgs_total / ny;  // one 8-wave workgroup per CU (its ring of staged tiles takes the LDS): never more workgroups than CUs, a second round doubles the time
   if (want < 1) want = 1;
   long tpb = (a.total_tiles + want - 1) / want;
