@@ -257,6 +257,39 @@ def test_dwconv_plain_and_grouped_residual(dtype):
     _close(ad, ref2, dtype, "dwconv pe")
 
 
+@pytest.mark.parametrize("case", [(12, 41, 45, 64, 1, 0, 0), (6, 40, 40, 128, 0, 1, 1), (9, 23, 67, 256, 1, 1, 0), (16, 20, 20, 64, 0, 0, 1)])
+def test_dwconv_lds_tiled_form_equals_the_pixel_pair_form(case):
+    """bf16, C a multiple of 64, >= 256 tiles: the LDS-tiled kernel (halo by LDS-DMA, column walk with the window in registers) — against torch, and
+    bit for bit against the thread-per-pixel-pair kernel (i[19] = 9) it replaces: ragged tiles, activation, residual (accumulate), flipped taps
+    (the input gradient), concat-slice views."""
+    N, H, W, C, act, res, flip = case
+    g = torch.Generator().manual_seed(sum(case))
+    x_cs, x_co, y_cs, y_co = C + 64, 32, C + 32, 16
+    xbuf = _rand_act((N, H, W, x_cs), MSL_BF16, g)
+    rbuf = _rand_act((N, H, W, y_cs), MSL_BF16, g)
+    w = (torch.rand((C, 1, 3, 3), generator=g) * 2 - 1) / 3
+    b = torch.rand(C, generator=g) - 0.5
+    wref = w.flip(2, 3) if flip else w
+    ref = F.conv2d(xbuf[..., x_co : x_co + C].float().permute(0, 3, 1, 2), wref, b, padding=1, groups=C)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if res:
+        ref = ref + rbuf[..., y_co : y_co + C].float()
+    wd, bd, xd = w.view(C, 9).t().contiguous().to(DEV), b.to(DEV), xbuf.to(DEV)
+    outs = []
+    for form in (0, 9):
+        yd = rbuf.to(DEV).clone()
+        op = hiplib.make_op(hiplib.OP_DWCONV, MSL_BF16, p=(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr() if res else 0, yd.data_ptr()),
+                            i={0: N, 1: H, 2: W, 3: C, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co, 14: y_cs, 15: y_co, 18: act, 19: form, 20: flip})
+        hiplib.launch(op, _stream())
+        torch.cuda.synchronize()
+        outs.append(yd.cpu())
+        _close(yd[..., y_co : y_co + C], ref, MSL_BF16, f"dwconv form {form} {case}")
+        assert torch.equal(yd.cpu()[..., :y_co], rbuf[..., :y_co]) and torch.equal(yd.cpu()[..., y_co + C :], rbuf[..., y_co + C :])  # neighbours of the slice untouched
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 def test_sppf_pool_equals_three_chained_maxpools(dtype):
     g = torch.Generator().manual_seed(11)

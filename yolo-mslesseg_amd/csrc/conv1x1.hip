@@ -18,21 +18,9 @@
 
 __device__ __attribute__((aligned(16))) unsigned c1_zero_page[4];
 
-typedef int c1_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ c1_i32x4 c1_rsrc(const void* p) {
-  const unsigned long u = (unsigned long)p;
-  c1_i32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
-  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
-  r.z = (int)0x80000000u;
-  r.w = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ void c1_dma16(c1_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
-}
+typedef msl_i32x4 c1_i32x4;
+__device__ __forceinline__ c1_i32x4 c1_rsrc(const void* p) { return msl_buf_rsrc(p); }
+__device__ __forceinline__ void c1_dma16(c1_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) { msl_buf_dma16(rsrc, lds_addr, voff, soff); }
 
 struct C1Args {
   const char* x;

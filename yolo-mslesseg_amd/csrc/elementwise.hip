@@ -283,6 +283,110 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   }
 }
 
+// LDS-tiled form (bf16, C a multiple of 64, plain channel order): a workgroup stages the (8 + 2) x (32 + 2)-pixel halo of one 64-channel block with
+// LDS-DMA (43 KiB; image edges zero-filled by the buffer bounds check) and every thread walks DOWN one output column for its 8 channels with the
+// 3 x 3 window in registers — 3 conflict-free 16-byte LDS reads per output instead of the 6 global loads per output of the thread-per-pixel-pair
+// form above, whose window re-reads (6x the tensor, through L1 / L2) left it at 2 TB/s with its waves parked on memory 68 % of the time.  Filter
+// taps and bias sit in registers; same taps skipped at the border, same fma order: bit-identical results.
+struct DwLdsArgs {
+  const char* x; const float* w; const float* bias; const char* res; char* y;
+  int N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, flip, tiles_x, tiles_y, cblocks;
+};
+
+template <bool RES>  // RES: accumulate into / add a residual view (its 8 rows are prefetched: 32 registers the plain form does not pay for)
+__global__ __launch_bounds__(256) void dwconv_lds_kernel(DwLdsArgs a) {  // 175 / 193 registers: two workgroups per CU (capping at 170 for a third spills and runs 2x slower)
+  constexpr int TH = 8, TW = 32, HC = TW + 2, SLOTS = (TH + 2) * HC, PIECES = (SLOTS + 7) / 8;  // 8 pixel slots x 128 B per 1-KiB piece
+  extern __shared__ __attribute__((aligned(16))) unsigned char hal[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = threadIdx.x & 7, col = threadIdx.x >> 3;
+  int bid = (int)xcd_block(blockIdx.x, gridDim.x);
+  const int cblk = bid % a.cblocks; bid /= a.cblocks;
+  const int txi = bid % a.tiles_x; bid /= a.tiles_x;
+  const int tyi = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const int c0 = cblk * 64 + cg * 8;
+  {
+    const msl_i32x4 rx = msl_buf_rsrc(a.x + ((long)n * a.H * a.W * a.x_cs + a.x_co + cblk * 64) * 2);
+    const unsigned l0 = msl_lds_addr(hal);
+#pragma unroll
+    for (int k = 0; k < (PIECES + 3) / 4; ++k) {
+      const int pc = wave + 4 * k;
+      if (pc >= PIECES) break;
+      const int slot = pc * 8 + (lane >> 3), r = slot / HC, c = slot - r * HC;
+      const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+      const bool ok = slot < SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      msl_buf_dma16(rx, __builtin_amdgcn_readfirstlane(l0 + pc * 1024), ok ? (unsigned)(((iy * a.W + ix) * a.x_cs + (lane & 7) * 8) * 2) : MSL_DMA_OOB, 0u);
+    }
+  }
+  float wr[9][8], br[8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float4 w0 = *(const float4*)(a.w + (a.flip ? 8 - t : t) * a.C + c0), w1 = *(const float4*)(a.w + (a.flip ? 8 - t : t) * a.C + c0 + 4);
+    wr[t][0] = w0.x; wr[t][1] = w0.y; wr[t][2] = w0.z; wr[t][3] = w0.w; wr[t][4] = w1.x; wr[t][5] = w1.y; wr[t][6] = w1.z; wr[t][7] = w1.w;
+  }
+  {
+    const float4 b0 = *(const float4*)(a.bias + c0), b1 = *(const float4*)(a.bias + c0 + 4);
+    br[0] = b0.x; br[1] = b0.y; br[2] = b0.z; br[3] = b0.w; br[4] = b1.x; br[5] = b1.y; br[6] = b1.z; br[7] = b1.w;
+  }
+  const int ox = ox0 + col;
+  RawV<false, 8> rres[RES ? TH : 1];
+  if constexpr (RES) {
+#pragma unroll
+    for (int row = 0; row < TH; ++row) {
+      const int oy = oy0 + row < a.H ? oy0 + row : a.H - 1, oxc = ox < a.W ? ox : a.W - 1;
+      rres[row] = ldraw<false, 8>(a.res, (((long)n * a.H + oy) * a.W + oxc) * a.res_cs + a.res_co + c0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (ox >= a.W) return;
+  const bool inl = ox - 1 >= 0, inr = ox + 1 < a.W;  // left / right tap inside the image
+  float win[3][3][8];  // [halo row mod 3][kx][channel]
+  auto load_row = [&](int hr, float (&dst)[3][8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      RawV<false, 8> t;
+      t.t = *(const uint4*)(hal + ((hr * HC + col + kx) * 8 + cg) * 16);
+      cvtraw<false, 8>(t, dst[kx]);
+    }
+  };
+  load_row(0, win[0]);
+  load_row(1, win[1]);
+#pragma unroll
+  for (int row = 0; row < TH; ++row) {
+    const int oy = oy0 + row;
+    load_row(row + 2, win[(row + 2) % 3]);
+    if (oy >= a.H) continue;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = br[r];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      if ((unsigned)(oy - 1 + ky) >= (unsigned)a.H) continue;  // rows outside the image: taps skipped, as in dwconv_kernel
+      const float (&wn)[3][8] = win[(row + ky) % 3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bool in = kx == 0 ? inl : (kx == 2 ? inr : true);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (in) acc[r] = fmaf(wn[kx][r], wr[ky * 3 + kx][r], acc[r]);
+      }
+    }
+    if (a.act) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = silu_f(acc[r]);
+    }
+    if constexpr (RES) {
+      float rv[8];
+      cvtraw<false, 8>(rres[row], rv);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += rv[r];
+    }
+    stv<false, 8>(a.y, (((long)n * a.H + oy) * a.W + ox) * a.y_cs + a.y_co + c0, acc);
+  }
+}
+
 int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
   int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], x_cs = op.i[10], x_co = op.i[11], y_cs = op.i[12], y_co = op.i[13];
   int res_cs = op.i[14], res_co = op.i[15], act = op.i[18], gsz = op.i[22], gstride = op.i[23], goff = op.i[24];
@@ -295,6 +399,26 @@ int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
   if (gsz && omap) MSL_REQUIRE(gsz % 4 == 0 && gstride % 4 == 0 && goff % 4 == 0 && C % gsz == 0 && y_co + (C / gsz - 1) * gstride + goff + gsz <= y_cs, "dwconv: bad output group map");
   if (op.p[3]) MSL_REQUIRE(res_cs % 4 == 0 && res_co % 4 == 0 && res_co + C <= res_cs, "dwconv: bad residual view");
   const bool v8 = C % 8 == 0 && ((x_cs | x_co | y_cs | y_co) & 7) == 0 && (!op.p[3] || ((res_cs | res_co) & 7) == 0) && (!gsz || ((gsz | gstride | goff) & 7) == 0);
+  if (op.dtype == MSL_BF16 && v8 && !gsz && C % 64 == 0 && op.i[19] != 9 && (long)H * W * x_cs * 2 < (1L << 31)) {  // (i[19] = 9 keeps the thread-per-pixel-pair form: A/B tests)
+    DwLdsArgs a;
+    a.x = (const char*)op.p[0]; a.w = (const float*)op.p[1]; a.bias = (const float*)op.p[2]; a.res = (const char*)op.p[3]; a.y = (char*)op.p[4];
+    a.N = N; a.H = H; a.W = W; a.C = C; a.x_cs = x_cs; a.x_co = x_co; a.y_cs = y_cs; a.y_co = y_co; a.res_cs = res_cs; a.res_co = res_co;
+    a.act = act; a.flip = flip; a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.cblocks = C / 64;
+    const long nblocks = (long)N * a.tiles_x * a.tiles_y * a.cblocks;
+    if (nblocks >= 256 && nblocks < (1L << 31)) {
+      constexpr int LDS = (10 * 34 + 7) / 8 * 1024;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)dwconv_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)dwconv_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+      }
+      if (a.res) hipLaunchKernelGGL(dwconv_lds_kernel<true>, dim3((unsigned)nblocks), dim3(256), LDS, s, a);
+      else hipLaunchKernelGGL(dwconv_lds_kernel<false>, dim3((unsigned)nblocks), dim3(256), LDS, s, a);
+      MSL_CHECK_LAUNCH("dwconv_lds");
+      return MSL_OK;
+    }
+  }
   const int V = v8 ? 8 : 4;
   const long total = (long)N * H * ((W + 1) / 2) * (C / V);
   MSL_REQUIRE(total < (1L << 31), "dwconv: too many items for 32-bit indexing");

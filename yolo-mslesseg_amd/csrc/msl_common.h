@@ -176,6 +176,26 @@ __device__ __forceinline__ void msl_glds16(const void* gsrc, unsigned lds_addr) 
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
+// Raw buffer descriptor over [p, p + 2 GiB) and one LDS-DMA piece through it (asm, like msl_glds16): each lane's 16 bytes at base + voff + soff go
+// to LDS bytes [lds_addr + 16 * lane, +16); an offset with bit 31 set is out of range — the load returns 0 to LDS without touching memory, which
+// is how padding, image edges and missing channels are staged (conv_wgrad_tr.hip, conv1x1.hip, the LDS-tiled depthwise conv).
+typedef int msl_i32x4 __attribute__((ext_vector_type(4)));
+#define MSL_DMA_OOB 0x80000000u
+__device__ __forceinline__ msl_i32x4 msl_buf_rsrc(const void* p) {
+  const unsigned long u = (unsigned long)p;
+  msl_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+  r.z = (int)0x80000000u;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void msl_buf_dma16(msl_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate): waits until at most the n youngest vector-memory operations
 // of the wave are outstanding (loads, stores and LDS-DMA count together, in issue order).  n > 32 waits for everything.
 __device__ __forceinline__ void msl_wait_vmcnt(int n) {
