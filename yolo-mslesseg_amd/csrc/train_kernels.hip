@@ -320,12 +320,12 @@ int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s) {
 // BN_ACT_BWD_APPLY: dz = gamma*invstd*(g - s1/M - zhat*s2/M), g = dy*act'(u).  Also writes dgamma = s2, dbeta = s1 (block 0).
 // Threads are laid out like the reduction (channel group x pixel lane): the per-channel constants are folded once into
 // registers, then each thread streams PPT pixels of its channel group.
-template <bool F32, int V>
+template <bool F32, int V, bool RES>  // RES: also d(residual) (+)= dy (its own instantiation: the third stream's registers would cost the plain form a wave per SIMD)
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ z, const float* __restrict__ stats,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
-                                                               int dz_cs, int dz_co, int act, int slots, int PPT) {
+                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first) {
   __shared__ float ks[2048];  // (s1, s2) per channel, summed over the accumulator slots
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
@@ -348,8 +348,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
   }
   const long p0 = (long)blockIdx.x * PL * PPT + pl;  // pixel of (k,u) = p0 + (k+u)*PL: every load instruction covers PL consecutive pixels
   constexpr int U = 4;  // batches of U pixel groups, software-pipelined like bn_act_kernel: 2U loads of the next batch in flight while this one is stored
-  RawV<F32, V> ga_[U], za_[U], gb_[U], zb_[U];
-  auto issue = [&](int k, RawV<F32, V> (&gg)[U], RawV<F32, V> (&zz)[U]) __attribute__((always_inline)) {
+  RawV<F32, V> ga_[U], za_[U], gb_[U], zb_[U], ra_[RES ? U : 1], rb_[RES ? U : 1];
+  const bool racc = RES && !gr_first;  // the residual's gradient already holds a contribution: a third stream of loads
+  auto issue = [&](int k, RawV<F32, V> (&gg)[U], RawV<F32, V> (&zz)[U], RawV<F32, V> (&rr)[RES ? U : 1]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       long p = p0 + (long)(k + u) * PL;
@@ -357,16 +358,35 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
       gg[u] = ldraw<F32, V>(dy, p * dy_cs + dy_co + c);
       zz[u] = ldraw<F32, V>(z, p * z_cs + z_co + c);
     }
+    if constexpr (RES) {
+      if (racc) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          long p = p0 + (long)(k + u) * PL;
+          p = p < M ? p : M - 1;
+          rr[u] = ldraw<F32, V>(gres, p * gr_cs + gr_co + c);
+        }
+      }
+    }
   };
-  issue(0, ga_, za_);
+  issue(0, ga_, za_, ra_);
   for (int k = 0; k < PPT; k += U) {
-    if (k + U < PPT) issue(k + U, gb_, zb_);
+    if (k + U < PPT) issue(k + U, gb_, zb_, rb_);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long p = p0 + (long)(k + u) * PL;
       float g[V], v[V];
       cvtraw<F32, V>(ga_[u], g);
       cvtraw<F32, V>(za_[u], v);
+      if constexpr (RES) {  // residual fan-out of the forward `y = act(bn(z)) + res`: d(res) (+)= dy — the pass already holds dy (a separate ADD_VIEW launch before)
+        float rg[V];
+#pragma unroll
+        for (int r = 0; r < V; ++r) rg[r] = 0.f;
+        if (racc) cvtraw<F32, V>(ra_[u], rg);
+#pragma unroll
+        for (int r = 0; r < V; ++r) rg[r] += g[r];
+        if (p < M) stv<F32, V>(gres, p * gr_cs + gr_co + c, rg);
+      }
 #pragma unroll
       for (int r = 0; r < V; r += 2) {  // float pairs → packed fp32 ops (see chan_reduce_kernel)
         const f2_t z2 = {v[r], v[r + 1]}, mu2 = {mu[r], mu[r + 1]}, is2 = {is[r], is[r + 1]}, ga2 = {ga[r], ga[r + 1]};
@@ -387,24 +407,33 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
       if (p < M) stv<F32, V>(dz, p * dz_cs + dz_co + c, v);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) { ga_[u] = gb_[u]; za_[u] = zb_[u]; }
+    for (int u = 0; u < U; ++u) { ga_[u] = gb_[u]; za_[u] = zb_[u]; if constexpr (RES) ra_[u] = rb_[u]; }
   }
 }
 
 // BN_ACT_BWD_APPLY: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc, 6 dz, 7 dgamma (dbeta = dgamma + i[20]) ; i as REDUCE + 14 dz_cs,15 dz_co, 20 dbeta offset (elements)
+// optional residual fan-out (i 16 = 1): p 4 = gradient view of the residual instead of beta (beta = gamma + i 22 elements), i 24 its stride, 25 its offset, 19 = 1 overwrite
 int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3], slots = slots_of(op, 21);
   MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_act_bwd_apply: bad args");
   MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14] && slots <= MSL_MAX_SLOTS, "bn_act_bwd_apply: bad dz view");
-  const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15]);
+  // i[16] = 1: p[4] is the residual's gradient view (i[24] stride, i[25] offset, i[19] = 1: first writer → overwrite) and beta = gamma + i[22] elements
+  const float* beta = (const float*)op.p[4];
+  void* gres = nullptr;
+  if (op.i[16] == 1) {
+    beta = (const float*)op.p[3] + op.i[22];
+    gres = op.p[4];
+    MSL_REQUIRE(gres && op.i[24] % 4 == 0 && op.i[25] % 4 == 0 && op.i[25] + C <= op.i[24], "bn_act_bwd_apply: bad residual-gradient view");
+  }
+  const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15]) && (!gres || ((op.i[24] | op.i[25]) & 7) == 0);
   const int PL = 256 / (C / (v8 ? 8 : 4));
   const int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;  // pixels per thread (multiple of 4): amortises the per-channel constants, keeps >= 2048 blocks on large layers
   const long per_block = (long)PL * PPT;
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
   float* dgamma = (float*)op.p[7];
   float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
-#define BB(F, V) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT)
+#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19]); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19]); } while (0)
   if (op.dtype == MSL_F32) { if (v8) BB(true, 8); else BB(true, 4); } else { if (v8) BB(false, 8); else BB(false, 4); }
 #undef BB
   MSL_CHECK_LAUNCH("bn_act_bwd_apply");

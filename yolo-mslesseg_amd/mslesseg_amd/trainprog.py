@@ -430,17 +430,20 @@ class TrainPlan(graph.Visitor):
         """dy = G(y) → dz written in place over z; dgamma/dbeta into the flat gradient; residual fan-out."""
         st = self.store
         gy = self.G(y)
-        if res is not None and not res_inplace:
-            gr = self.G(res)
-            first = self._init.first_write(gr)
-            ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(gr.t.data_ptr(), gy.t.data_ptr()),
-                                      i={0: self.N, 1: y.H, 2: y.W, 3: C, 10: gr.cs, 11: gr.co, 12: gy.cs, 13: gy.co, 20: 1 if first else 0}))
         acc = self._acc_bwd(C, ACC_SLOTS)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS}
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
-        ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=pcommon + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
-                                  i={**dims, 14: z.cs, 15: z.co, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
+        papply, extra = pcommon, {}
+        if res is not None and not res_inplace:
+            # residual fan-out d(res) (+)= dy rides in the apply pass, which reads dy anyway (a separate ADD_VIEW launch per shortcut before):
+            # p[4] carries the residual's gradient view, beta is addressed relative to gamma
+            gr = self.G(res)
+            first = self._init.first_write(gr)
+            papply = pcommon[:4] + (gr.t.data_ptr(),) + pcommon[5:]
+            extra = {16: 1, 19: 1 if first else 0, 22: st.off(name + ".beta") - st.off(name + ".gamma"), 24: gr.cs, 25: gr.co}
+        ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=papply + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
+                                  i={**dims, 14: z.cs, 15: z.co, 20: st.off(name + ".beta") - st.off(name + ".gamma"), **extra}))
 
     # ------------------------------------------------------------------ Visitor
     def input(self):
