@@ -4,8 +4,8 @@
 //
 // NHWC keeps CHANNELS contiguous, but this contraction runs over PIXELS, so neither operand is K-contiguous in memory.
 // A workgroup (8 waves) walks a run of 4x32-pixel output tiles (2x32 for stride 2).  Each tile of dz and the matching x halo
-// tile are copied to LDS with coalesced 16-byte LDS-DMA transfers along the channel axis, DOUBLE-BUFFERED: the DMA of
-// tile i+1 is in flight while tile i is multiplied.  Waves pull MFMA fragments with ds_read_b64_tr_b16 (a 4-pixel x 16-channel
+// tile are copied to LDS with coalesced 16-byte LDS-DMA transfers along the channel axis into a RING of D staged tiles (3 where the
+// LDS allows): the DMA of tiles i+1 .. i+D-1 is in flight while tile i is multiplied.  Waves pull MFMA fragments with ds_read_b64_tr_b16 (a 4-pixel x 16-channel
 // block read column-major: 4 consecutive PIXELS of one channel per lane; two reads = the 8 k-values of
 // v_mfma_f32_16x16x32_bf16).  Fragment reuse is what keeps the LDS pipe below the MFMA pipe:
 //   * a wave owns up to 2 co-tiles x 2 ci-tiles (16 channels each) x all taps — every A/B fragment feeds 2 MFMAs;
