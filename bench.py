@@ -206,10 +206,7 @@ def train_setup(args, dev, rank, world, state, B):
     from mslesseg_amd.train import Trainer
     from mslesseg_amd.yolo import YOLO
 
-    y = YOLO.__new__(YOLO)  # a model object around the benchmark weights (no checkpoint file involved)
-    y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
-    y.dtype = y.train_dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
-    y.scale, y.nc, y.state, y.pretrained = args.scale, 1, state, True
+    y = bench_model(args, dev, state)
     ds = D.SyntheticSegDataset(B, args.size, seed=rank)
     tr = Trainer(y, dataset=ds, val_dataset=None, epochs=1, batch=B, project=ROOT / "gpurun_out" / "bench_runs", name=f"r{rank}",
                  imgsz=args.size, nbs=B * world, warmup_epochs=0.0, replica=(args.mode == "replicas"))
@@ -457,6 +454,76 @@ def volume_plane_bench(eng, dev):
     return res
 
 
+class RepeatDataset:
+    """`ds` repeated k times (optionally only the items `select(i)` keeps): a fold-sized dataset from the one demo patient's slices."""
+
+    def __init__(self, ds, k, select=None, raw=True):
+        self.ds, self.imgsz = ds, ds.imgsz
+        self.map = [i for _ in range(k) for i in range(len(ds)) if select is None or select(i)]
+        if raw:
+            self.raw = [ds.raw[i] for i in self.map]  # raw slices: resized on the device
+
+    def __len__(self):
+        return len(self.map)
+
+    def resized_shape(self, i):
+        return self.ds.resized_shape(self.map[i])
+
+    def get(self, i):
+        return self.ds.get(self.map[i])
+
+
+def demo_p39_dataset():
+    from mslesseg_amd import data as D
+
+    z = np.load(ROOT / "tests" / "golden" / "demo_volumes.npz")
+    shape = tuple(int(v) for v in z["P39_shape"])
+    mask = np.unpackbits(z["P39_mask_bits"])[: int(np.prod(shape))].reshape(shape).astype(np.uint8)
+    return D.VolumeSliceDataset(z["P39_flair_u16"].astype(np.float64), mask)
+
+
+def bench_model(args, dev, state):
+    from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
+    from mslesseg_amd.yolo import YOLO
+
+    y = YOLO.__new__(YOLO)  # a model object around the benchmark weights (no checkpoint file involved)
+    y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
+    y.dtype = y.train_dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
+    y.scale, y.nc, y.state, y.pretrained = args.scale, 1, state, True
+    return y
+
+
+def fit_epoch_bench(args, dev, rank, world, state, dist):
+    """`model.train()`'s whole epoch — train steps from the device feeder, validation of the held-out fold, checkpoint — on a fold-sized dataset
+    (demo patient P39's 361 lesion slices x 8: 2 312 train / 576 held out, like the reference's folds of 112-174 iterations x batch), per rank:
+    seconds of train steps / validation / checkpoint hand-off.  What `--mode train` cannot see: work that only one rank does."""
+    from mslesseg_amd.train import Trainer
+
+    base = demo_p39_dataset()
+    tr_ds = RepeatDataset(base, 8, select=lambda i: i % 5 != 0)
+    va_ds = RepeatDataset(base, 8, select=lambda i: i % 5 == 0)
+    B = args.batch or 256  # what batch=-1 resolves to
+    epochs = max(args.steps, 2) + 1
+    tr = Trainer(bench_model(args, dev, state), dataset=tr_ds, val_dataset=va_ds, epochs=epochs, batch=B, project=ROOT / "gpurun_out" / "bench_runs", name=f"fit{rank}_of{world}",
+                 imgsz=args.size, close_mosaic=0)
+    t0 = time.perf_counter()
+    tr.fit()
+    wall = time.perf_counter() - t0
+    et = tr.epoch_times[1:]  # the first epoch builds the validation plans
+    mine = [float(np.median([e[k] for e in et])) for k in ("train_s", "val_s", "ckpt_s")]
+    allr = [mine]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        g = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(g, t)
+        allr = [[float(v) for v in x] for x in g]
+    epoch_s = max(sum(r) for r in allr)
+    return {"train_slices": len(tr_ds), "val_slices": len(va_ds), "per_gpu_batch": B, "iterations_per_epoch": tr.nb, "epochs_timed": len(et), "fit_wall_s": round(wall, 2),
+            "epoch_s": round(epoch_s, 4), "per_rank_train_val_ckpt_s": [[round(v, 4) for v in r] for r in allr],
+            "rank0_only_s": round(allr[0][2], 4), "rank0_only_share_of_epoch": round(allr[0][2] / epoch_s, 4),
+            "note": "medians over the timed epochs; validation is sharded over the ranks (train._validate), checkpoints are written by a thread from a pinned-host snapshot"}, tr
+
+
 def train_e2e_bench(args, dev, rank, world, state, B):
     """`model.train()`'s real loop: batches come from the data feeder (mosaic on, the reference's augmentation set) instead of one resident batch.
     Dataset: the lesion slices of demo patient P39 rendered as the reference's dataset stage writes them (361 slices, three planes), repeated 8x
@@ -467,34 +534,12 @@ def train_e2e_bench(args, dev, rank, world, state, B):
     from mslesseg_amd.train import Trainer
     from mslesseg_amd.yolo import YOLO
 
-    z = np.load(ROOT / "tests" / "golden" / "demo_volumes.npz")
-    shape = tuple(int(v) for v in z["P39_shape"])
-    mask = np.unpackbits(z["P39_mask_bits"])[: int(np.prod(shape))].reshape(shape).astype(np.uint8)
     t0 = time.perf_counter()
-    base = D.VolumeSliceDataset(z["P39_flair_u16"].astype(np.float64), mask)
+    base = demo_p39_dataset()
     t_ds = time.perf_counter() - t0
 
-    class Repeat:
-        def __init__(self, ds, k):
-            self.ds, self.k, self.imgsz = ds, k, ds.imgsz
-            self.raw = [ds.raw[i % len(ds)] for i in range(len(ds) * k)] if not args.host_augment else None  # raw slices: resized on the device
-
-        def __len__(self):
-            return len(self.ds) * self.k
-
-        def resized_shape(self, i):
-            return self.ds.resized_shape(i % len(self.ds))
-
-        def get(self, i):
-            return self.ds.get(i % len(self.ds))
-
-    ds = Repeat(base, 8)
-    if args.host_augment:
-        del ds.raw
-    y = YOLO.__new__(YOLO)
-    y.ckpt_path, y.task, y.device, y.names, y._engine, y.trainer = Path("synthetic-weights"), "segment", str(dev), {0: "lesion"}, None, None
-    y.dtype = y.train_dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
-    y.scale, y.nc, y.state, y.pretrained = args.scale, 1, state, True
+    ds = RepeatDataset(base, 8, raw=not args.host_augment)
+    y = bench_model(args, dev, state)
     tr = Trainer(y, dataset=ds, val_dataset=None, epochs=10 ** 6, batch=B, project=ROOT / "gpurun_out" / "bench_runs", name=f"e2e{rank}", imgsz=args.size,
                  nbs=B * world, warmup_epochs=0.0, device_augment=not args.host_augment)
 
@@ -537,9 +582,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="train", choices=["train", "predict", "train-e2e", "replicas"],
+    ap.add_argument("--mode", default="train", choices=["train", "predict", "train-e2e", "replicas", "fit-epoch"],
                     help="train: one resident batch per step (the headline); predict: the inference leg; train-e2e: the same step fed by the data feeder "
-                         "(mosaic on); replicas: independent trainings, one per GPU, no collective (SURVEY 8e zero-communication mode)")
+                         "(mosaic on); replicas: independent trainings, one per GPU, no collective (SURVEY 8e zero-communication mode); fit-epoch: whole epochs of "
+                         "model.train() on a fold-sized dataset (train steps + sharded validation + checkpoint), --steps = epochs timed")
     ap.add_argument("--batch", type=int, default=0, help="slices per GPU per step (default: 128 for both legs — north_star: batch >= 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--scale", default="n", choices=["n", "s"], help="n = BASELINE configs[1]; s = configs[2] (YOLO11s-seg, seeded random initialisation)")
@@ -629,6 +675,16 @@ def main():
                                                      "throughput mode: |dDice| <= 1e-3 per plane volume, not at the 1e-4 tolerance")}
                     del eng, imgs
                     torch.cuda.empty_cache()
+    elif args.mode == "fit-epoch":
+        rec, tr = fit_epoch_bench(args, dev, rank, world, state, dist)
+        value = rec["train_slices"] / rec["epoch_s"]
+        line.update(value=round(value, 2), ms_per_step=round(rec["epoch_s"] / max(tr.nb, 1) * 1e3, 4), steps=rec["epochs_timed"], warmup=1, scaling="strong",
+                    data="real FLAIR slices (demo patient P39, 361 lesion slices x 8, every 5th held out) through the training augmentation",
+                    config={"workload": f"whole epochs of model.train() ({cfg_name}): {model_name} nc=1, batch {rec['per_gpu_batch']}/GPU, {args.dtype}; device feeder (mosaic on) + "
+                                        f"train steps + eval-mode validation of the held-out fifth (sharded over ranks) + last.pt/best.pt; value = train slices per epoch second",
+                            "per_gpu_batch": rec["per_gpu_batch"], "global_batch": rec["per_gpu_batch"] * world, "parallelism": f"dp{world}"})
+        if rank == 0:
+            line["fit_epoch"] = rec
     elif args.mode == "train-e2e":
         B = args.batch or 128
         tr, step, split = train_e2e_bench(args, dev, rank, world, state, B)

@@ -25,13 +25,27 @@ def main():
     from mslesseg_amd.yolo import YOLO
 
     ds = D.SyntheticSegDataset(16, 128, seed=0)
-    val = D.SyntheticSegDataset(4, 128, seed=1)
+    val = D.SyntheticSegDataset(12, 128, seed=1)  # three validation batches of 4: rank 0 scores batches 0 and 2, rank 1 batch 1
     model = YOLO("yolo11n-seg.pt", precision="fp32")
     tr = Trainer(model, dataset=ds, val_dataset=val, epochs=2, batch=4, project=out, name=f"w{world}", imgsz=128, nbs=4 * world, warmup_epochs=0.0,
                  augment=False, close_mosaic=0)
     assert tr.world == world and tr.nb == 16 // (4 * world)
-    tr.fit()  # 2 epochs: all-reduce every step; rank 0 alone validates and writes the files; everyone meets at the final barrier
-    torch.save({"p": tr.store.p.cpu(), "ema": tr.ema_p.cpu(), "steps": tr.opt_steps}, out / f"rank{rank}_of{world}.pt")
+    tr.fit()  # 2 epochs: all-reduce every step; validation sharded over the ranks; rank 0 writes the files; everyone meets at the final barrier
+    rec = {"p": tr.store.p.cpu(), "ema": tr.ema_p.cpu(), "steps": tr.opt_steps, "model_device": model.device, "trainer_device": str(tr.device),
+           "epoch_times": [[e["train_s"], e["val_s"], e["ckpt_s"]] for e in tr.epoch_times]}
+    # the sharded validation against the same pass done by one rank alone, on the same (bit-identical across ranks) EMA weights
+    vl, mets = tr._validate()
+    rec["val_sharded"] = {"losses": torch.tensor(vl), "metrics": {k: float(v) for k, v in mets.items()}}
+    if world > 1:
+        dist.barrier()
+        tr.world, tr.rank, keep = 1, 0, (tr.world, tr.rank)
+        vl1, mets1 = tr._validate()  # no collective inside at world 1: every rank can do it on its own
+        tr.world, tr.rank = keep
+        rec["val_single"] = {"losses": torch.tensor(vl1), "metrics": {k: float(v) for k, v in mets1.items()}}
+    # predict() after fit() runs on the trainer's device with the reloaded best.pt (it used to fall back to cuda:0's default)
+    res = model(D.SyntheticSegDataset(1, 128, seed=3).get(0)[0], verbose=False)[0]
+    rec["predict_device"] = str(model._get_engine().device)
+    torch.save(rec, out / f"rank{rank}_of{world}.pt")
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
 """Data-parallel training rehearsed on one GPU (-m gpu): two real `Trainer` ranks (processes) under a gloo group share the box's GPU, run two
-epochs of `fit()` — per-step flat-gradient all-reduce, rank-0-only validation + checkpoint writing, final barrier — and must end with bit-identical
-parameters and EMA; a single-rank run of the same schedule on rank 0's shard alone must differ (the other rank's gradient took part).
+epochs of `fit()` — per-step flat-gradient all-reduce, validation sharded over the ranks (one all-gather of the match records), checkpoint files
+from rank 0's writer thread, final barrier — and must end with bit-identical parameters and EMA; the sharded validation must give the metrics
+and val losses one rank computes alone on the same weights; a single-rank run of the same schedule on rank 0's shard alone must differ (the other rank's gradient took part).
 The production collective is RCCL over xGMI, one rank per GPU (`torch.distributed` backend "nccl"): same code path, `allreduce_gradients`."""
 import os
 import subprocess
@@ -43,6 +44,13 @@ def test_two_trainer_ranks_stay_identical_and_both_contribute(tmp_path):
     for f in ("weights/best.pt", "weights/last.pt", "results.csv", "args.yaml"):  # written by rank 0 only
         assert (run / f).exists() and (run / f).stat().st_size > 0
     assert len((run / "results.csv").read_text().strip().splitlines()) == 3
+    for r in (a, b):
+        sh, si = r["val_sharded"], r["val_single"]
+        assert torch.allclose(sh["losses"], si["losses"], rtol=2e-4, atol=1e-6), (sh["losses"], si["losses"])  # the loss op sums with fp32 atomics: 1e-5 run to run
+        for k, v in si["metrics"].items():
+            assert abs(sh["metrics"][k] - v) <= 1e-6, (k, sh["metrics"][k], v)
+        assert r["model_device"] == r["trainer_device"] == r["predict_device"]
+    assert a["val_sharded"]["metrics"] == b["val_sharded"]["metrics"]  # every rank rebuilds the same merged lists
     _launch(tmp_path, 1, 29532)
     solo = torch.load(tmp_path / "rank0_of1.pt", weights_only=True)
     assert float((solo["p"] - a["p"]).abs().max()) > 0

@@ -207,7 +207,42 @@ def test_predict_variants_mixed_work_list_equals_single_variant_runs(trained_sta
     assert seen == [1, 1, 1, 1]
     assert not torch.equal(single[0], V.predict_volume(models["HE"], fl, "axial", idx["axial"], mejora="GC").cpu())  # the weights matter
     with pytest.raises(KeyError):
-        V.predict_variants(models, [(fl, "LT", "axial", idx["axial"])], rank=0, world=1)
+        V.predict_variants(models, [(fl, "LT", "axial", idx["axial"])], rank=0, world=1, strict=True)
+
+
+def test_a_bad_item_is_logged_and_skipped_like_the_reference_skips_a_patient(trained_state, demo_volumes, tmp_path, caplog):
+    """The reference wraps every patient in try / except → logger.warning("… se omite") → continue [REF scripts/generar_predicciones.py:289-301,
+    reconstruir_volumen.py:297-306]; the batched paths keep that: one wrong-shaped volume, one variant without a model and one out-of-range
+    slice index in the list leave their entries None, the good items are still predicted and equal the undisturbed run."""
+    import logging
+
+    from ultralytics import YOLO
+
+    from mslesseg_amd import params
+
+    path = tmp_path / "GC" / "weights" / "best.pt"
+    params.save_checkpoint(path, trained_state, "n", 1, {0: "lesion"})
+    models = {"GC": YOLO(path)}
+    fl, gt = demo_volumes["P39_flair"], demo_volumes["P39_mask"]
+    idx = V.select_slices(gt, "axial", 6)
+    good = (fl, "GC", "axial", idx)
+    items = [good, (fl[:, :, 0], "GC", "axial", None), (fl, "LT", "coronal", idx), (fl, "GC", "sagital", [10 ** 6]), good]
+    want = V.predict_volume(models["GC"], fl, "axial", idx, mejora="GC").cpu()
+    with caplog.at_level(logging.WARNING, logger="ultralytics"):
+        outs = V.predict_variants(models, items, rank=0, world=1)
+    assert outs[1] is None and outs[2] is None and outs[3] is None
+    assert torch.equal(outs[0].cpu(), want) and torch.equal(outs[4].cpu(), want)
+    assert sum("se omite" in r.getMessage() for r in caplog.records) == 3
+    # the per-patient loop around the three-plane consensus
+    plane_models = {pl: models["GC"] for pl in ("axial", "coronal", "sagital")}
+    sel = {pl: V.select_slices(gt, pl, 4) for pl in ("axial", "coronal", "sagital")}
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="ultralytics"):
+        res = V.predict_patients(plane_models, [("P39", fl), ("Pbad", np.zeros((4, 4))), ("P39b", fl)], indices={"P39": sel, "P39b": sel})
+    assert res["Pbad"] is None and sum("Pbad" in r.getMessage() for r in caplog.records) == 1
+    assert torch.equal(res["P39"][0], res["P39b"][0]) and res["P39"][0].dtype == torch.uint8
+    with pytest.raises(ValueError):
+        V.predict_patients(plane_models, [("Pbad", np.zeros((4, 4)))], strict=True)
 
 
 def test_validator_mask_counts_op_equals_the_dense_formulation(trained_state, demo_volumes):

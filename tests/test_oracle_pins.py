@@ -198,3 +198,80 @@ def test_fused_parameter_counts_equal_upstream_model_summaries():
         unfused = sum(p.numel() for p in m.parameters())
         bn = sum(mod.num_features for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
         assert unfused - bn == want, (scale, unfused, bn)
+
+
+# ----------------------------------------------------------------------------- KAT: the 25 args.yaml (resolved hyper-parameters)
+def test_hyperparameters_match_the_reference_args_yaml(golden_dir):
+    """Every hyper-parameter this library hard-codes or defaults, against the block the reference's 25 args.yaml files share
+    [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/args.yaml:5-103; fixture tests/golden/args_kat.json written by make_golden_ref.py]."""
+    import inspect
+
+    from mslesseg_amd import augment as A
+    from mslesseg_amd import data as D
+    from mslesseg_amd import engine as E
+    from mslesseg_amd import loss as L
+    from mslesseg_amd import train as T
+    from oracle import loss as OL
+
+    doc = json.loads((golden_dir / "args_kat.json").read_text())
+    assert doc["files"] == 25
+    a = doc["common"]
+    d = T.DEFAULTS
+    for k in ("imgsz", "nbs", "seed", "lrf", "warmup_epochs", "weight_decay", "close_mosaic", "momentum", "warmup_momentum"):
+        assert d[k] == a[k], k
+    # optimizer 'auto' resolves lr0 / warm-up bias LR itself [UPSTREAM build_optimizer]: args.yaml keeps the unused 0.01 / 0.1, results.csv pins
+    # what ran (test_lr_schedule_matches_all_25_results_csv): AdamW 0.002, every group warmed up from 0
+    assert a["optimizer"] == "auto" and a["lr0"] == 0.01 and a["warmup_bias_lr"] == 0.1 and d["optimizer"] is None and d["warmup_bias_lr"] == 0.0
+    assert (L.GAIN_BOX, L.GAIN_CLS, L.GAIN_DFL) == (a["box"], a["cls"], a["dfl"]) == (7.5, 0.5, 1.5)
+    assert OL.GAINS == dict(box=a["box"], cls=a["cls"], dfl=a["dfl"])
+    assert D.HSV == (a["hsv_h"], a["hsv_s"], a["hsv_v"]) and D.TRANSLATE == a["translate"] and D.SCALE == a["scale"] and D.FLIPLR == a["fliplr"]
+    assert D.MASK_RATIO == a["mask_ratio"] and a["overlap_mask"] is True and a["mosaic"] == 1.0
+    sig = inspect.signature(D.draw_params).parameters
+    assert (sig["scale"].default, sig["translate"].default, sig["hsv"].default, sig["fliplr"].default) == (a["scale"], a["translate"], D.HSV, a["fliplr"])
+    sig = inspect.signature(A.DeviceAugmenter.__init__).parameters
+    assert (sig["mask_ratio"].default, sig["scale"].default, sig["translate"].default, sig["hsv"].default, sig["fliplr"].default) == (4, 0.5, 0.1, D.HSV, 0.5)
+    # the transforms this library does not implement are switched off in every run of the reference
+    for k in ("degrees", "shear", "perspective", "flipud", "mixup", "copy_paste", "bgr", "cutmix"):
+        assert a[k] == 0.0, k
+    assert a["rect"] is False and a["single_cls"] is False and a["multi_scale"] is False and a["cos_lr"] is False and a["freeze"] is None
+    assert E.IOU_THRES == a["iou"] and E.MAX_DET == a["max_det"] and a["conf"] is None and a["half"] is False and a["retina_masks"] is False
+    assert a["amp"] is True and a["cache"] is True and a["batch"] == -1 and a["epochs"] == 50 and a["patience"] == 100 and a["deterministic"] is True
+
+
+def test_written_args_yaml_and_results_row_have_the_reference_types(tmp_path, golden_dir):
+    """The files `model.train()` leaves are the drop-in contract [REF scripts/train.py:105-116]: `amp` boolean, `optimizer` the requested name,
+    numbers of results.csv with six significant digits like the reference's rows."""
+    import re
+
+    row = [3, 214.97912, 2.131394, 0.0007308425000000001]
+    txt = ",".join([str(row[0])] + [f"{v:.6g}" for v in row[1:]])
+    assert txt == "3,214.979,2.13139,0.000730843"
+    runs = json.loads((golden_dir / "lr_kat.json").read_text())
+    for lr in runs[0]["lr_pg0"]:
+        assert float(f"{lr:.6g}") == lr and re.fullmatch(r"[0-9.e-]+", f"{lr:.6g}")
+
+
+# ----------------------------------------------------------------------------- KAT: loss magnitudes / metric ranges of the 25 results.csv
+def test_own_training_run_lands_in_the_reference_loss_range(golden_dir):
+    """A sanity pin of the loss normalisation (box / seg / cls / dfl sums and their divisors): the end-of-training losses of the demo run this
+    library trained (profiles/r02g_demo_p39_train_results.csv: one patient, 80 epochs, random init) against the range the reference's 25 runs
+    end in at epoch 50 [REF trains/*/…/results.csv:51].  Different data and no COCO pre-training, so the check is a band (0.6 x min … 1.5 x max),
+    wide enough for that and far too narrow for a wrong gain or a per-image instead of per-batch normalisation (factors of 2 - 128)."""
+    import csv
+    from pathlib import Path
+
+    doc = json.loads((golden_dir / "results_kat.json").read_text())
+    assert doc["runs"] == 25
+    ref = doc["range"]["50"]
+    own = list(csv.DictReader(open(Path(__file__).resolve().parents[1] / "profiles" / "r02g_demo_p39_train_results.csv")))[-1]
+    for c in ("train/box_loss", "train/seg_loss", "train/cls_loss", "train/dfl_loss", "val/box_loss", "val/seg_loss", "val/cls_loss", "val/dfl_loss"):
+        lo, hi = ref[c]
+        assert 0.6 * lo <= float(own[c]) <= 1.5 * hi, (c, own[c], lo, hi)
+    # first-epoch losses of the reference (COCO-pretrained start) for the record: box 2.2-2.7, seg 2.9-3.5, cls 3.0-4.0, dfl 1.2-1.4
+    first = doc["range"]["1"]
+    assert 2.0 < first["train/box_loss"][0] < first["train/box_loss"][1] < 3.0 and 1.0 < first["train/dfl_loss"][0] < 1.5
+    # metric columns are fractions
+    for e in doc["range"].values():
+        for c, (lo, hi) in e.items():
+            if c.startswith("metrics/"):
+                assert 0.0 <= lo <= hi <= 1.0

@@ -4,6 +4,7 @@ import json
 
 import numpy as np
 import pytest
+import torch
 
 from mslesseg_amd import data as D
 from mslesseg_amd import labels as LB
@@ -115,3 +116,57 @@ def test_replica_skips_finished_runs(tmp_path):
     seen = []
     R.run_replicas(jobs, seen.append, run_dir_of=lambda job: tmp_path / job[0] / f"fold{job[1]}", rank=0, world=1)
     assert seen == [("axial", 2)]
+
+
+def test_validation_batches_are_dealt_over_ranks_without_changing_them():
+    """val_batches: one rank → batches of min(batch, 128) in fold order; several ranks → the same boundaries (every rank takes each world-th batch) while
+    every rank gets at least one, smaller equal batches for a fold too short for that."""
+    from mslesseg_amd.train import val_batches
+
+    one = val_batches(584, 256, 1)
+    assert one == [(0, 128), (128, 256), (256, 384), (384, 512), (512, 584)]
+    assert val_batches(584, 256, 2) == one and val_batches(584, 256, 4) == one
+    eight = val_batches(584, 256, 8)
+    assert len(eight) == 8 and eight[0] == (0, 73) and eight[-1][1] == 584 and all(b[1] - b[0] <= 73 for b in eight)
+    for world in (1, 2, 3, 8):
+        bs = val_batches(361, 64, world)
+        dealt = sorted(b for r in range(world) for b in bs[r::world])
+        assert dealt == bs and bs[0][0] == 0 and bs[-1][1] == 361 and all(a[1] == b[0] for a, b in zip(bs, bs[1:]))
+    assert val_batches(3, 128, 8) == [(0, 1), (1, 2), (2, 3)]  # fewer slices than ranks: some ranks score nothing
+
+
+def test_segstats_parts_of_several_ranks_merge_into_the_single_rank_lists():
+    """SegStats.export / merged: per-image rows carry the image index, so the union of what the ranks collected over disjoint batches is, row for
+    row, what one rank collects walking the fold in order (sharded validation: train._validate)."""
+    from mslesseg_amd import metrics as MT
+
+    rng = np.random.default_rng(0)
+    B, P, G = 12, 7, 3
+
+    def batch(lo, hi):
+        n = hi - lo
+        r = np.random.default_rng([1, lo])
+        n_pred = torch.from_numpy(r.integers(0, P + 1, n))
+        n_gt = torch.from_numpy(r.integers(0, G + 1, n))
+        gt_xy = torch.from_numpy(r.uniform(0, 60, (n, G, 2)).astype(np.float32))
+        gt = torch.cat([gt_xy, gt_xy + torch.from_numpy(r.uniform(8, 30, (n, G, 2)).astype(np.float32))], 2)
+        pr = gt[:, r.integers(0, G, P)] + torch.from_numpy(r.normal(0, 2.0, (n, P, 4)).astype(np.float32))
+        conf = torch.from_numpy(r.uniform(0.01, 1, (n, P)).astype(np.float32))
+        pm = torch.from_numpy((r.random((n, P, 64)) < 0.4).astype(np.float32))
+        gm = torch.from_numpy((r.random((n, G, 64)) < 0.4).astype(np.float32))
+        return pr, conf, torch.zeros(n, P), pm, n_pred, gt, torch.zeros(n, G), gm, n_gt
+
+    bounds = [(0, 4), (4, 8), (8, 12)]
+    single = MT.SegStats()
+    for lo, hi in bounds:
+        single.add_batch(*batch(lo, hi), first_id=lo)
+    ranks = [MT.SegStats(), MT.SegStats()]
+    for bi, (lo, hi) in enumerate(bounds):
+        ranks[bi % 2].add_batch(*batch(lo, hi), first_id=lo)
+    merged = MT.SegStats.merged([ranks[1].export(), ranks[0].export()])  # part order must not matter
+    assert merged.pids == single.pids and merged.tids == single.tids and len(single.tids) == B
+    for f in ("tp_b", "tp_m", "conf", "pcls", "tcls"):
+        a, b = getattr(merged, f), getattr(single, f)
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), f
+    assert merged.result() == single.result() and single.result()["metrics/mAP50(B)"] > 0
+    del rng

@@ -116,8 +116,8 @@ class SliceCache:
 
 
 class DeviceAugmenter:
-    def __init__(self, cache: SliceCache, size: int = D.IMGSZ, mask_ratio: int = 4, scale: float = 0.5, translate: float = 0.1,
-                 hsv=(0.015, 0.7, 0.4), fliplr: float = 0.5):
+    def __init__(self, cache: SliceCache, size: int = D.IMGSZ, mask_ratio: int = D.MASK_RATIO, scale: float = D.SCALE, translate: float = D.TRANSLATE,
+                 hsv=D.HSV, fliplr: float = D.FLIPLR):
         self.c, self.size, self.mask_ratio = cache, int(size), int(mask_ratio)
         self.scale, self.translate, self.hsv, self.fliplr = scale, translate, hsv, fliplr
         self.device = cache.device
@@ -172,7 +172,7 @@ class DeviceAugmenter:
         if augment and len(pid):
             vb = p_b[v_poly]
             q = D.affine_points(pts, Ms[vb, 0], Ms[vb, 1], Ms[vb, 2], Ms[vb, 3], Ms[vb, 4], Ms[vb, 5])
-            q = np.clip(q, 0, [s - 1e-3, s - 1e-3]).astype(np.float32)
+            q = D.clip_polygons_to_image(q, off, s, s)
             keep = D.box_candidates(D.poly_bboxes(pts, off) * scs.astype(np.float32)[p_b][:, None], D.poly_bboxes(q, off))
             fl = flips[vb]
             q[:, 0] = np.where(fl, np.float32(s) - q[:, 0], q[:, 0])

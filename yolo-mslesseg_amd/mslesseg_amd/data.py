@@ -21,6 +21,10 @@ from . import labels as L
 
 IMGSZ = 640
 PAD = 114
+# augmentation hyper-parameters of the reference's runs [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/args.yaml:85-97; the same in all 25
+# args.yaml: tests/test_oracle_pins.py::test_hyperparameters_match_the_reference_args_yaml]
+HSV = (0.015, 0.7, 0.4)
+TRANSLATE, SCALE, FLIPLR, MASK_RATIO = 0.1, 0.5, 0.5, 4
 MAX_INSTANCES = 255  # per slice: pixel value of the overlap mask = 1 + instance index (uint8)
 
 
@@ -124,6 +128,54 @@ def box_candidates(b0: np.ndarray, b1: np.ndarray) -> np.ndarray:
     return (w1 > 2) & (h1 > 2) & (w1 * h1 / (w0 * h0 + e) > np.float32(0.01)) & (ar < 100)
 
 
+def clip_polygons_to_image(q: np.ndarray, off: np.ndarray, w: float, h: float) -> np.ndarray:
+    """Warped polygons (float64 [V,2], polygon i = q[off[i]:off[i+1]]) → float32 vertices clipped the way upstream's RandomPerspective leaves them
+    [UPSTREAM RandomPerspective.apply_segments + ops.segment2box + Instances.clip]: the box of a polygon is the box of its points INSIDE the
+    image, and the polygon is clipped to that box — not to the image, which would stretch the box of a lesion cut by the border to the extent of
+    the part that left the image.  Upstream gets "the points inside" from a 1000-point resampling of the outline; here the same set is taken in
+    the limit: the vertices inside plus the exact points where an edge crosses a border line, so the box is that of the outline's part inside the
+    image, independent of how sparsely the contour was traced.  A polygon sticking out on three or four sides is clipped to the image first
+    (upstream, 8.3.5x onwards).  Polygons with no point inside collapse to a zero box (dropped by box_candidates).  Vectorised over the ragged
+    array: the per-sample restatement (`warp_instances`) and the batched device feeder (augment.DeviceAugmenter.prepare) both call this."""
+    st, cnt = off[:-1], np.diff(off)
+    P = len(st)
+    if P == 0:
+        return q.astype(np.float32)
+    seg = np.repeat(np.arange(P), cnt)
+    x, y = q[:, 0].copy(), q[:, 1].copy()
+    sides = ((np.minimum.reduceat(x, st) < 0).astype(np.int64) + (np.minimum.reduceat(y, st) < 0) + (np.maximum.reduceat(x, st) > w) + (np.maximum.reduceat(y, st) > h))
+    pre = (sides >= 3)[seg]
+    x = np.where(pre, np.clip(x, 0, w), x)
+    y = np.where(pre, np.clip(y, 0, h), y)
+    inside = (x >= 0) & (y >= 0) & (x <= w) & (y <= h)
+    nxt = np.arange(len(x)) + 1
+    nxt[off[1:] - 1] = st
+    xj, yj = x[nxt], y[nxt]
+    INF = np.inf
+    lo_x, hi_x = np.where(inside, x, INF), np.where(inside, x, -INF)
+    lo_y, hi_y = np.where(inside, y, INF), np.where(inside, y, -INF)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for bx in (0.0, float(w)):  # edge i -> i+1 against the line x = bx
+            cross = (x < bx) != (xj < bx)
+            yc = y + (bx - x) / (xj - x) * (yj - y)
+            ok = cross & (yc >= 0) & (yc <= h)
+            lo_x, hi_x = np.where(ok, np.minimum(lo_x, bx), lo_x), np.where(ok, np.maximum(hi_x, bx), hi_x)
+            lo_y, hi_y = np.where(ok, np.minimum(lo_y, yc), lo_y), np.where(ok, np.maximum(hi_y, yc), hi_y)
+        for by in (0.0, float(h)):  # against the line y = by
+            cross = (y < by) != (yj < by)
+            xc = x + (by - y) / (yj - y) * (xj - x)
+            ok = cross & (xc >= 0) & (xc <= w)
+            lo_y, hi_y = np.where(ok, np.minimum(lo_y, by), lo_y), np.where(ok, np.maximum(hi_y, by), hi_y)
+            lo_x, hi_x = np.where(ok, np.minimum(lo_x, xc), lo_x), np.where(ok, np.maximum(hi_x, xc), hi_x)
+    bx1, by1 = np.minimum.reduceat(lo_x, st), np.minimum.reduceat(lo_y, st)
+    bx2, by2 = np.maximum.reduceat(hi_x, st), np.maximum.reduceat(hi_y, st)
+    none = ~np.isfinite(bx1)
+    bx1, by1, bx2, by2 = (np.where(none, 0.0, v) for v in (bx1, by1, bx2, by2))
+    x = np.clip(x, bx1[seg], bx2[seg])
+    y = np.clip(y, by1[seg], by2[seg])
+    return np.stack([x, y], 1).astype(np.float32)
+
+
 def flatten_instances(inst):
     """list of (cls, [k,2] float32) -> (cls [P], pts [V,2] float32, off [P+1])."""
     cls = np.asarray([c for c, _ in inst], np.float32)
@@ -188,7 +240,7 @@ class VolumeSliceDataset(_SliceDataset):
     """The dataset `extraer_dataset` would stage for one patient volume, built in memory: per plane the lesion-bearing slices
     (`volume.select_slices` = Paciente.indices_a_usar), each rendered like `plt.imsave(corte.T, cmap="gray", origin="lower")` + `cv2.imread`
     (`volume.slice_as_png_array`), its GT mask cut the same way and traced into polygons like `convert_segment_masks_to_yolo_seg` writes them
-    (normalised, 6 decimals) [REF scripts/extraer_dataset.py:174-227, utils/Paciente.py:281-295]."""
+    (normalised, 6 decimals) [REF scripts/extraer_dataset.py:174-227, utils/Paciente.py:261-275]."""
 
     def __init__(self, flair: np.ndarray, mask: np.ndarray, planes=("axial", "coronal", "sagital"), num_cortes=None, mejora=None, imgsz: int = IMGSZ,
                  keep=None):
@@ -250,8 +302,8 @@ def _letterbox(img, inst, size):
 # Random draws of a whole batch in one go (the device feeder prepares 128 slices per step: per-sample scalar draws and 3x3 matrix products cost
 # more host time than everything else it does).  Both paths — `augment` below and augment.DeviceAugmenter — consume the same record, so they see
 # the same numbers however those were generated.
-def draw_params(rng, B: int, n_ds: int, mosaic: bool, size: int = IMGSZ, scale: float = 0.5, translate: float = 0.1, hsv=(0.015, 0.7, 0.4),
-                fliplr: float = 0.5) -> Dict[str, np.ndarray]:
+def draw_params(rng, B: int, n_ds: int, mosaic: bool, size: int = IMGSZ, scale: float = SCALE, translate: float = TRANSLATE, hsv=HSV,
+                fliplr: float = FLIPLR) -> Dict[str, np.ndarray]:
     """Mosaic centre and the three extra slices [UPSTREAM Mosaic], RandomPerspective's scale and translation (degrees / shear / perspective are 0 in
     the reference's runs), RandomHSV's gains, the flip decision [REF trains/Base/…/args.yaml:85-103]."""
     d: Dict[str, np.ndarray] = {}
@@ -317,13 +369,14 @@ def _random_affine(img, inst, dr, size, border):
 
 
 def warp_instances(inst, M, s, w, h):
-    """Polygons through the affine M, clipped to the output image, filtered by box_candidates on the scaled source box."""
+    """Polygons through the affine M, clipped to the box of their part inside the output image (`clip_polygons_to_image`), filtered by
+    box_candidates on the scaled source box."""
     inst = [(c, p) for c, p in inst if len(p)]
     if not inst:
         return []
     cls, pts, off = flatten_instances(inst)
     q = affine_points(pts, M[0, 0], M[0, 1], M[0, 2], M[1, 0], M[1, 1], M[1, 2])
-    q = np.clip(q, 0, [w - 1e-3, h - 1e-3]).astype(np.float32)
+    q = clip_polygons_to_image(q, off, w, h)
     keep = box_candidates(poly_bboxes(pts, off) * np.float32(s), poly_bboxes(q, off))
     return [(c, q[off[i] : off[i + 1]]) for i, (c, _) in enumerate(inst) if keep[i]]
 

@@ -55,17 +55,19 @@ def match_batch(iou: torch.Tensor, same: torch.Tensor) -> torch.Tensor:
     among the pairs above the threshold, then every ground truth keeps the LOWEST-index prediction among those that chose it (the order
     `np.unique` leaves behind in upstream's match_predictions) — one transfer per batch instead of seven per image."""
     B, G, P = iou.shape
-    thr = torch.as_tensor(IOUV, dtype=iou.dtype, device=iou.device).view(1, -1, 1, 1)
-    x = (iou * same).unsqueeze(1)                                   # [B,1,G,P]
-    ok = x >= thr                                                   # [B,T,G,P]
-    masked = torch.where(ok, x, torch.full_like(x, -1.0))
-    best_g = masked.argmax(2)                                       # [B,T,P] best gt of every prediction
-    has = ok.any(2)                                                 # [B,T,P]
-    chose = torch.zeros_like(ok).scatter_(2, best_g.unsqueeze(2), has.unsqueeze(2))  # [B,T,G,P]: prediction p chose gt g
-    idx = torch.arange(P, device=iou.device).view(1, 1, 1, P).expand_as(chose)
-    first_p = torch.where(chose, idx, torch.full_like(idx, P)).amin(3)              # [B,T,G] lowest prediction index per gt
+    x = iou * same                                                  # [B,G,P]
+    idx = torch.arange(P, dtype=torch.int32, device=iou.device).view(1, 1, P)
+    big = torch.full((1, 1, 1), P, dtype=torch.int32, device=iou.device)
     correct = torch.zeros(B, len(IOUV), P + 1, dtype=torch.bool, device=iou.device)
-    correct.scatter_(2, first_p, torch.ones_like(first_p, dtype=torch.bool))
+    one = torch.ones(B, G, dtype=torch.bool, device=iou.device)
+    for t, thr in enumerate(IOUV):  # one threshold at a time: the [B,10,G,P] temporaries of a 128-slice batch with 300 detections were ~1 GB
+        ok = x >= float(torch.tensor(thr, dtype=iou.dtype))           # the threshold rounded to the IoU dtype, as the broadcast compare did
+        masked = torch.where(ok, x, torch.full_like(x, -1.0))
+        best_g = masked.argmax(1)                                   # [B,P] best gt of every prediction
+        has = ok.any(1)                                             # [B,P]
+        chose = torch.zeros_like(ok).scatter_(1, best_g.unsqueeze(1), has.unsqueeze(1))  # [B,G,P]: prediction p chose gt g
+        first_p = torch.where(chose, idx, big).amin(2)              # [B,G] lowest prediction index per gt
+        correct[:, t].scatter_(1, first_p.long(), one)
     return correct[:, :, :P].permute(0, 2, 1)
 
 
@@ -118,7 +120,9 @@ def fitness(box: Tuple[float, float, float, float], mask: Tuple[float, float, fl
 
 
 class SegStats:
-    """Accumulates per-image matches; `result()` → dict of the eight metric columns + fitness."""
+    """Accumulates per-image matches; `result()` → dict of the eight metric columns + fitness.  Every image's rows carry the image's index in
+    the fold (`first_id` of add_batch), so that the parts several ranks collected over disjoint batches (`export`) merge into exactly the lists a
+    single rank walking the fold in order would hold (`merged`): sharded validation changes who computes, not what is scored."""
 
     def __init__(self):
         self.tp_b: List[np.ndarray] = []
@@ -126,13 +130,35 @@ class SegStats:
         self.conf: List[np.ndarray] = []
         self.pcls: List[np.ndarray] = []
         self.tcls: List[np.ndarray] = []
+        self.pids: List[int] = []  # image index of every entry of tp_b / tp_m / conf / pcls
+        self.tids: List[int] = []  # image index of every entry of tcls
+        self._next = 0
+
+    def export(self) -> Dict[str, list]:
+        return {"tp_b": self.tp_b, "tp_m": self.tp_m, "conf": self.conf, "pcls": self.pcls, "tcls": self.tcls, "pids": self.pids, "tids": self.tids}
+
+    @classmethod
+    def merged(cls, parts: List[Dict[str, list]]) -> "SegStats":
+        out = cls()
+        pred = sorted(((pid, k, j) for k, part in enumerate(parts) for j, pid in enumerate(part["pids"])))
+        for pid, k, j in pred:
+            for f in ("tp_b", "tp_m", "conf", "pcls"):
+                getattr(out, f).append(parts[k][f][j])
+            out.pids.append(pid)
+        for tid, k, j in sorted(((tid, k, j) for k, part in enumerate(parts) for j, tid in enumerate(part["tids"]))):
+            out.tcls.append(parts[k]["tcls"][j])
+            out.tids.append(tid)
+        return out
 
     def add_image(self, pred_boxes, pred_conf, pred_cls, pred_masks, gt_boxes, gt_cls, gt_masks) -> None:
         """pred_boxes [n,4] xyxy px, pred_masks [n,P] {0,1}; gt_boxes [m,4] xyxy px, gt_masks [m,P] {0,1} (same pixel grid)."""
         n, m = pred_boxes.shape[0], gt_boxes.shape[0]
         self.tcls.append(gt_cls.cpu().numpy().astype(np.int64))
+        self.tids.append(self._next)
+        self._next += 1
         if n == 0:
             return
+        self.pids.append(self._next - 1)
         if m:
             cb = match_predictions(pred_cls, gt_cls, box_iou(gt_boxes, pred_boxes))
             cm = match_predictions(pred_cls, gt_cls, mask_iou(gt_masks, pred_masks))
@@ -143,7 +169,7 @@ class SegStats:
         self.conf.append(pred_conf.cpu().numpy())
         self.pcls.append(pred_cls.cpu().numpy().astype(np.int64))
 
-    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts=None) -> None:
+    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts=None, first_id=None) -> None:
         """A whole batch at once, matched on the device (`match_batch`): pred_* [B,P,…] with the first n_pred[b] rows valid, gt_* [B,G,…] with the
         first n_gt[b] rows valid; masks as [B,·,pixels] {0,1} floats on one pixel grid — or `mask_counts` = (intersection [B,P,G], prediction
         areas [B,P], ground-truth areas [B,G]) as MSL_OP_MASK_IOU counts them, in which case no mask tensor is needed."""
@@ -171,9 +197,13 @@ class SegStats:
             cb = cm = torch.zeros(B, P, len(IOUV), dtype=torch.bool, device=dev)
         cb, cm, conf, pcls, pvh = cb.cpu().numpy(), cm.cpu().numpy(), pred_conf.cpu().numpy(), pred_cls.cpu().numpy(), pv.cpu().numpy()
         gvh, tcls = gv.cpu().numpy(), gt_cls.cpu().numpy()
+        first = self._next if first_id is None else int(first_id)
+        self._next = first + B
         for b in range(B):
             self.tcls.append(tcls[b][gvh[b]].astype(np.int64))
+            self.tids.append(first + b)
             if pvh[b].any():
+                self.pids.append(first + b)
                 self.tp_b.append(cb[b][pvh[b]])
                 self.tp_m.append(cm[b][pvh[b]])
                 self.conf.append(conf[b][pvh[b]])

@@ -22,6 +22,7 @@ from __future__ import annotations
 import csv
 import math
 import os
+import shutil
 import struct
 import threading
 import time
@@ -36,7 +37,7 @@ import yaml
 from . import data as D
 from . import hiplib, params
 from .hiplib import MSL_BF16, MSL_F32
-from .loss import segmentation_loss
+from .loss import GAIN_BOX, GAIN_CLS, GAIN_DFL, segmentation_loss
 from .segloss import SegLossOp, device_targets, pack_targets
 from .trainprog import ParamStore, TrainPlan
 
@@ -105,6 +106,68 @@ def allreduce_gradients(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def gather_objects(obj, world: int):
+    """[obj of rank 0, …, obj of rank world-1] on every rank (small host-side records: validation statistics).  Not on the training data path."""
+    if world <= 1:
+        return [obj]
+    out = [None] * world
+    torch.distributed.all_gather_object(out, obj)
+    return out
+
+
+def val_batches(n: int, batch: int, world: int):
+    """[(first, last+1)] slice ranges of the validation batches.  One rank: batches of min(batch, 128) in fold order.  Several ranks: the SAME
+    boundaries while there are at least `world` of them (rank r takes every world-th batch, so every per-batch loss is the number a single rank
+    computes), smaller equal batches once the fold is too short to give every rank one."""
+    vb = min(batch, 128)
+    if world > 1 and math.ceil(n / vb) < world:
+        vb = max(math.ceil(n / world), 1)
+    return [(b0, min(b0 + vb, n)) for b0 in range(0, n, vb)]
+
+
+class CheckpointWriter:
+    """last.pt / best.pt off the training stream: the EMA buffers are copied into pinned host memory by an asynchronous copy on the caller's
+    stream, a thread waits for that copy and writes the files while the next epoch's steps are already queued.  One write in flight; `wait()`
+    before the files are read (end of fit) — it re-raises what the thread caught."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        st = trainer.store
+        self.hp = torch.empty(st.p.numel(), dtype=torch.float32).pin_memory()
+        self.hb = torch.empty(st.b.numel(), dtype=torch.float32).pin_memory()
+        self.thread, self.error = None, None
+
+    def wait(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise RuntimeError(f"checkpoint writer failed: {e!r}") from e
+
+    def submit(self, extra: dict, is_best: bool):
+        self.wait()
+        tr = self.tr
+        self.hp.copy_(tr.ema_p, non_blocking=True)
+        self.hb.copy_(tr.ema_b, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(tr.device))
+
+        def work():
+            try:
+                ev.synchronize()
+                sd = tr.store.state_dict(p=self.hp, b=self.hb)
+                last, best = tr.wdir / "last.pt", tr.wdir / "best.pt"
+                params.save_checkpoint(last, sd, tr.store.scale, tr.nc, tr.names, extra)
+                if is_best:
+                    shutil.copyfile(last, best)  # the same bytes: one serialisation per epoch
+            except BaseException as e:  # surfaced by wait()
+                self.error = e
+
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+
 class Trainer:
     def __init__(self, yolo, data=None, epochs: int = 100, batch: int = -1, cache: bool = True, project=None, name: str = "train",
                  verbose: bool = False, dataset=None, val_dataset=None, max_iters: Optional[int] = None, replica: bool = False, **overrides):
@@ -124,7 +187,7 @@ class Trainer:
         if self.world > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.distributed.init_process_group("nccl", device_id=self.device)
-        self.yolo_device = str(self.device)
+        self.yolo.device = str(self.device)  # predict()/val() after fit() run where the training ran (one process per GPU: never all on cuda:0)
         # ---- data
         self.names, self.nc = {0: "lesion"}, 1
         if dataset is None:
@@ -140,7 +203,7 @@ class Trainer:
         # the slice cache of `cache=True` lives in HBM and batches are augmented there (augment.py); device_augment=False keeps the NumPy path of data.py
         self.aug = self.val_aug = None
         self._aug_stream = None
-        self._val_engine, self._val_loss_ops = None, None
+        self._val_engine, self._val_loss_ops, self._ckpt = None, None, None
         if self.hyp["device_augment"]:
             from .augment import DeviceAugmenter, SliceCache
 
@@ -352,7 +415,13 @@ class Trainer:
         the validator runs the EMA model in eval mode (running BatchNorm statistics), accumulates v8SegmentationLoss on its raw head outputs for
         the val/* columns and scores NMS(conf 0.001, IoU 0.7, max_det 300) detections for box/mask P, R, mAP50, mAP50-95].  Masks are compared at
         prototype resolution like upstream's default `process_mask`.  `val_max` (not a reference setting) bounds the slices for quick runs and
-        is recorded in args.yaml."""
+        is recorded in args.yaml.
+
+        **Sharded over ranks** (every rank calls this): the batches of `val_batches` are dealt round-robin, each rank scores its own, one
+        all-gather of the small host-side records (per-image match rows, per-batch loss items) rebuilds on every rank exactly the lists a single
+        rank would hold — ultralytics validates on rank 0 alone, which at this trainer's step rate would leave N-1 GPUs idle for a time
+        comparable to the epoch's training steps (0.3 s of 0.7 s on one GPU).  Eval-mode outputs do not depend on what else is in the batch, so
+        the metrics equal the single-rank run's (tests/test_gpu_ddp_rehearsal.py)."""
         from . import metrics as MT
         from .engine import InferEngine
 
@@ -368,10 +437,12 @@ class Trainer:
             self._val_engine.refresh(sd)
         eng, loss_ops = self._val_engine, self._val_loss_ops
         stats = MT.SegStats()
-        vb = min(self.batch, 128)
-        tot, nbat = np.zeros(4), 0
-        for b0 in range(0, limit, vb):
-            idx = list(range(b0, min(b0 + vb, limit)))
+        bounds = val_batches(limit, self.batch, self.world)
+        mine = list(range(self.rank, len(bounds), self.world))
+        items = torch.zeros(max(len(mine), 1), 4, dtype=torch.float32, device=self.device)  # per-batch loss items, one transfer at the end
+        for k, bi in enumerate(mine):
+            b0, b1 = bounds[bi]
+            idx = list(range(b0, b1))
             nb_ = len(idx)
             plan = eng.plan(nb_, S, S)  # validation slices are letterboxed RGB at the training size: no LetterBox pass
             if self.val_aug is not None:
@@ -386,8 +457,7 @@ class Trainer:
             if nb_ not in loss_ops:
                 lv = [plan.builder.levels[i] for i in sorted(plan.builder.levels)]
                 loss_ops[nb_] = SegLossOp(lv, lv, plan.proto, plan.proto, self.nc, S, S, self.dtype, self.device)  # no_grad: the gradient views are never written
-            tot += loss_ops[nb_](gt, masks_d, no_grad=True)[:4].cpu().numpy()
-            nbat += 1
+            items[k].copy_(loss_ops[nb_](gt, masks_d, no_grad=True)[:4])
             # metrics: mask areas / intersections counted by MSL_OP_MASK_IOU from the low-res logits, the whole batch matched on the device
             # (metrics.SegStats.add_batch), one transfer per batch
             mh, mw = plan.proto.H, plan.proto.W
@@ -403,25 +473,46 @@ class Trainer:
                                                                              inter.data_ptr(), parea.data_ptr(), garea.data_ptr()),
                                              i={0: nb_, 1: mh, 2: mw, 3: G, 7: det.shape[1], 8: S, 9: S}), torch.cuda.current_stream(self.device).cuda_stream)
                 counts = (inter, parea, garea)
-            stats.add_batch(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt, mask_counts=counts)
-        return tot / max(nbat, 1), stats.result()
+            stats.add_batch(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt, mask_counts=counts,
+                            first_id=b0)
+        mine_items = items[: len(mine)].cpu().numpy().astype(np.float64)
+        parts = gather_objects({"batches": mine, "items": mine_items, "stats": stats.export()}, self.world)
+        per_batch = np.zeros((len(bounds), 4))
+        for part in parts:
+            for bi, it in zip(part["batches"], part["items"]):
+                per_batch[bi] = it
+        tot = np.zeros(4)
+        for bi in range(len(bounds)):  # summed in fold order whatever rank computed the batch
+            tot += per_batch[bi]
+        allstats = stats if self.world == 1 else MT.SegStats.merged([part["stats"] for part in parts])
+        return tot / max(len(bounds), 1), allstats.result()
 
     # ------------------------------------------------------------------ files
     def _save(self, epoch: int, fitness: float) -> None:
-        sd = self.store.state_dict(p=self.ema_p, b=self.ema_b)
+        """last.pt every epoch, best.pt when the fitness improved [UPSTREAM BaseTrainer.save_model] — written by the CheckpointWriter thread from
+        a pinned-host snapshot of the EMA buffers, so the training stream only pays for the 11 MB device-to-host copy."""
+        is_best = self.best_fitness is None or fitness >= self.best_fitness
+        if is_best:
+            self.best_fitness = fitness
         extra = {"epoch": epoch, "best_fitness": self.best_fitness, "train_args": {"data": self.data_path, "epochs": self.epochs, "batch": self.batch,
                                                                                      "imgsz": self.hyp["imgsz"], "optimizer": self.optimizer, "lr0": self.lr0}}
-        params.save_checkpoint(self.wdir / "last.pt", sd, self.store.scale, self.nc, self.names, extra)
-        if self.best_fitness is None or fitness >= self.best_fitness:
-            self.best_fitness = fitness
-            params.save_checkpoint(self.wdir / "best.pt", sd, self.store.scale, self.nc, self.names, extra)
+        if self._ckpt is None:
+            self._ckpt = CheckpointWriter(self)
+        self._ckpt.submit(extra, is_best)
 
     def _write_args(self) -> None:
+        """args.yaml with the reference's keys and value types [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/args.yaml]: `optimizer` is what
+        was asked for ('auto' unless overridden), `amp` a boolean; what this trainer resolved them to sits beside them (optimizer_resolved, amp_dtype)."""
+        h = self.hyp
         args = dict(task="segment", mode="train", model=str(self.yolo.ckpt_path), data=self.data_path, epochs=self.epochs, batch=self.batch,
-                    imgsz=self.hyp["imgsz"], cache=True, optimizer="auto", seed=self.hyp["seed"], amp="bf16" if self.dtype == MSL_BF16 else False,
-                    lr0=self.lr0, lrf=self.hyp["lrf"], weight_decay=self.hyp["weight_decay"], warmup_epochs=self.hyp["warmup_epochs"], nbs=self.hyp["nbs"],
-                    close_mosaic=self.hyp["close_mosaic"], box=7.5, cls=0.5, dfl=1.5, overlap_mask=True, mask_ratio=4, world_size=self.world, val_max=self.hyp.get("val_max"),
-                    save_dir=str(self.save_dir))
+                    imgsz=h["imgsz"], cache=True, optimizer=h.get("optimizer") or "auto", seed=h["seed"], amp=self.dtype == MSL_BF16,
+                    lr0=self.lr0, lrf=h["lrf"], momentum=h["momentum"], weight_decay=h["weight_decay"], warmup_epochs=h["warmup_epochs"],
+                    warmup_momentum=h["warmup_momentum"], warmup_bias_lr=h["warmup_bias_lr"], nbs=h["nbs"],
+                    close_mosaic=h["close_mosaic"], box=GAIN_BOX, cls=GAIN_CLS, dfl=GAIN_DFL, overlap_mask=True, mask_ratio=4,
+                    hsv_h=D.HSV[0], hsv_s=D.HSV[1], hsv_v=D.HSV[2], translate=D.TRANSLATE, scale=D.SCALE, fliplr=D.FLIPLR, mosaic=1.0 if h["augment"] else 0.0,
+                    # not reference keys: what this trainer resolved / added
+                    optimizer_resolved=self.optimizer, amp_dtype="bf16" if self.dtype == MSL_BF16 else "fp32", device_augment=bool(h["device_augment"]),
+                    world_size=self.world, val_max=h.get("val_max"), save_dir=str(self.save_dir))
         (self.save_dir / "args.yaml").write_text(yaml.safe_dump(args, sort_keys=False))
 
     # ------------------------------------------------------------------ main loop
@@ -432,8 +523,10 @@ class Trainer:
             with open(self.save_dir / "results.csv", "w", newline="") as f:
                 csv.writer(f).writerow(RESULT_COLUMNS)
         self.store.g.zero_()
+        self.epoch_times = []  # per epoch: seconds of train steps / validation / checkpoint hand-off on this rank (bench.py --mode fit-epoch)
         ni, last_opt, done = 0, -1, False
         for epoch in range(self.epochs):
+            te0 = time.perf_counter()
             tl_dev, nb_seen = torch.zeros(4, dtype=torch.float32, device=self.device), 0  # summed on the device: no host sync inside the epoch
             lr = self.sched.lr(ni, epoch)
             for batch in self._batches(epoch):
@@ -450,19 +543,24 @@ class Trainer:
                     done = True
                     break
             tl = tl_dev.cpu().numpy().astype(np.float64) / max(nb_seen, 1)
-            vl, mets = self._validate() if self.rank == 0 else (np.zeros(4), None)  # rank 0 validates; the others meet it again at the next all-reduce
+            te1 = time.perf_counter()
+            vl, mets = self._validate()  # every rank scores its share of the held-out fold
+            te2 = time.perf_counter()
             fitness = mets["fitness"] if mets else -float(tl.sum())
             if self.rank == 0:
-                mcols = [round(float(mets[c]), 5) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
-                row = [epoch + 1, round(time.time() - self.t0, 4)] + [round(float(x), 5) for x in tl] + mcols + [round(float(x), 5) for x in vl] + [lr] * 3
+                mcols = [float(mets[c]) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
+                row = [epoch + 1, time.time() - self.t0] + [float(x) for x in tl] + mcols + [float(x) for x in vl] + [lr] * 3
                 with open(self.save_dir / "results.csv", "a", newline="") as f:
-                    csv.writer(f).writerow(row)
+                    f.write(",".join([str(row[0])] + [f"{v:.6g}" for v in row[1:]]) + "\n")  # six significant digits, as the reference's files carry
                 self._save(epoch, fitness)
                 if self.verbose:
                     print(f"epoch {epoch + 1}/{self.epochs} train {tl.round(4)} val {vl.round(4)} lr {lr:.6g}", flush=True)
+            self.epoch_times.append({"train_s": te1 - te0, "val_s": te2 - te1, "ckpt_s": time.perf_counter() - te2, "iterations": nb_seen})
             if done:
                 break
         torch.cuda.synchronize(self.device)
+        if self._ckpt is not None:
+            self._ckpt.wait()
         if self.world > 1:
             torch.distributed.barrier()
         # the best checkpoint becomes the model's weights, like ultralytics' trainer reloads best.pt into the YOLO object after training

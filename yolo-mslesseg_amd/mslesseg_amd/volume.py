@@ -12,6 +12,7 @@ GT affine, as `guardar_volumen` writes them [REF utils/utils.py:153-180].
 from __future__ import annotations
 
 import gzip
+import logging
 import struct
 from pathlib import Path
 from typing import Dict, Iterable, Optional, Sequence, Tuple
@@ -21,6 +22,8 @@ import torch
 
 from . import hiplib
 from .hiplib import MSL_F32
+
+LOGGER = logging.getLogger("ultralytics")  # the logger the reference silences / reads [REF scripts/train.py:78]
 
 PLANE_AXIS = {"axial": 2, "coronal": 1, "sagital": 0}
 _GRAY_LUT = (np.linspace(0, 1, 256) * 255).astype(np.uint8)  # matplotlib cm.gray(bytes=True): truncation, 24 entries one below
@@ -88,7 +91,7 @@ def take_slice(vol: np.ndarray, plano: str, i: int) -> np.ndarray:
 
 
 def lesion_slices(mask: np.ndarray, plano: str) -> list:
-    """Indices of the slices of `plano` whose GT mask holds a lesion voxel [REF utils/Paciente.py:267-279 indices_cortes_con_lesion]."""
+    """Indices of the slices of `plano` whose GT mask holds a lesion voxel [REF utils/Paciente.py:252-259 indices_cortes_con_lesion]."""
     ax = PLANE_AXIS[plano]
     other = tuple(a for a in range(3) if a != ax)
     return np.nonzero((np.asarray(mask) > 0).any(axis=other))[0].astype(int).tolist()
@@ -97,7 +100,7 @@ def lesion_slices(mask: np.ndarray, plano: str) -> list:
 def select_slices(mask: np.ndarray, plano: str, num_cortes: Optional[int] = None) -> list:
     """The slice set the reference's dataset stage writes and its predict stage therefore reads (the predict loop globs the PNGs that exist
     [REF scripts/generar_predicciones.py:205-222]): every lesion-bearing slice, or — when there are more than `num_cortes` — the
-    `num_cortes` central ones of that list [REF utils/Paciente.py:281-295 indices_a_usar]."""
+    `num_cortes` central ones of that list [REF utils/Paciente.py:261-275 indices_a_usar]."""
     valid = lesion_slices(mask, plano)
     if num_cortes is None or len(valid) <= num_cortes:
         return valid
@@ -198,7 +201,12 @@ def extract_slices(vol_dev: torch.Tensor, shape, plano: str, indices, mejora: Op
         _tables_cache[key] = torch.from_numpy(enhancement_tables()).to(dev)
     X, Y, Z = (int(d) for d in shape)
     axis = PLANE_AXIS[plano]
-    idx = torch.tensor([int(i) for i in indices], dtype=torch.int32, device=dev)
+    host_idx = [int(i) for i in indices]
+    if vol_dev.numel() != X * Y * Z or vol_dev.dtype != torch.float64:
+        raise ValueError(f"volumen en dispositivo {tuple(vol_dev.shape)} {vol_dev.dtype} no corresponde a {tuple(shape)} float64")
+    if any(i < 0 or i >= (X, Y, Z)[axis] for i in host_idx):  # checked on the host: the kernel trusts its indices
+        raise ValueError(f"Índice fuera de rango para plano {plano}.")
+    idx = torch.tensor(host_idx, dtype=torch.int32, device=dev)
     d0, d1 = expected_slice_shape(shape, plano)
     out = torch.empty((idx.numel(), d1, d0, 3), dtype=torch.uint8, device=dev)
     op = hiplib.make_op(hiplib.OP_SLICE_EXTRACT, MSL_F32, p=(vol_dev.data_ptr(), idx.data_ptr(), _tables_cache[key].data_ptr(), 0, out.data_ptr()),
@@ -245,13 +253,37 @@ def assign_variant_items(items: Sequence[Tuple], world: int) -> list:
     return [[order[j] for j in sorted(p)] for p in parts]
 
 
-def predict_variants(models: Dict[Optional[str], object], items: Sequence[Tuple], rank: Optional[int] = None, world: Optional[int] = None, batch: int = 128):
+def predict_patients(models: Dict[str, object], patients: Sequence[Tuple[str, np.ndarray]], umbral: int = 2, indices=None, strict: bool = False) -> Dict[str, Optional[Tuple]]:
+    """The per-patient loop around `predict_consensus`, with the reference's failure isolation: a patient whose volume cannot be processed (wrong
+    shape for the plane models, a non-finite FLAIR, a kernel error …) is logged and skipped, the others are still predicted
+    [REF scripts/generar_predicciones.py:289-301 `except Exception → logger.warning("… se omite") → continue`; reconstruir_volumen.py:297-306].
+    `patients`: (patient id, FLAIR volume) pairs → {patient id: (consensus, plane volumes) | None}.  `strict=True` re-raises instead."""
+    out: Dict[str, Optional[Tuple]] = {}
+    for pid, flair in patients:
+        try:
+            a = np.asarray(flair)
+            if a.ndim != 3:
+                raise ValueError(f"se esperaba un volumen 3D, se recibió {a.shape}")
+            out[pid] = predict_consensus(models, a, umbral, None if indices is None else indices.get(pid))
+        except Exception as e:  # noqa: BLE001 — the reference's own `except Exception` around a patient
+            if strict:
+                raise
+            LOGGER.warning(f"⚠️ Error generando predicciones de {pid}, se omite: {e}.")
+            out[pid] = None
+    return out
+
+
+def predict_variants(models: Dict[Optional[str], object], items: Sequence[Tuple], rank: Optional[int] = None, world: Optional[int] = None, batch: int = 128,
+                     strict: bool = False):
     """BASELINE configs[4]: inference over a mixed list of (flair volume, mejora, plano[, slice indices]) work items with one trained model per
     enhancement variant — the reference selects the weights by the variant's name (`trains/<mejora>/…/<plano>/fold<k>/weights/best.pt`
     [REF yolo_mslesseg/configs/ConfigPred.py:150-166]) and enhances every slice before it is rendered [REF utils/mejora_imagen.py:43-184,
     utils/Paciente.py:195-222].  `models` maps a variant (None, "HE", "CLAHE", "GC", "LT") — or a (variant, plano) pair — to a YOLO object.
     This rank's share (`assign_variant_items`) is grouped by variant so that each model's weights are used in consecutive whole-volume batches;
-    → list aligned with `items`: the plane volume (float32 {0,1}, device) for items of this rank, None for the others."""
+    → list aligned with `items`: the plane volume (float32 {0,1}, device) for items of this rank, None for the others.
+    An item that fails (no model for its variant, a volume of the wrong rank, a kernel error) is logged and left None like the reference's
+    per-patient `try / except → warning → continue` [REF scripts/generar_predicciones.py:289-301]; the rest of the rank's list is still predicted
+    (`strict=True` re-raises)."""
     import os
 
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
@@ -260,13 +292,21 @@ def predict_variants(models: Dict[Optional[str], object], items: Sequence[Tuple]
     for it in items:
         flair, mejora, plano = it[0], it[1], it[2]
         idx = list(it[3]) if len(it) > 3 and it[3] is not None else None
-        norm.append((flair, mejora, plano, len(idx) if idx is not None else flair.shape[PLANE_AXIS[plano]], idx))
+        n_sl = len(idx) if idx is not None else (np.shape(flair)[PLANE_AXIS[plano]] if np.ndim(flair) == 3 and plano in PLANE_AXIS else 1)
+        norm.append((flair, mejora, plano, n_sl, idx))
     mine = assign_variant_items(norm, world)[rank]
     out: list = [None] * len(items)
     for k in mine:  # already grouped: assign_variant_items keeps (variant, plane) order inside a rank's share
         flair, mejora, plano, _, idx = norm[k]
-        model = models.get((mejora, plano), models.get(mejora))
-        if model is None:
-            raise KeyError(f"no model for enhancement variant {mejora!r} (plane {plano})")
-        out[k] = predict_volume(model, flair, plano, idx, batch=batch, mejora=mejora)
+        try:
+            model = models.get((mejora, plano), models.get(mejora))
+            if model is None:
+                raise KeyError(f"no model for enhancement variant {mejora!r} (plane {plano})")
+            if np.ndim(flair) != 3:
+                raise ValueError(f"se esperaba un volumen 3D, se recibió {np.shape(flair)}")
+            out[k] = predict_volume(model, flair, plano, idx, batch=batch, mejora=mejora)
+        except Exception as e:  # noqa: BLE001
+            if strict:
+                raise
+            LOGGER.warning(f"⚠️ Error generando predicciones del elemento {k} ({mejora}, {plano}), se omite: {e}.")
     return out
