@@ -249,6 +249,27 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             return float(a_in + a_out * (2 if I[19] else 1))  # x and dz (fp32 dz: twice the bytes)
         return float(a_in + a_out * (2 if op.p[3] else 1))
 
+    def op_bytes(kind, op):
+        """Algorithmic HBM bytes of any op of the train programs: activation tensors it reads and writes, each once (weights, statistics and
+        scratch are noise beside them).  Elementwise ops: accesses x N*H*W*C*element size."""
+        I = op.i
+        if kind == hiplib.OP_CONV:
+            return conv_bytes(op)
+        if kind == hiplib.OP_CONV_WGRAD:
+            return conv_bytes(op, True)
+        t = float(I[0]) * I[1] * I[2] * I[3] * es
+        acc = {hiplib.OP_BN_ACT: 2 + (1 if op.p[3] else 0), hiplib.OP_BN_ACT_BWD_REDUCE: 2, hiplib.OP_BN_ACT_BWD_APPLY: 3, hiplib.OP_BN_STATS: 1, hiplib.OP_DWCONV: 2,
+               hiplib.OP_DW_WGRAD: 2, hiplib.OP_COLSUM: 1, hiplib.OP_ADD_VIEW: 3, hiplib.OP_UPSAMPLE2X: 5, hiplib.OP_UPSAMPLE2X_BWD: 5, hiplib.OP_SPPF_POOL: 4,
+               hiplib.OP_SPPF_POOL_BWD: 5}.get(kind)
+        if acc is not None:
+            return t * acc
+        if kind == hiplib.OP_STEM:
+            return float(I[0]) * I[1] * I[2] * 3 + float(I[0]) * I[4] * I[5] * I[6] * es
+        if kind == hiplib.OP_STEM_WGRAD:
+            return float(I[0]) * I[1] * I[2] * 3 + float(I[0]) * I[4] * I[5] * I[6] * es
+        return 0.0  # attention, loss, packing, drains: small tensors
+
+    step_bytes = sum(op_bytes(kind, it) for tag, what, kind, ms, it in rows if what == "op")
     wg_ms, wg_fl, cv_ms, cv_fl = 0.0, 0.0, 0.0, 0.0
     cands = []  # every MFMA launch as (ms, flops, kernel label, dtype, tag, op); the top 3 by time are replayed for PMC
     for tag, what, kind, ms, it in rows:
@@ -307,7 +328,11 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
             "all_conv_fwd_dgrad": {"tflops": round(cv_fl / (cv_ms * 1e-3) / 1e12, 2), "frac": round(cv_fl / (cv_ms * 1e-3) / 1e12 / PEAK[args.dtype], 4), "ms": round(cv_ms, 3)},
             "program_ms": {"total_fwd_bwd_pack": round(total, 3),
                            **{f"{t}:{names.get(k, 'torch-attention')}": round(v, 3) for (t, k), v in sorted(by_kind.items(), key=lambda x: -x[1])[:14]}},
-            "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP[args.scale] * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4)}
+            "whole_step_frac_of_bf16_mfma_roof": round(value_per_gpu * 3 * FWD_GFLOP[args.scale] * (args.size * args.size / 640.0 / 640.0) / 1e3 / PEAK["bf16"], 4),
+            # the whole step against the HBM roof: algorithmic bytes of every op of the forward + backward programs (each activation tensor an op reads or
+            # writes, once) over the measured step time
+            "step_bytes": round(step_bytes), "step_hbm_gbs": round(step_bytes / (tr.batch / value_per_gpu) / 1e9, 1),
+            "step_hbm_frac": round(step_bytes / (tr.batch / value_per_gpu) / 1e9 / PEAK_HBM_GBS, 4)}
     def shape_of(o):
         J = o.i
         return {"N": J[0], "H": J[1], "W": J[2], "Cin": J[3], "Ho": J[4], "Wo": J[5], "Cout": J[6], "k": J[7], "stride": J[8]}
@@ -322,6 +347,15 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
                     roof["mfma_util"] = round(rec["mfma_util"], 4)
                     roof["mfma_util_counters"] = {k: rec["sq"][k] for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "kernel_cycles") if k in rec["sq"]}
                 roof["traffic_source"] = "profiles/pmc_latest.json: a committed rocprofv3 --pmc summary of an earlier run of this kernel and shape (scripts/pmc_traffic.py), not collected in this run"
+    ins = ROOT / "profiles" / "in_stream_latest.json"  # scripts/in_stream.py: the same launch inside whole steps (rocprofv3 --kernel-trace), not replayed alone
+    if ins.exists():
+        for rec in json.loads(ins.read_text()).get("records", []):
+            if rec.get("kernel") == kname and rec.get("launch_shape") == roof["launch_shape"]:
+                roof["launch_ms_in_stream"] = rec["launch_ms_in_stream"]
+                a_in = (by / (rec["launch_ms_in_stream"] * 1e-3) / 1e9) if hbm_bound else (fl / (rec["launch_ms_in_stream"] * 1e-3) / 1e12)
+                roof["frac_in_stream"] = round(a_in / (PEAK_HBM_GBS if hbm_bound else peak), 4)
+                roof["in_stream_source"] = ("profiles/in_stream_latest.json: mean duration of this launch in a committed rocprofv3 --kernel-trace of whole steps, where the "
+                                            "deferred weight-gradient lanes and the head lanes share the device with it; `launch_ms` / `frac` are the launch replayed alone")
     if args.replay_dominant > 0:  # for the PMC passes: the three longest MFMA launches, each alone and back to back, as the LAST dispatches of the process
         s_ = torch.cuda.current_stream(tr.device).cuda_stream
         torch.cuda.synchronize(tr.device)
@@ -452,6 +486,38 @@ def volume_plane_bench(eng, dev):
     res["patient_three_planes_consensus_dice"] = {"ms_per_patient": round(dt3 * 1e3, 2), "slices": 582, "slices_per_s": round(582 / dt3, 1),
                                                   "note": "BASELINE configs[3]: 3 x (upload + extract + predict + insert) + consensus + Dice on the device, from the host volume"}
     return res
+
+
+def batch1_latency(eng, state, host, dev, args):
+    """The call an UNMODIFIED reference makes: one slice per `modelo(img, verbose=False)[0]`, then `.masks.data.cpu().numpy()`
+    [REF scripts/generar_predicciones.py:114-120] — batch 1, fp32 (the predict default), host array in, host masks out.  Also the engine's batch-1
+    path that stops at the merged uint8 slice (what `predict_slices` returns), eager and as a hipGraph replay of the network program."""
+    y = bench_model(args, dev, state)
+    y.dtype = eng.dtype
+    y._engine = eng
+    n = min(len(host), 32)
+    for i in range(3):
+        r = y(host[i], verbose=False)[0]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kept = 0
+    for i in range(n):
+        r = y(host[i], verbose=False)[0]
+        if r.masks is not None:
+            kept += r.masks.data.cpu().numpy().shape[0]
+    call_ms = (time.perf_counter() - t0) / n * 1e3
+    out = {"reference_call_ms_per_slice": round(call_ms, 3), "reference_call_slices_per_s": round(1e3 / call_ms, 1), "mean_instances": round(kept / n, 1),
+           "note": "model(img, verbose=False)[0].masks.data.cpu().numpy() per slice, batch 1, fp32, 640x640 synthetic slices; engine_*: LetterBox + net + NMS + "
+                   "masks + merge + D2H of the merged uint8 slice per slice"}
+    for name, replay in (("engine_eager_ms_per_slice", False), ("engine_hipgraph_ms_per_slice", True)):
+        for i in range(3):
+            eng.predict_slices(torch.from_numpy(host[i : i + 1]), graph_replay=replay).cpu()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            eng.predict_slices(torch.from_numpy(host[i : i + 1]), graph_replay=replay).cpu()
+        out[name] = round((time.perf_counter() - t0) / n * 1e3, 3)
+    return out
 
 
 class RepeatDataset:
@@ -673,6 +739,8 @@ def main():
                                           "mean_kept_instances_per_slice": round(float(eng.plan(128, S, S).keep_cnt.float().mean().item()), 1),
                                           "parity": ("exact vs the CPU oracle (north_star tolerance met)" if pdt == "fp32" else
                                                      "throughput mode: |dDice| <= 1e-3 per plane volume, not at the 1e-4 tolerance")}
+                    if pdt == "fp32":
+                        line["infer"]["batch1"] = batch1_latency(eng, pstate, host, dev, args)
                     del eng, imgs
                     torch.cuda.empty_cache()
     elif args.mode == "fit-epoch":

@@ -26,8 +26,9 @@
  *       base + ((n*H + y)*W + x)*cs + co + c        (cs = channel stride of the underlying buffer,
  *                                                    co = channel offset of this view inside it)
  *     so a Concat is just several producers writing different `co` of one buffer.
- *   - dtype: MSL_BF16 (bf16 storage, fp32 accumulate on v_mfma_f32_16x16x32_bf16) or
- *            MSL_F32  (fp32 storage, exact fp32 on v_mfma_f32_16x16x4_f32 — the parity mode).
+ *   - dtype: MSL_BF16 (bf16 storage, fp32 accumulate on v_mfma_f32_16x16x32_bf16),
+ *            MSL_F32  (fp32 storage, exact fp32 on v_mfma_f32_16x16x4_f32 — the parity mode) or
+ *            MSL_F32S (fp32 storage, split-precision conv products on the f16 matrix cores — predict only).
  */
 #ifndef MSLESSEG_HIP_H
 #define MSLESSEG_HIP_H
@@ -40,7 +41,11 @@ extern "C" {
 
 #define MSL_ABI_VERSION 1
 
-enum { MSL_BF16 = 0, MSL_F32 = 1 };
+enum { MSL_BF16 = 0, MSL_F32 = 1,
+       MSL_F32S = 2 /* fp32 tensors like MSL_F32, but MSL_OP_CONV takes every product as three f16 partial products (operands split hi + lo: 21-22 bits
+                       each, fp32 accumulate) on v_mfma_f32_16x16x16_f16 — 1e-6-grade instead of exact fp32, several times the fp32 matrix rate.  Conv
+                       weights must be packed pre-split: every 16-byte unit of four fp32 values rewritten as (hi f16 x 4 | lo f16 x 4), hi = f16(w),
+                       lo = f16(w - hi) (mslesseg_amd.engine.split_f16_units).  Every other op kind treats it as MSL_F32. */ };
 
 enum {
   MSL_OK = 0,
@@ -250,6 +255,33 @@ int msl_letterbox_u8(const uint8_t* src, const int32_t* xtab, const int32_t* yta
 int msl_nms(const float* pred, int32_t* keep_idx, int32_t* keep_cnt, float* det, int32_t N, int32_t A, int32_t max_det, float conf_thres, float iou_thres, void* stream);
 int msl_volume_consensus(const float* axial, const float* coronal, const float* sagital, uint8_t* out, int64_t voxels, int32_t umbral, void* stream);
 int msl_volume_dice_sums(const uint8_t* gt, const uint8_t* pred, uint64_t* sums3, int64_t voxels, void* stream);
+
+/* ---- Typed entry points of the TRAINING leg: what ultralytics' trainer computes under model.train(...) [REF yolo_mslesseg/scripts/train.py:358-366],
+ * one call per step of a train-mode Conv (Conv2d → BatchNorm2d(batch statistics) → SiLU), its backward, the loss and the optimizer — callable without
+ * knowing the descriptor slots.  Dense NHWC tensors (channel stride = channel count) in `dtype` (MSL_BF16 | MSL_F32) unless said otherwise.
+ *
+ * msl_conv2d_wgrad_nhwc: dw[co][ky][kx][ci] += sum over pixels of dz[p][co] * x[pix(p, ky, kx)][ci] — the weight gradient of Conv2d (k 1 | 3, pad k/2,
+ *   stride 1 | 2) or of ConvTranspose2d(2, 2) (k 2, stride 2, pad 0, operands swapped by the caller); dw fp32, ACCUMULATED (zero it first);
+ *   scratch (optional, fp32 [scratch_floats]): per-workgroup partial sums + one reduction instead of atomics.
+ * msl_bn_act_fwd: train-mode BatchNorm2d + SiLU: y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ res) with the BATCH statistics of z
+ *   [UPSTREAM nn.BatchNorm2d(eps 1e-3, momentum 0.03) inside ultralytics' Conv]; stats fp32 [2C] receives (mean, 1/sqrt(var + eps)) for the backward;
+ *   running_mean / running_var (one allocation, variance after mean; or both NULL) are updated with `momentum` (unbiased variance);
+ *   acc: fp64 [8][2C] scratch (zeroed here).
+ * msl_bn_act_bwd: the backward of the same: dz, dgamma [C], dbeta [C] (dbeta must follow dgamma in one allocation) from dy, z and the saved stats.
+ * msl_seg_loss: v8SegmentationLoss + its gradient (MSL_OP_SEG_LOSS; level_table as documented there, prototypes dense [B][mh][mw][32]);
+ *   workspace of msl_seg_loss_workspace(B, A, n_max) bytes; items fp32 [8] = box, seg, cls, dfl (gains applied), target-score sum, foreground count.
+ * msl_adamw: one AdamW step over a flat fp32 range [torch.optim.AdamW semantics: decoupled decay, bias correction by `step` >= 1]; clip_scale: device
+ *   float multiplied into the gradient (gradient clipping), or NULL. */
+int msl_conv2d_wgrad_nhwc(const void* x, const void* dz, float* dw, float* scratch, int64_t scratch_floats, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                          int32_t k, int32_t stride, int32_t dtype, void* stream);
+int msl_bn_act_fwd(const void* z, const float* gamma, const float* beta, const void* res, void* y, float* stats, double* acc, float* running_mean, float* running_var,
+                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t act_silu, float eps, float momentum, int32_t dtype, void* stream);
+int msl_bn_act_bwd(const void* dy, const void* z, const float* stats, const float* gamma, const float* beta, double* acc, void* dz, float* dgamma, float* dbeta,
+                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t act_silu, int32_t dtype, void* stream);
+int msl_seg_loss(const int64_t* level_table, int32_t nlev, const float* gt, const uint8_t* masks, const void* proto, void* gproto, void* workspace, float* items,
+                 int32_t B, int32_t A, int32_t nc, int32_t n_max, int32_t mh, int32_t mw, int32_t img_h, int32_t img_w, int32_t no_grad, int32_t dtype, void* stream);
+int msl_adamw(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+              const float* clip_scale, void* stream);
 
 /* Bytes of device workspace MSL_OP_SEG_LOSS needs for B slices, A anchors and at most n_max instances per slice (negative = error). */
 int64_t msl_seg_loss_workspace(int32_t B, int32_t A, int32_t n_max);

@@ -77,3 +77,21 @@ def test_device_tables_match_the_numpy_variants():
     for m in (1, 17, 128, 255):
         img = np.arange(m + 1, dtype=np.uint8).reshape(1, -1)  # uint8 input: normalizar_a_uint8 passes it through, max == m
         assert np.array_equal(lt[m][img], E.lt(img))
+
+
+def test_lt_of_an_all_zero_slice_is_zero_by_rule():
+    """LT on a slice of air (every voxel equal → normalizar_a_uint8 gives all zeros → max g = 0): the reference's expression is 255 / log(1) = inf,
+    inf * log(1) = NaN, NaN → uint8 [REF utils/mejora_imagen.py:176-182] — platform-defined, 0 on x86 NumPy.  Host function and device table emit
+    zeros explicitly, without evaluating the expression (no RuntimeWarning)."""
+    import warnings
+
+    from mslesseg_amd import enhance as E, volume as V
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for sl in (np.zeros((7, 9), np.float64), np.full((7, 9), 3.5), np.zeros((4, 4), np.uint8)):
+            out = E.lt(sl)
+            assert out.dtype == np.uint8 and out.shape == sl.shape and not out.any()
+        t = V.enhancement_tables()
+    assert not t[1024 : 1024 + 256].any()  # row 0 of the device's LT table
+    assert np.array_equal(E.aplicar_mejora(np.zeros((5, 5)), "LT"), np.zeros((5, 5), np.uint8))

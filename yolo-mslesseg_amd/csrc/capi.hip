@@ -1,4 +1,5 @@
 // extern "C" surface of libmslesseg_hip.so (include/mslesseg_hip.h): validation + dispatch only.
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -13,7 +14,12 @@ void msl_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static int dispatch(const msl_op& op, hipStream_t s) {
+static int dispatch(const msl_op& op_in, hipStream_t s) {
+  // MSL_F32S (fp32 tensors, split-precision conv products) is a mode of the convolutions only: every other op sees plain fp32
+  msl_op op_plain;
+  const msl_op* pop = &op_in;
+  if (op_in.dtype == MSL_F32S && op_in.kind != MSL_OP_CONV) { op_plain = op_in; op_plain.dtype = MSL_F32; pop = &op_plain; }
+  const msl_op& op = *pop;
   switch (op.kind) {
     case MSL_OP_CONV: return msl_launch_conv(op, s);
     case MSL_OP_STEM: return msl_launch_stem(op, s);
@@ -284,6 +290,97 @@ int msl_volume_dice_sums(const uint8_t* gt, const uint8_t* pred, uint64_t* sums3
   op.kind = MSL_OP_VOL_DICE; op.dtype = MSL_F32;
   op.p[0] = (void*)gt; op.p[1] = (void*)pred; op.p[4] = sums3;
   op.i[0] = (int32_t)(voxels & 0x7FFFFFFF); op.i[1] = (int32_t)(voxels >> 31);
+  return dispatch(op, (hipStream_t)stream);
+}
+
+// ---- typed entry points of the training leg [replaces what ultralytics' trainer runs under model.train(...), REF yolo_mslesseg/scripts/train.py:358-366]:
+// dense NHWC tensors (channel stride = channel count), device pointers, asynchronous on `stream`.
+static void dense4(msl_op& op, int N, int H, int W, int C) { op.i[0] = N; op.i[1] = H; op.i[2] = W; op.i[3] = C; }
+
+int msl_conv2d_wgrad_nhwc(const void* x, const void* dz, float* dw, float* scratch, int64_t scratch_floats, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                          int32_t k, int32_t stride, int32_t dtype, void* stream) {
+  if (!(k == 1 || k == 3 || (k == 2 && stride == 2))) { msl_set_error("msl_conv2d_wgrad_nhwc: k must be 1, 3 or (2 with stride 2)"); return MSL_EINVAL; }
+  if (stride != 1 && stride != 2) { msl_set_error("msl_conv2d_wgrad_nhwc: stride must be 1 or 2"); return MSL_EINVAL; }
+  if (scratch && (scratch_floats <= 0 || scratch_floats > 0x7FFFFFFF)) { msl_set_error("msl_conv2d_wgrad_nhwc: bad scratch size"); return MSL_EINVAL; }
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  const int pad = k == 3 ? 1 : 0;
+  op.kind = MSL_OP_CONV_WGRAD; op.dtype = dtype;
+  op.p[0] = (void*)x; op.p[1] = (void*)dz; op.p[4] = dw; op.p[5] = scratch;
+  dense4(op, N, H, W, Cin);
+  op.i[4] = (H + 2 * pad - k) / stride + 1; op.i[5] = (W + 2 * pad - k) / stride + 1; op.i[6] = Cout; op.i[7] = k; op.i[8] = stride; op.i[9] = pad;
+  op.i[10] = Cin; op.i[11] = 0; op.i[12] = Cout; op.i[13] = 0; op.i[21] = scratch ? (int32_t)scratch_floats : 0;
+  return dispatch(op, (hipStream_t)stream);
+}
+
+int msl_bn_act_fwd(const void* z, const float* gamma, const float* beta, const void* res, void* y, float* stats, double* acc, float* running_mean, float* running_var,
+                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t act_silu, float eps, float momentum, int32_t dtype, void* stream) {
+  if (!z || !gamma || !beta || !y || !stats || !acc) { msl_set_error("msl_bn_act_fwd: null pointer"); return MSL_EINVAL; }
+  if ((running_mean == nullptr) != (running_var == nullptr) || (running_mean && running_var <= running_mean)) {
+    msl_set_error("msl_bn_act_fwd: running_mean / running_var must both be given, variance after mean in one allocation"); return MSL_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  const int slots = 8;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * slots * 2 * (size_t)C, s);
+  if (e != hipSuccess) { msl_set_error("msl_bn_act_fwd: hipMemsetAsync: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  msl_op st;
+  memset(&st, 0, sizeof(st));
+  st.kind = MSL_OP_BN_STATS; st.dtype = dtype; st.p[0] = (void*)z; st.p[1] = acc;
+  dense4(st, N, H, W, C); st.i[10] = C; st.i[11] = 0; st.i[21] = slots;
+  int rc = dispatch(st, s);
+  if (rc) return rc;
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_BN_ACT; op.dtype = dtype;
+  op.p[0] = (void*)z; op.p[1] = stats; op.p[2] = (void*)gamma; op.p[3] = (void*)res; op.p[4] = y; op.p[5] = (void*)beta; op.p[6] = acc; op.p[7] = running_mean;
+  dense4(op, N, H, W, C);
+  op.i[10] = C; op.i[12] = C; op.i[14] = C; op.i[16] = running_mean ? (int32_t)(running_var - running_mean) : 0; op.i[18] = act_silu ? 1 : 0; op.i[21] = slots;
+  op.f[0] = eps; op.f[1] = momentum;
+  return dispatch(op, s);
+}
+
+int msl_bn_act_bwd(const void* dy, const void* z, const float* stats, const float* gamma, const float* beta, double* acc, void* dz, float* dgamma, float* dbeta,
+                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t act_silu, int32_t dtype, void* stream) {
+  if (!dy || !z || !stats || !gamma || !beta || !acc || !dz || !dgamma || !dbeta) { msl_set_error("msl_bn_act_bwd: null pointer"); return MSL_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  const int slots = 8;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * slots * 2 * (size_t)C, s);
+  if (e != hipSuccess) { msl_set_error("msl_bn_act_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return MSL_ELAUNCH; }
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_BN_ACT_BWD_REDUCE; op.dtype = dtype;
+  op.p[0] = (void*)dy; op.p[1] = (void*)z; op.p[2] = (void*)stats; op.p[3] = (void*)gamma; op.p[4] = (void*)beta; op.p[5] = acc;
+  dense4(op, N, H, W, C);
+  op.i[10] = C; op.i[12] = C; op.i[18] = act_silu ? 1 : 0; op.i[21] = slots;
+  int rc = dispatch(op, s);
+  if (rc) return rc;
+  op.kind = MSL_OP_BN_ACT_BWD_APPLY;
+  op.p[6] = dz; op.p[7] = dgamma;
+  op.i[14] = C; op.i[15] = 0; op.i[20] = (int32_t)(dbeta - dgamma);
+  return dispatch(op, s);
+}
+
+int msl_seg_loss(const int64_t* level_table, int32_t nlev, const float* gt, const uint8_t* masks, const void* proto, void* gproto, void* workspace, float* items,
+                 int32_t B, int32_t A, int32_t nc, int32_t n_max, int32_t mh, int32_t mw, int32_t img_h, int32_t img_w, int32_t no_grad, int32_t dtype, void* stream) {
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_SEG_LOSS; op.dtype = dtype;
+  op.p[0] = (void*)level_table; op.p[1] = (void*)(n_max > 0 ? gt : nullptr); op.p[2] = (void*)masks; op.p[3] = (void*)proto; op.p[4] = gproto; op.p[5] = workspace; op.p[6] = items;
+  op.i[0] = B; op.i[1] = A; op.i[2] = nc; op.i[3] = n_max; op.i[4] = mh; op.i[5] = mw; op.i[6] = nlev; op.i[7] = no_grad ? 1 : 0;
+  op.i[10] = 32; op.i[11] = 0; op.i[12] = 32; op.i[13] = 0; op.i[14] = img_h; op.i[15] = img_w;
+  return dispatch(op, (hipStream_t)stream);
+}
+
+int msl_adamw(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+              const float* clip_scale, void* stream) {
+  if (n <= 0 || step < 1) { msl_set_error("msl_adamw: n and step must be positive"); return MSL_EINVAL; }
+  msl_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MSL_OP_ADAMW; op.dtype = MSL_F32;
+  op.p[0] = params; op.p[1] = (void*)grads; op.p[2] = m; op.p[3] = v; op.p[5] = (void*)clip_scale;
+  op.i[0] = (int32_t)(n & 0x7FFFFFFF); op.i[1] = (int32_t)(n >> 31);
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  memcpy(&op.i[2], &weight_decay, 4); memcpy(&op.i[3], &bc1, 4); memcpy(&op.i[4], &bc2, 4);
+  op.f[0] = lr; op.f[1] = beta1; op.f[2] = beta2; op.f[3] = eps;
   return dispatch(op, (hipStream_t)stream);
 }
 

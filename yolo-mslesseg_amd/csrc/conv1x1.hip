@@ -38,8 +38,11 @@ struct C1Args {
 // F32: fp32 tensors (the parity engine, the default of predict): the same stream with 16-byte fragments of 4 floats and four
 // v_mfma_f32_16x16x4_f32 per K-step of 16 (lane group g holds channels 4g..4g+3 of the step, MFMA i contracts element i of every group — the
 // k-permutation conv_igemm uses, an exact fp32 fma chain).  The generic kernel these layers used before has no LDS staging: 2-4 TB/s.
-template <int NCP, bool STATS, int PT, bool F32 = false>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
-__global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 waves: 8 when the weight matrix is large, so that fewer LDS copies of it buy more pixels in flight per CU
+// SPLIT (fp32 tensors): split-precision products (msl_common.h) — the weight rows arrive pre-split from the host, and the wave rewrites the slice it staged
+// itself as (hi x 4 | lo x 4) units once it has landed (wave-private ring: no barrier), so the K loop reads ready-made f16 operands.
+template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
+__global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
+  static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");  // 4 or 8 waves: 8 when the weight matrix is large, so that fewer LDS copies of it buy more pixels in flight per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4, NW = blockDim.x >> 6;
@@ -132,6 +135,9 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
     prev_full = (tile + 1) * SP <= a.M;  // a ragged slice skips stores: then the count above would not cover the DMA
     if (tile + stride < tiles) stage(tile + stride, buf ^ 1);
     const unsigned char* xs = s_x + buf * slice_bytes;
+    if constexpr (SPLIT) {
+      for (int k = 0; k < npieces; ++k) msl_split_lds16(s_x + buf * slice_bytes + k * 1024 + lane * 16);
+    }
     // residual (bf16: an input gradient that adds to what its view already holds): fetched here, before the MFMAs, into registers.  Loaded in the
     // store loop, each group's load made hipcc wait — in order — for the next slice's DMA and for the previous group's stores.
     constexpr bool RPRE = !F32 && !STATS;  // (the statistics form is the raw forward conv of training: its residual is added by BN_ACT)
@@ -160,7 +166,19 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {  // 4 or 8 wav
         for (int m = 0; m < 2; ++m) acc[pt][c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < KS; ++ks) {
       const int kb = (ks * KSTEP + EPC * g) * ES;  // 16 bytes per lane either way
-      if constexpr (F32) {
+      if constexpr (SPLIT) {
+        uint4 bfr[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const uint4*)(xs + (pt * 16 + li) * pitch + kb);
+#pragma unroll
+        for (int c = 0; c < NCP; ++c)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const uint4 af = *(const uint4*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = msl_mfma_split(af, bfr[pt], acc[pt][c][m]);
+          }
+      } else if constexpr (F32) {
         f32x4 bfr[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const f32x4*)(xs + (pt * 16 + li) * pitch + kb);
@@ -509,7 +527,7 @@ static const size_t C1_LDS_MAX = 150 * 1024;
 // Eligibility test used by msl_launch_conv (bf16, 1x1, stride 1, pad 0, plain store, everything a multiple of 8, weights + rings fit in LDS)
 bool msl_conv1x1_eligible(const msl_op& op) {
   const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
-  const bool f32 = op.dtype == MSL_F32;
+  const bool f32 = op.dtype == MSL_F32 || op.dtype == MSL_F32S;
   if ((op.dtype != MSL_BF16 && !f32) || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || (op.i[20] != 0 && op.i[20] != 1)) return false;
   if (op.i[20] == 1 && (Cout % 32 || op.p[3] || op.p[5])) return false;  // pixel-shuffle store: whole 8-channel runs per quadrant, no residual / statistics
   if (f32 && op.p[5]) return false;                                       // the statistics epilogue is bf16 only
@@ -520,7 +538,7 @@ bool msl_conv1x1_eligible(const msl_op& op) {
   return c1_lds((Cout + 31) / 32, Kpad, 1, 4, f32 ? 4 : 2) <= C1_LDS_MAX;
 }
 
-template <int NCP, bool STATS, int PT, bool F32 = false>
+template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false>
 static int c1_launch(const C1Args& a, hipStream_t s) {
   constexpr int ES = F32 ? 4 : 2;
   // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
@@ -528,7 +546,7 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const long tiles = (a.M + PT * 16 - 1) / (PT * 16);
@@ -537,14 +555,14 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   if (per_cu < 1) per_cu = 1;
   long blocks = (tiles + nw - 1) / nw;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
+  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32, SPLIT>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
   MSL_CHECK_LAUNCH("conv1x1");
   return MSL_OK;
 }
-template <int NCP>
+template <int NCP, bool SPLIT = false>
 static int c1_launch_f32(const C1Args& a, hipStream_t s) {
-  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true>(a, s);
-  return c1_launch<NCP, false, 1, true>(a, s);
+  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true, SPLIT>(a, s);
+  return c1_launch<NCP, false, 1, true, SPLIT>(a, s);
 }
 template <int NCP, bool STATS>
 static int c1_launch_pt(const C1Args& a, hipStream_t s) {
@@ -568,6 +586,14 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + (a.shuffle ? a.Cout / 4 : a.Cout) <= a.y_cs, "conv1x1: bad dims / views");
   MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
+  if (op.dtype == MSL_F32S) {
+#define C1S(N) case N: return c1_launch_f32<N, true>(a, s)
+    switch (ncp) {
+      C1S(1); C1S(2); C1S(3); C1S(4);
+      C1S(5); C1S(6); C1S(7); C1S(8);
+    }
+#undef C1S
+  }
   if (op.dtype == MSL_F32) {
 #define C1F(N) case N: return c1_launch_f32<N>(a, s)
     switch (ncp) {

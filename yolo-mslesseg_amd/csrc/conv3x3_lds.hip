@@ -157,8 +157,11 @@ __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co
   store_pixel_b<F32, COT>(a, pix, co0, accp, s1, s2, bias);
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false>  // SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
+// image arrives pre-split from the host; every lane rewrites the 16 bytes of the halo tile it staged itself as (hi x 4 | lo x 4) once per chunk,
+// so the nine taps read ready-made f16 operands and the MFMA loop carries no conversion
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
+  static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");
   using T = Tile3<S, RW, KH>;
   constexpr int NT = KH * KW;            // taps: 3x3 (pad 1), or the 1x1 / 1x2 / 2x1 / 2x2 kernels (pad 0) of the stride-2 input gradient's parity classes
   constexpr int PAD = KH == 3 ? 1 : 0;
@@ -246,6 +249,13 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
                                        (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < IN_PER_WAVE; ++j) {
+        const int pc = wave + 4 * j;
+        if (pc < IN_PIECES) msl_split_lds16(s_in + pc * 1024 + lane * 16);
+      }
+    }
     __syncthreads();
 
     // ---- 9 taps; the fragments of tap t+1 are fetched while tap t's MFMAs issue.  (Measured and rejected: reusing the pixel fragments
@@ -273,7 +283,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       for (int c = 0; c < COT; ++c)
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-          if constexpr (F32) {
+          if constexpr (SPLIT) {
+            acc[c][p] = msl_mfma_split(av[t & 1][c], bv[t & 1][p], acc[c][p]);
+          } else if constexpr (F32) {
             f32x4 af = __builtin_bit_cast(f32x4, av[t & 1][c]), bf = __builtin_bit_cast(f32x4, bv[t & 1][p]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][p], 0, 0, 0);
@@ -341,19 +353,19 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false>
 static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<S, RW, KH>;
   constexpr int LDS = T::PIECES * 1024 + KH * KW * 4 * COT * 16 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   Conv3Args b = a;
   b.cout_blocks = cout_blocks;
   dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * cout_blocks));
-  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW>), grid, dim3(256), LDS, s, b);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT>), grid, dim3(256), LDS, s, b);
   MSL_CHECK_LAUNCH("conv3x3_lds");
   return MSL_OK;
 }
@@ -911,9 +923,10 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   }
   a.acc = (double*)op.p[5]; a.slots = op.i[23] > 0 ? op.i[23] : 1;  // BatchNorm-statistics epilogue (train-mode raw convs)
   if (a.acc) MSL_REQUIRE(a.slots <= 16 && !a.out_f32 && !a.res && a.act == 0, "conv3x3_lds: the statistics epilogue is for raw convs (no activation / residual / fp32 output)");
-  const bool f32 = op.dtype == MSL_F32;
+  const bool f32 = op.dtype != MSL_BF16, split = op.dtype == MSL_F32S;
   const int chunk = f32 ? 16 : 32, v = f32 ? 4 : 8;
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv3x3_lds: null pointer");
+  if (split) MSL_REQUIRE(!a.acc && !a.w2, "conv3x3_lds: split-precision products are a predict mode (no statistics epilogue, no fused tail)");
   MSL_REQUIRE(k == 3 && pad == 1 && (stride == 1 || stride == 2) && op.i[20] == 0, "conv3x3_lds: needs k=3 pad=1 stride 1|2, plain store");
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho == (a.H + 2 - 3) / stride + 1 && a.Wo == (a.W + 2 - 3) / stride + 1, "conv3x3_lds: bad dims");
   MSL_REQUIRE(a.Cin > 0 && a.Cin % v == 0 && (a.Cin % chunk == 0 || a.Cin < chunk) && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs,
@@ -944,7 +957,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
                   "conv3x3 + fused 1x1 tail: needs bf16, stride 1, Cin = Cout = 64, 32 tail channels, plain bf16 output view");
       return launch3p<false, 4, 2, true>(a, cout_blocks, s);
     }
-    if (stride == 1 && rw == 2 && nch <= 2 && fits && (pays || op.i[23] == -9) && op.i[23] != -8) {
+    if (!split && stride == 1 && rw == 2 && nch <= 2 && fits && (pays || op.i[23] == -9) && op.i[23] != -8) {
 #define L3P(F, NCH_, R1)                                                           \
   do {                                                                             \
     if (cot == 4) return launch3p<F, 4, NCH_>(a, cout_blocks, s);                  \
@@ -965,6 +978,16 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (cot == 2) return launch3<F, S_, RW_, 2>(a, cout_blocks, s);      \
     return launch3<F, S_, RW_, 1>(a, cout_blocks, s);                    \
   } while (0)
+  if (split) {  // the tile-per-workgroup kernel only
+#define L3S(S_, RW_)                                                                     \
+  do {                                                                                   \
+    if (cot == 4) return launch3<true, S_, RW_, 4, 3, 3, true>(a, cout_blocks, s);       \
+    if (cot == 2) return launch3<true, S_, RW_, 2, 3, 3, true>(a, cout_blocks, s);       \
+    return launch3<true, S_, RW_, 1, 3, 3, true>(a, cout_blocks, s);                     \
+  } while (0)
+    if (stride == 2) L3S(2, 1); else L3S(1, 2);
+#undef L3S
+  }
   if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else L3(true, 1, 2); }
   else     { if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
 #undef L3

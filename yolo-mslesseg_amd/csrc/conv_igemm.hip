@@ -33,8 +33,10 @@ struct ConvArgs {
   int kw, lat_a, lat_b, full_h, full_w;  // kernel width (taps per row); store_mode 2: output pixel (Y,X) → (2Y+lat_a, 2X+lat_b) of a full_h x full_w image
 };
 
-template <bool F32, int COT, int PT>
+template <bool F32, int COT, int PT, bool SPLIT = false>  // SPLIT (fp32 tensors only): split-precision products on the f16 matrix cores (msl_common.h); weights arrive
+                                                          // pre-split from the host (every 16-byte unit (hi x 4 | lo x 4)), pixel fragments are split in registers
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");
   constexpr int CH = F32 ? 4 : 8;      // elements per 16-byte fragment
   constexpr int KSTEP = F32 ? 16 : 32; // K elements consumed per step
   constexpr int ES = F32 ? 4 : 2;
@@ -98,11 +100,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       if (ok) v = *(const uint4*)(a.x + (xoff[pt] + ((long)iy * a.W + ix) * a.x_cs + ci) * ES);
       bv[pt] = v;
     }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) bv[pt] = msl_split_unit(bv[pt]);
+    }
 #pragma unroll
     for (int c = 0; c < COT; ++c)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        if constexpr (F32) {
+        if constexpr (SPLIT) {
+          acc[c][pt] = msl_mfma_split(av[c], bv[pt], acc[c][pt]);
+        } else if constexpr (F32) {
           f32x4 af = __builtin_bit_cast(f32x4, av[c]), bf = __builtin_bit_cast(f32x4, bv[pt]);
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][pt], 0, 0, 0);
@@ -210,12 +218,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <bool F32, int COT, int PT>
+template <bool F32, int COT, int PT, bool SPLIT = false>
 static int launch_t(const ConvArgs& a, hipStream_t s) {
   long M = (long)a.N * a.Ho * a.Wo;
   long gx = (M + 64 * PT - 1) / (64 * PT);
   int gy = a.Cout_pad / (16 * COT);
-  hipLaunchKernelGGL((conv_igemm_kernel<F32, COT, PT>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<F32, COT, PT, SPLIT>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, a);
   MSL_CHECK_LAUNCH("conv_igemm");
   return MSL_OK;
 }
@@ -260,9 +268,9 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
   if (op.i[7] >= 16) { kh = op.i[7] >> 4; a.kw = op.i[7] & 15; a.k = kh > a.kw ? kh : a.kw; }  // rectangular kernel: i[7] = kh*16 + kw
   a.lat_a = op.i[23] & 1; a.lat_b = (op.i[23] >> 1) & 1;
   a.full_h = 2 * a.H - ((op.i[23] >> 2) & 1); a.full_w = 2 * a.W - ((op.i[23] >> 3) & 1);  // (H, W) = the stride-2 conv's output = this pass's source
-  const bool f32 = op.dtype == MSL_F32;
+  const bool f32 = op.dtype != MSL_BF16, split = op.dtype == MSL_F32S;
   const int ch = f32 ? 4 : 8, kstep = f32 ? 16 : 32;
-  MSL_REQUIRE(op.dtype == MSL_F32 || op.dtype == MSL_BF16, "conv: bad dtype %d", op.dtype);
+  MSL_REQUIRE(op.dtype == MSL_F32 || op.dtype == MSL_BF16 || op.dtype == MSL_F32S, "conv: bad dtype %d", op.dtype);
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv: null pointer");
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.Cout > 0 && a.Cin > 0, "conv: bad dims");
   MSL_REQUIRE(a.k >= 1 && a.k <= 3, "conv: k=%d unsupported", a.k);
@@ -290,6 +298,11 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
   const int cot = tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1);
   a.perm = cot >= 2 && a.Cout == a.Cout_pad && a.y_cs % 8 == 0 && a.y_co % 8 == 0 && (!a.res || (a.res_cs % 8 == 0 && a.res_co % 8 == 0)) &&
            (a.store_mode != 1 || (a.Cout / 4) % (4 * cot) == 0);
+  if (split) {
+    if (cot == 4) return launch_t<true, 4, 4, true>(a, s);
+    if (cot == 2) return launch_t<true, 2, 4, true>(a, s);
+    return launch_t<true, 1, 4, true>(a, s);
+  }
   if (f32) {
     if (cot == 4) return launch_t<true, 4, 4>(a, s);
     if (cot == 2) return launch_t<true, 2, 4>(a, s);

@@ -211,6 +211,36 @@ __device__ __forceinline__ unsigned msl_lds_addr(const void* p) {  // byte addre
   return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p);
 }
 
+// ---- split-precision products (dtype MSL_F32S: fp32 tensors, conv products on the f16 matrix cores).  A 16-byte unit of four fp32 values
+// x0..x3 is rewritten in place as (hi0..hi3 | lo0..lo3), hi = f16(x) (toward zero: an overflow saturates instead of becoming inf), lo = f16(x - hi)
+// (nearest even; x - hi is exact in fp32), so hi + lo carries 21-22 bits of x.  A product of two such operands is taken as
+// lo_a*hi_b + hi_a*lo_b + hi_a*hi_b on v_mfma_f32_16x16x16_f16 (f16 x f16 is exact in the fp32 accumulator; the dropped lo*lo term is 2^-22 of
+// the product): three matrix instructions of 8 cycles instead of four fp32 ones of 32.  Lane group g of both operands holds k = 4g..4g+3 of the
+// step, exactly the elements the four v_mfma_f32_16x16x4_f32 of the exact path contract, and the result layout is the same.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 msl_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 msl_split_unit(uint4 raw) {
+  const f32x4 v = __builtin_bit_cast(f32x4, raw);
+  const msl_h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+  const _Float16 l0 = (_Float16)(v[0] - (float)h01[0]), l1 = (_Float16)(v[1] - (float)h01[1]);
+  const _Float16 l2 = (_Float16)(v[2] - (float)h23[0]), l3 = (_Float16)(v[3] - (float)h23[1]);
+  uint4 o;
+  o.x = __builtin_bit_cast(unsigned, h01);
+  o.y = __builtin_bit_cast(unsigned, h23);
+  o.z = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  o.w = (unsigned)__builtin_bit_cast(unsigned short, l2) | ((unsigned)__builtin_bit_cast(unsigned short, l3) << 16);
+  return o;
+}
+__device__ __forceinline__ f32x4 msl_mfma_split(uint4 a, uint4 b, f32x4 acc) {
+  const f16x4 ah = __builtin_bit_cast(f16x4, make_uint2(a.x, a.y)), al = __builtin_bit_cast(f16x4, make_uint2(a.z, a.w));
+  const f16x4 bh = __builtin_bit_cast(f16x4, make_uint2(b.x, b.y)), bl = __builtin_bit_cast(f16x4, make_uint2(b.z, b.w));
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+}
+// in-place conversion of 16 staged bytes in LDS (the lane that brought them in converts them, before the barrier that publishes the tile)
+__device__ __forceinline__ void msl_split_lds16(unsigned char* p) { *(uint4*)p = msl_split_unit(*(const uint4*)p); }
+
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // op launchers (one per translation unit)

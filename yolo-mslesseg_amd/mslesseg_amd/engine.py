@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import geometry, graph, hiplib, params
-from .hiplib import MSL_BF16, MSL_F32, PRED_STRIDE
+from .hiplib import MSL_BF16, MSL_F32, MSL_F32S, PRED_STRIDE
 
 CONF_THRES = 0.25  # [UPSTREAM predictor default conf]
 IOU_THRES = 0.7  # [REF trains/Base/…/args.yaml:41]
@@ -24,17 +24,29 @@ MAX_DET = 300  # [REF …/args.yaml:42]
 
 
 def precision_code(name: str) -> int:
-    """'bf16' | 'fp32' → MSL_BF16 | MSL_F32 (the storage / arithmetic type of an engine)."""
+    """'bf16' | 'fp32' | 'fp32s' → MSL_BF16 | MSL_F32 | MSL_F32S (the storage / arithmetic type of an engine)."""
     n = str(name).lower()
     if n in ("bf16", "bfloat16"):
         return MSL_BF16
     if n in ("fp32", "f32", "float32"):
         return MSL_F32
-    raise ValueError(f"unknown precision {name!r} (bf16 | fp32)")
+    if n in ("fp32s", "f32s", "split", "fp32-split"):
+        return MSL_F32S
+    raise ValueError(f"unknown precision {name!r} (bf16 | fp32 | fp32s)")
 
 
 def _dt(dtype: int) -> torch.dtype:
-    return torch.float32 if dtype == MSL_F32 else torch.bfloat16
+    return torch.bfloat16 if dtype == MSL_BF16 else torch.float32
+
+
+def split_f16_units(w: torch.Tensor) -> torch.Tensor:
+    """Packed fp32 conv weights → the pre-split form MSL_F32S kernels read (include/mslesseg_hip.h): every 16-byte unit of four values becomes
+    (hi f16 x 4 | lo f16 x 4) with hi = f16(w), lo = f16(w - hi); same size, returned as a float32 tensor of bit patterns.  All conv weight layouts
+    (GEMM rows, the 3x3 LDS image) are read by the kernels in such units of four consecutive K elements."""
+    v = w.detach().to(torch.float32).reshape(-1, 4)
+    hi = v.to(torch.float16)
+    lo = (v - hi.to(torch.float32)).to(torch.float16)
+    return torch.cat([hi, lo], 1).contiguous().view(torch.float32).reshape(w.shape)
 
 
 class View:
@@ -58,7 +70,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
     """Zero-pad GEMM weights to [Cout_pad(16)][Kpad(K-step)] in the op dtype; bias stays fp32."""
-    kstep = 16 if dtype == MSL_F32 else 32
+    kstep = 32 if dtype == MSL_BF16 else 16
     cout, K = wg.shape
     cout_pad = (cout + 15) // 16 * 16
     kpad = (K + kstep - 1) // kstep * kstep
@@ -66,11 +78,14 @@ def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
     wp[:cout, :K] = wg
     bp = torch.zeros(cout_pad, dtype=torch.float32, device=wg.device)
     bp[:cout] = b
-    return wp.to(_dt(dtype)).contiguous().to(device), bp.to(device), dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
+    wp = wp.to(_dt(dtype)).contiguous()
+    if dtype == MSL_F32S:
+        wp = split_f16_units(wp)
+    return wp.to(device), bp.to(device), dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
 
 
 def lds3x3_eligible(cin: int, cout: int, k: int, dtype: int) -> bool:
-    chunk = 16 if dtype == MSL_F32 else 32
+    chunk = 32 if dtype == MSL_BF16 else 16
     # whole channel chunks, or ONE partial chunk (narrow layers: the missing k-group planes are staged as zeros)
     # Cout = 8 (the C3k2 bottlenecks of the 160² level) runs as one 16-row block whose upper half is zero weights
     return k == 3 and (cout % 16 == 0 or cout == 8) and (cin % chunk == 0 or (cin < chunk and cin % (chunk // 4) == 0))
@@ -88,7 +103,7 @@ def lds_col_perm(cot: int) -> torch.Tensor:
 def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
     """[Cout,Cin,3,3] → the LDS image of conv3x3_lds.hip: [cout_blk][chunk][tap][g][COB rows, lds_col_perm order][CH] (include/mslesseg_hip.h)."""
     cout, cin, _, _ = w.shape
-    ch = 4 if dtype == MSL_F32 else 8
+    ch = 8 if dtype == MSL_BF16 else 4
     chunk = 4 * ch
     cout_real = cout
     if cout == 8:  # pad to one 16-row block
@@ -104,7 +119,10 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
         w = wp
     wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot).to(w.device)]   # [blk, col, cc, g, e, ky, kx]
     img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
-    return img.to(_dt(dtype)).reshape(-1).to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
+    img = img.to(_dt(dtype)).reshape(-1)
+    if dtype == MSL_F32S:
+        img = split_f16_units(img)
+    return img.to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
 
 
 class PackedWeights:
@@ -114,7 +132,7 @@ class PackedWeights:
         self.scale, self.nc, self.dtype, self.device = scale, nc, dtype, device
         self.specs = params.param_specs(scale, nc)
         self.t: Dict[str, Tuple[torch.Tensor, torch.Tensor, dict]] = {}
-        kstep = 16 if dtype == MSL_F32 else 32
+        kstep = 32 if dtype == MSL_BF16 else 16
         for name, s in self.specs.items():
             w, b = params.folded(state, name, s)
             if s["kind"] == "convT":  # [Cin,Cout,2,2] → GEMM rows (dy*2+dx)*Cout+co, K = Cin
@@ -408,7 +426,7 @@ class Plan:
         """Algorithmic (flops, bytes) of op i: 2*MAC for conv/attention GEMM work; bytes = input view + output view
         + weights, each touched once."""
         op = self.program.arr[i]
-        es = 4 if self.dtype == MSL_F32 else 2
+        es = 2 if self.dtype == MSL_BF16 else 4
         I = op.i
         if op.kind == hiplib.OP_CONV:
             N, H, W, Cin, Ho, Wo, Cout, K = I[0], I[1], I[2], I[3], I[4], I[5], I[6], I[16]
@@ -460,7 +478,8 @@ class LetterBoxProgram:
 
 
 class InferEngine:
-    """Weights + plan cache.  `dtype` MSL_BF16 (throughput) or MSL_F32 (exact-fp32 parity mode)."""
+    """Weights + plan cache.  `dtype` MSL_BF16 (throughput), MSL_F32 (exact-fp32 parity mode) or MSL_F32S (fp32 tensors, conv products as three f16
+    partial products on the matrix cores: the parity tolerance at several times the fp32 rate)."""
 
     def __init__(self, state, scale: str, nc: int, dtype: int = MSL_BF16, device="cuda:0", use_lds3x3: bool = True,
                  conf: float = CONF_THRES, iou: float = IOU_THRES, max_det: int = MAX_DET):

@@ -9,7 +9,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parents[1] / "lib" / "libmslesseg_hip.so"
 
-MSL_BF16, MSL_F32 = 0, 1
+MSL_BF16, MSL_F32, MSL_F32S = 0, 1, 2  # MSL_F32S: fp32 tensors, split-precision conv products on the f16 matrix cores (include/mslesseg_hip.h)
 PRED_STRIDE = 40
 
 OP_CONV, OP_STEM, OP_DWCONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_ATTENTION = 1, 2, 3, 4, 5, 6
@@ -24,6 +24,7 @@ EXPORTS = (
     "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_launch",
     "msl_graph_destroy", "msl_event_create", "msl_event_record", "msl_event_elapsed_ms", "msl_event_destroy",
     "msl_seg_loss_workspace", "msl_conv2d_nhwc", "msl_letterbox_u8", "msl_nms", "msl_volume_consensus", "msl_volume_dice_sums",
+    "msl_conv2d_wgrad_nhwc", "msl_bn_act_fwd", "msl_bn_act_bwd", "msl_seg_loss", "msl_adamw",
 )
 
 

@@ -178,10 +178,9 @@ def enhancement_tables() -> np.ndarray:
     v = np.arange(256, dtype=np.uint8)
     lt = np.zeros((256, 256), np.uint8)
     g = np.arange(256, dtype=np.uint16)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        for m in range(256):
-            c = 255 / np.log(1 + np.array([m], dtype=np.uint16).max())
-            lt[m] = np.clip(c * np.log(1 + g), 0, 255).astype(np.uint8)
+    for m in range(1, 256):  # row 0 (an all-zero slice) stays zero by rule: enhance.lt
+        c = 255 / np.log(1 + np.array([m], dtype=np.uint16).max())
+        lt[m] = np.clip(c * np.log(1 + g), 0, 255).astype(np.uint8)
     return np.concatenate([_GRAY_LUT, enhance.gc(v.reshape(1, -1)).reshape(-1), enhance._srgb_to_L8(v), enhance._L8_to_srgb(v), lt.reshape(-1)])
 
 

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import geometry, params
-from .hiplib import MSL_BF16, MSL_F32
+from .hiplib import MSL_BF16, MSL_F32, MSL_F32S
 
 LOGGER = logging.getLogger("ultralytics")
 _NAME_RE = re.compile(r"^yolo11([nsmlx])-seg(\.pt|\.yaml)?$")
@@ -34,7 +34,9 @@ def _precision(p: Optional[str], env: str, default: str) -> int:
         return MSL_BF16
     if p in ("fp32", "f32", "float32"):
         return MSL_F32
-    raise ValueError(f"unknown precision {p!r} (bf16 | fp32)")
+    if p in ("fp32s", "f32s", "split", "fp32-split"):
+        return MSL_F32S
+    raise ValueError(f"unknown precision {p!r} (bf16 | fp32 | fp32s)")
 
 
 class Masks:
@@ -112,6 +114,8 @@ class YOLO:
         self.device = device
         self.dtype = _precision(precision, "MSLESSEG_PRECISION", "fp32")
         self.train_dtype = _precision(train_precision or precision, "MSLESSEG_TRAIN_PRECISION", "bf16")
+        if self.train_dtype == MSL_F32S:  # split-precision products exist for the predict kernels only: training under it runs the exact fp32 engine
+            self.train_dtype = MSL_F32
         self.names = {0: "lesion"}
         self._engine = None
         self.trainer = None
