@@ -31,7 +31,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 METRIC = "FLAIR slices/sec train+infer at 1/2/4/8 GPU; Dice vs GT volumes"  # BASELINE.json "metric"
-PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+PEAK = {"bf16": 2500.0, "fp32": 157.3,  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+        "fp32s": 2500.0 / 3}  # split-precision products: three f16 matrix instructions per algorithmic product
 PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_SLICE_640 = 9.630  # n, nc=1, 640x640, 2*MAC over conv + attention + ConvT; training = 3x
 FWD_GFLOP = {"n": 9.630, "s": 32.90}  # SURVEY §8d, nc=1, 640x640
@@ -111,7 +112,9 @@ def predict_setup(args, dev, rank, state, B):
     from mslesseg_amd import engine as E
     from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
 
-    dtype = MSL_BF16 if args.dtype == "bf16" else MSL_F32
+    from mslesseg_amd.hiplib import MSL_F32S
+
+    dtype = {"bf16": MSL_BF16, "fp32": MSL_F32, "fp32s": MSL_F32S}[args.dtype]
     S = args.size
     host = synthetic_slices(B, S, S, seed=rank)
     imgs = torch.from_numpy(host).to(dev)
@@ -653,7 +656,7 @@ def main():
                          "(mosaic on); replicas: independent trainings, one per GPU, no collective (SURVEY 8e zero-communication mode); fit-epoch: whole epochs of "
                          "model.train() on a fold-sized dataset (train steps + sharded validation + checkpoint), --steps = epochs timed")
     ap.add_argument("--batch", type=int, default=0, help="slices per GPU per step (default: 128 for both legs — north_star: batch >= 128)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32s"], help="fp32s (predict only): fp32 tensors, split-precision conv products (MSL_F32S)")
     ap.add_argument("--scale", default="n", choices=["n", "s"], help="n = BASELINE configs[1]; s = configs[2] (YOLO11s-seg, seeded random initialisation)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -666,6 +669,8 @@ def main():
                     help="predict leg: shift the class bias so NMS keeps about this many instances per synthetic slice (0: leave the "
                          "calibrated-random weights as they are, which saturates max_det=300 on noise slices)")
     args = ap.parse_args()
+    if args.dtype == "fp32s" and args.mode != "predict":
+        ap.error("--dtype fp32s is a predict mode (train steps run bf16 or fp32)")
     world, rank, dev, dist = dist_setup(args)
     state = load_weights(args.scale)
     S = args.size
@@ -723,7 +728,7 @@ def main():
                 line["infer"] = {}
                 # the inference leg in both arithmetic modes: fp32 = the default of YOLO() predict (exact parity with the CPU path: identical NMS
                 # indices and mask bytes, tests/test_gpu_trained.py), bf16 = the opt-in throughput mode
-                for pdt in ("fp32", "bf16"):
+                for pdt in ("fp32", "fp32s", "bf16"):
                     pargs = argparse.Namespace(**{**vars(args), "steps": 10, "warmup": 3, "dtype": pdt})
                     eng, imgs, host, pstate, shift = predict_setup(pargs, dev, rank, state, 128)
                     t0 = None
@@ -737,8 +742,10 @@ def main():
                     line["infer"][pdt] = {"value": round(128 * 10 / pdt_s, 2), "unit": "slices/s (1 GPU)", "ms_per_step": round(pdt_s / 10 * 1e3, 3), "per_gpu_batch": 128,
                                           "workload": f"predict leg: LetterBox+net+NMS+masks+merge, class bias shifted {shift:+.2f} for ~{args.target_kept:g} kept instances/slice",
                                           "mean_kept_instances_per_slice": round(float(eng.plan(128, S, S).keep_cnt.float().mean().item()), 1),
-                                          "parity": ("exact vs the CPU oracle (north_star tolerance met)" if pdt == "fp32" else
-                                                     "throughput mode: |dDice| <= 1e-3 per plane volume, not at the 1e-4 tolerance")}
+                                          "parity": {"fp32": "exact vs the CPU oracle (north_star tolerance met)",
+                                                     "fp32s": "fp32 tensors, conv products as three f16 partial products (MSL_F32S): north_star tolerance met on the trained "
+                                                              "checkpoint (tests/test_gpu_trained.py, same assertions as fp32)",
+                                                     "bf16": "throughput mode: |dDice| <= 1e-3 per plane volume, not at the 1e-4 tolerance"}[pdt]}
                     if pdt == "fp32":
                         line["infer"]["batch1"] = batch1_latency(eng, pstate, host, dev, args)
                     del eng, imgs

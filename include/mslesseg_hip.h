@@ -45,7 +45,8 @@ enum { MSL_BF16 = 0, MSL_F32 = 1,
        MSL_F32S = 2 /* fp32 tensors like MSL_F32, but MSL_OP_CONV takes every product as three f16 partial products (operands split hi + lo: 21-22 bits
                        each, fp32 accumulate) on v_mfma_f32_16x16x16_f16 — 1e-6-grade instead of exact fp32, several times the fp32 matrix rate.  Conv
                        weights must be packed pre-split: every 16-byte unit of four fp32 values rewritten as (hi f16 x 4 | lo f16 x 4), hi = f16(w),
-                       lo = f16(w - hi) (mslesseg_amd.engine.split_f16_units).  Every other op kind treats it as MSL_F32. */ };
+                       lo = f16(w - hi), after scaling the tensor by a power of two that brings its largest magnitude to [2^13, 2^14); the inverse power of two
+                       goes into msl_op.f[0] and is applied to the accumulators (mslesseg_amd.engine.split_f16_units).  Every other op kind treats it as MSL_F32. */ };
 
 enum {
   MSL_OK = 0,

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 from mslesseg_amd import engine as E  # noqa: E402
 from mslesseg_amd import geometry, hiplib  # noqa: E402
-from mslesseg_amd.hiplib import MSL_BF16, MSL_F32  # noqa: E402
+from mslesseg_amd.hiplib import MSL_BF16, MSL_F32, MSL_F32S  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -24,7 +24,7 @@ def _stream():
 
 
 def _tdt(dtype):
-    return torch.float32 if dtype == MSL_F32 else torch.bfloat16
+    return torch.bfloat16 if dtype == MSL_BF16 else torch.float32
 
 
 def _rand_act(shape, dtype, gen, scale=1.0):
@@ -34,7 +34,7 @@ def _rand_act(shape, dtype, gen, scale=1.0):
 
 def _close(out, ref, dtype, what=""):
     out, ref = out.float().cpu(), ref.float()
-    if dtype == MSL_F32:
+    if dtype != MSL_BF16:  # MSL_F32 and the split-precision mode MSL_F32S: the same fp32 tolerance
         rtol, atol = 1e-4, 1e-5 * max(1.0, float(ref.abs().max()))
     else:
         rtol, atol = 1e-2, 1e-2 * max(1e-3, float(ref.abs().max()))
@@ -80,7 +80,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16, MSL_F32S])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm(case, dtype):
     N, H, W, Cin, Cout, k, s, x_cs, x_co, y_cs, y_co, act, res, out_f32 = case
@@ -103,7 +103,7 @@ def test_conv_igemm(case, dtype):
     xd, rd, yd = xbuf.to(DEV), rbuf.to(DEV), ybuf.to(DEV)
     op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), rd.data_ptr() if res else 0, yd.data_ptr()),
                         i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: k, 8: s, 9: pad, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co,
-                           14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"]})
+                           14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"]}, f=(m.get("oscale", 1.0),))
     hiplib.launch(op, _stream())
     torch.cuda.synchronize()
     out = yd.cpu()
@@ -140,7 +140,7 @@ LDS3_CASES = [
 
 
 @pytest.mark.parametrize("pers", [0, 1])
-@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
+@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16, MSL_F32S])
 @pytest.mark.parametrize("case", LDS3_CASES)
 def test_conv3x3_lds(case, dtype, pers):
     """pers=1 asks for the persistent weights-resident kernel (i[23] = -9; taken when stride 1 and the weight block fits LDS, else the
@@ -165,7 +165,7 @@ def test_conv3x3_lds(case, dtype, pers):
     op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), rd.data_ptr() if res else 0, yd.data_ptr()),
                         i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co,
                            14: y_cs, 15: y_co, 16: m["K"], 17: m["Kpad"], 18: act, 19: out_f32, 20: 0, 21: m["Cout_pad"], 23: -9 if pers else -8,
-                           24: m["cot"], 25: 1})
+                           24: m["cot"], 25: 1}, f=(m.get("oscale", 1.0),))
     hiplib.launch(op, _stream())
     torch.cuda.synchronize()
     out = yd.cpu()
@@ -730,6 +730,43 @@ def test_slice_extract_device_matches_host_restatement(plano, mejora, demo_volum
             assert got[j].shape == want.shape, (got[j].shape, want.shape)
             nd = int((got[j] != want).sum())
             assert nd == 0, f"{plano} slice {i} {mejora}: {nd} differing bytes, max |d| {int(np.abs(got[j].astype(int) - want.astype(int)).max())}"
+
+
+@pytest.mark.parametrize("kind", ["3x3", "3x3s2", "1x1", "1x1wide"])
+def test_split_precision_products_are_fp32_grade(kind):
+    """MSL_F32S (every conv product as three f16 partial products, operands split hi + lo) against a float64 reference, beside the exact fp32
+    kernels on the same data: the split mode's error must be of the order of fp32 rounding (a few 1e-7 of the output scale), not of f16 (1e-3)."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 3, 40, 56
+    Cin, Cout, k, s = {"3x3": (64, 64, 3, 1), "3x3s2": (32, 64, 3, 2), "1x1": (128, 64, 1, 1), "1x1wide": (384, 128, 1, 1)}[kind]
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = torch.randn(N, H, W, Cin, generator=g) * 3.0                      # post-SiLU-like scale, both signs
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    w[0] *= 1e-3                                                           # a row of tiny weights and a row of large ones
+    w[1] *= 50.0
+    b = torch.rand(Cout, generator=g) - 0.5
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=s, padding=pad).permute(0, 2, 3, 1)
+    errs = {}
+    for dtype in (MSL_F32, MSL_F32S):
+        if k == 3:
+            wt, bt, m = E.pack_conv3x3_lds(w, b, dtype, DEV)
+            extra = {23: -8, 24: m["cot"], 25: 1}
+        else:
+            wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), b, dtype, DEV)
+            extra = {}
+        xd = x.to(DEV)
+        yd = torch.zeros(N, Ho, Wo, Cout, device=DEV)
+        op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr()),
+                            i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: k, 8: s, 9: pad, 10: Cin, 11: 0, 12: Cout, 13: 0, 14: Cout, 15: 0,
+                               16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 0, 21: m["Cout_pad"], **extra}, f=(m.get("oscale", 1.0),))
+        hiplib.launch(op, _stream())
+        torch.cuda.synchronize()
+        d = (yd.cpu().double() - ref).abs()
+        scale = ref.abs().amax(dim=(0, 1, 2)).clamp_min(1e-30)             # per output channel: the tiny and the large row are judged on their own scale
+        errs[dtype] = float((d.amax(dim=(0, 1, 2)) / scale).max())
+    print(f"{kind}: max error / channel scale  fp32 {errs[MSL_F32]:.2e}  split {errs[MSL_F32S]:.2e}")
+    assert errs[MSL_F32] <= 2e-6 and errs[MSL_F32S] <= 4e-6, errs
 
 
 def test_conv3x3_with_fused_1x1_tail():

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 from mslesseg_amd import engine as E  # noqa: E402
 from mslesseg_amd import volume as V  # noqa: E402
-from mslesseg_amd.hiplib import MSL_BF16, MSL_F32  # noqa: E402
+from mslesseg_amd.hiplib import MSL_BF16, MSL_F32, MSL_F32S  # noqa: E402
 
 STRIDE = 3  # every 3rd slice of the reference's slice set (121 of the 361 lesion slices) keeps the oracle's CPU time to a few seconds
 
@@ -81,14 +81,18 @@ def _engine_run(eng, oracle_run, gt):
     return res
 
 
-def test_fp32_engine_meets_the_north_star_tolerance_on_trained_weights(trained_state, oracle_run, demo_volumes):
+@pytest.mark.parametrize("mode", ["fp32", "fp32s"])
+def test_fp32_engine_meets_the_north_star_tolerance_on_trained_weights(trained_state, oracle_run, demo_volumes, mode):
+    """The north-star contract (bit-exact kept indices after NMS, <= 2 output bytes, |dDice| <= 1e-4 per plane volume and for the consensus) for
+    the exact fp32 engine (the predict default) AND for the split-precision mode MSL_F32S (fp32 tensors, every conv product as three f16 partial
+    products on the matrix cores): the same assertions, nothing relaxed."""
     from oracle import prepost as P
 
     gt = demo_volumes["P39_mask"]
     assert sum(len(k) for o in oracle_run.values() for k in o["kept"]) > 300, "the trained network must detect lesions for this test to mean anything"
-    res = _engine_run(E.InferEngine(trained_state, "n", 1, MSL_F32), oracle_run, gt)
+    res = _engine_run(E.InferEngine(trained_state, "n", 1, MSL_F32 if mode == "fp32" else MSL_F32S), oracle_run, gt)
     for plano, r in res.items():
-        print(f"fp32 {plano}: {r['same_list']}/{r['n']} identical kept lists, {r['px']} of {r['total']} bytes differ, dice {r['dice']:.6f} oracle {oracle_run[plano]['dice']:.6f}")
+        print(f"{mode} {plano}: {r['same_list']}/{r['n']} identical kept lists, {r['px']} of {r['total']} bytes differ, dice {r['dice']:.6f} oracle {oracle_run[plano]['dice']:.6f}")
         assert r["same_list"] == r["n"], f"{plano}: kept indices differ on {r['n'] - r['same_list']} slices"
         assert r["px"] <= 2, f"{plano}: {r['px']} output bytes differ"
         assert abs(r["dice"] - oracle_run[plano]["dice"]) <= 1e-4

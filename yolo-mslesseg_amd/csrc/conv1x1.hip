@@ -31,6 +31,7 @@ struct C1Args {
   double* acc;        // [slots][2*Cout] or NULL
   long M;
   int Cin, Cout, Kpad, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, slots, w_rows;
+  float oscale;       // MSL_F32S: accumulators x this before bias / activation (inverse of the host's power-of-two weight scale)
   int shuffle, H, W;  // shuffle = 1: pixel-shuffle store of a ConvTranspose2d k2 s2 run as a 1x1 GEMM — channel q*C + c (C = Cout/4, q = dy*2 + dx) of
                       // pixel (y, x) goes to channel c of pixel (2y + dy, 2x + dx) of the 2H x 2W output (same contract as conv_igemm's store mode 1)
 };
@@ -205,6 +206,14 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
             for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
           }
       }
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int c = 0; c < NCP; ++c)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[pt][c][m] *= a.oscale;
     }
     // ---- epilogue: lane (li, g) holds channels c*32 + 8g .. +7 of pixel p0 + 16*pt + li
 #pragma unroll
@@ -586,7 +595,9 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + (a.shuffle ? a.Cout / 4 : a.Cout) <= a.y_cs, "conv1x1: bad dims / views");
   MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
+  a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
   if (op.dtype == MSL_F32S) {
+    MSL_REQUIRE(op.f[0] > 0.f && !a.acc, "conv1x1 (MSL_F32S): f[0] must hold the output scale of the pre-split weights; no statistics epilogue");
 #define C1S(N) case N: return c1_launch_f32<N, true>(a, s)
     switch (ncp) {
       C1S(1); C1S(2); C1S(3); C1S(4);

@@ -33,6 +33,7 @@ struct Conv3Args {
   int N, H, W, Cin, Ho, Wo, Cout;
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int act, out_f32, tiles_x, tiles_y;
+  float oscale;     // MSL_F32S: accumulators x this before bias / activation (inverse of the host's power-of-two weight scale); 1 otherwise
   int cout_blocks;  // output-channel blocks per tile: the fastest-varying part of the workgroup index, so that the blocks of one tile run
                     // back to back and re-read its halo from L2 (as the slow grid dimension every block pulled it from HBM again)
   const char* w2;       // fused 1x1 tail (persistent kernel, bf16): weights [C2 = 32][Cout = 64] row-major, y = act(W2 * act(conv(x) + bias) + bias2)
@@ -297,6 +298,12 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     }
   }
 
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int p = 0; p < PT; ++p) acc[c][p] *= a.oscale;
+  }
   // ---- epilogue: bias + SiLU (+ residual); 4 consecutive channels per lane and tile
   float s1[COT][4], s2[COT][4];  // BatchNorm sums of this lane's pixels (train-mode raw conv: bias 0, no activation)
 #pragma unroll
@@ -926,7 +933,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   const bool f32 = op.dtype != MSL_BF16, split = op.dtype == MSL_F32S;
   const int chunk = f32 ? 16 : 32, v = f32 ? 4 : 8;
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv3x3_lds: null pointer");
-  if (split) MSL_REQUIRE(!a.acc && !a.w2, "conv3x3_lds: split-precision products are a predict mode (no statistics epilogue, no fused tail)");
+  if (split) MSL_REQUIRE(!a.acc && !a.w2 && op.f[0] > 0.f, "conv3x3_lds: split-precision products are a predict mode (no statistics epilogue, no fused tail) and need the output scale in f[0]");
+  a.oscale = split ? op.f[0] : 1.0f;
   MSL_REQUIRE(k == 3 && pad == 1 && (stride == 1 || stride == 2) && op.i[20] == 0, "conv3x3_lds: needs k=3 pad=1 stride 1|2, plain store");
   MSL_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Ho == (a.H + 2 - 3) / stride + 1 && a.Wo == (a.W + 2 - 3) / stride + 1, "conv3x3_lds: bad dims");
   MSL_REQUIRE(a.Cin > 0 && a.Cin % v == 0 && (a.Cin % chunk == 0 || a.Cin < chunk) && a.x_cs % v == 0 && a.x_co % v == 0 && a.x_co + a.Cin <= a.x_cs,
@@ -985,6 +993,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (cot == 2) return launch3<true, S_, RW_, 2, 3, 3, true>(a, cout_blocks, s);       \
     return launch3<true, S_, RW_, 1, 3, 3, true>(a, cout_blocks, s);                     \
   } while (0)
+    // (measured and rejected: 16 x 32 tiles for whole 64-channel blocks, which halve the weight slab re-staged per pixel — proto.cv2 0.965 -> 1.18 ms)
     if (stride == 2) L3S(2, 1); else L3S(1, 2);
 #undef L3S
   }

@@ -30,6 +30,7 @@ struct ConvArgs {
   int x_cs, x_co, y_cs, y_co, res_cs, res_co;
   int K, Kpad, act, out_f32, store_mode, Cout_pad, dgrad;
   int perm;  // 1: weight row (c*16 + 4q + r) of a block carries channel q*4*COT + c*4 + r → a lane's outputs of one pixel are consecutive channels
+  float oscale;  // MSL_F32S: the accumulators are multiplied by this (the inverse of the power of two the host scaled the weights by) before bias / activation
   int kw, lat_a, lat_b, full_h, full_w;  // kernel width (taps per row); store_mode 2: output pixel (Y,X) → (2Y+lat_a, 2X+lat_b) of a full_h x full_w image
 };
 
@@ -126,6 +127,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[c][pt] *= a.oscale;
+  }
   // epilogue: bias + activation (+ residual), 4 consecutive channels per lane and tile
   const int C4 = a.Cout >> 2;  // pixel-shuffle: channels per quadrant
 #pragma unroll
@@ -269,6 +276,8 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
   a.lat_a = op.i[23] & 1; a.lat_b = (op.i[23] >> 1) & 1;
   a.full_h = 2 * a.H - ((op.i[23] >> 2) & 1); a.full_w = 2 * a.W - ((op.i[23] >> 3) & 1);  // (H, W) = the stride-2 conv's output = this pass's source
   const bool f32 = op.dtype != MSL_BF16, split = op.dtype == MSL_F32S;
+  a.oscale = split ? op.f[0] : 1.0f;
+  if (split) MSL_REQUIRE(op.f[0] > 0.f, "conv (MSL_F32S): f[0] must hold the output scale of the pre-split weights");
   const int ch = f32 ? 4 : 8, kstep = f32 ? 16 : 32;
   MSL_REQUIRE(op.dtype == MSL_F32 || op.dtype == MSL_BF16 || op.dtype == MSL_F32S, "conv: bad dtype %d", op.dtype);
   MSL_REQUIRE(a.x && a.w && a.bias && a.y, "conv: null pointer");

@@ -39,14 +39,19 @@ def _dt(dtype: int) -> torch.dtype:
     return torch.bfloat16 if dtype == MSL_BF16 else torch.float32
 
 
-def split_f16_units(w: torch.Tensor) -> torch.Tensor:
-    """Packed fp32 conv weights → the pre-split form MSL_F32S kernels read (include/mslesseg_hip.h): every 16-byte unit of four values becomes
-    (hi f16 x 4 | lo f16 x 4) with hi = f16(w), lo = f16(w - hi); same size, returned as a float32 tensor of bit patterns.  All conv weight layouts
-    (GEMM rows, the 3x3 LDS image) are read by the kernels in such units of four consecutive K elements."""
+def split_f16_units(w: torch.Tensor):
+    """Packed fp32 conv weights → (the pre-split form MSL_F32S kernels read, output scale) (include/mslesseg_hip.h): the tensor is first multiplied
+    by a power of two that brings its largest magnitude to [2^13, 2^14) — f16 has 5 exponent bits: without this a weight below 6e-5 would be a
+    subnormal hi with nothing left for lo — then every 16-byte unit of four values becomes (hi f16 x 4 | lo f16 x 4), hi = f16(w), lo = f16(w - hi);
+    same size, returned as a float32 tensor of bit patterns.  The kernel multiplies its accumulators by the returned scale (the inverse power of
+    two: exact).  All conv weight layouts (GEMM rows, the 3x3 LDS image) are read in such units of four consecutive K elements."""
     v = w.detach().to(torch.float32).reshape(-1, 4)
+    amax = float(v.abs().max())
+    e = 0 if amax == 0.0 else max(-40, min(40, 13 - math.floor(math.log2(amax))))
+    v = v * (2.0 ** e)
     hi = v.to(torch.float16)
     lo = (v - hi.to(torch.float32)).to(torch.float16)
-    return torch.cat([hi, lo], 1).contiguous().view(torch.float32).reshape(w.shape)
+    return torch.cat([hi, lo], 1).contiguous().view(torch.float32).reshape(w.shape), 2.0 ** (-e)
 
 
 class View:
@@ -79,9 +84,10 @@ def pack_gemm(wg: torch.Tensor, b: torch.Tensor, dtype: int, device):
     bp = torch.zeros(cout_pad, dtype=torch.float32, device=wg.device)
     bp[:cout] = b
     wp = wp.to(_dt(dtype)).contiguous()
+    meta = dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
     if dtype == MSL_F32S:
-        wp = split_f16_units(wp)
-    return wp.to(device), bp.to(device), dict(K=K, Kpad=kpad, Cout_pad=cout_pad)
+        wp, meta["oscale"] = split_f16_units(wp)
+    return wp.to(device), bp.to(device), meta
 
 
 def lds3x3_eligible(cin: int, cout: int, k: int, dtype: int) -> bool:
@@ -120,9 +126,10 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
     wv = w.reshape(cout // cob, cob, w.shape[1] // chunk, 4, ch, 3, 3)[:, lds_col_perm(cot).to(w.device)]   # [blk, col, cc, g, e, ky, kx]
     img = wv.permute(0, 2, 5, 6, 3, 1, 4).contiguous()                   # [blk, cc, ky, kx, g, col, e]
     img = img.to(_dt(dtype)).reshape(-1)
+    meta = dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
     if dtype == MSL_F32S:
-        img = split_f16_units(img)
-    return img.to(device), b.float().contiguous().to(device), dict(K=9 * cin, Kpad=9 * cin, Cout_pad=cout_real, lds=1, cot=cot)
+        img, meta["oscale"] = split_f16_units(img)
+    return img.to(device), b.float().contiguous().to(device), meta
 
 
 class PackedWeights:
@@ -232,7 +239,7 @@ class ProgramBuilder(graph.Visitor):
         if res is not None:
             assert (res.H, res.W, res.C) == (Ho, Wo, cout), name
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
-        self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), rp, y.t.data_ptr()), i=i))
+        self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), rp, y.t.data_ptr()), i=i, f=(m.get("oscale", 1.0),)))
         self.taps[name] = y
         return y
 
@@ -262,7 +269,7 @@ class ProgramBuilder(graph.Visitor):
         wt, bt, m = self.w.t[name]
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: x.H, 5: x.W, 6: 4 * cout, 7: 1, 8: 1, 9: 0, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
              16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 1, 21: m["Cout_pad"]}
-        self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.t.data_ptr()), i=i))
+        self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.t.data_ptr()), i=i, f=(m.get("oscale", 1.0),)))
         self.taps[name] = y
         return y
 
