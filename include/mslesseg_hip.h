@@ -228,6 +228,7 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
 
 /* hipGraph capture of a program: launch-bound inner loops (batch-1 predict, ~110 small kernels) replay as one graph. */
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out);
+int msl_graph_create_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream, void** graph_exec_out); /* a program with lanes: fork / join become graph edges */
 int msl_graph_launch(void* graph_exec, void* stream);
 int msl_graph_destroy(void* graph_exec);
 

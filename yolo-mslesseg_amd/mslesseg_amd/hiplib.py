@@ -21,7 +21,7 @@ OP_CONV_WGRAD, OP_DW_WGRAD, OP_STEM_WGRAD, OP_CAST_PAD, OP_GATHER_CAST, OP_ADAMW
 OP_SEG_LOSS, OP_ATTENTION_BWD, OP_SLICE_EXTRACT, OP_SGD, OP_AUGMENT, OP_RASTER_MASKS, OP_MASK_IOU = 33, 34, 35, 36, 37, 38, 39
 
 EXPORTS = (
-    "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_launch",
+    "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_create_lanes", "msl_graph_launch",
     "msl_graph_destroy", "msl_event_create", "msl_event_record", "msl_event_elapsed_ms", "msl_event_destroy",
     "msl_seg_loss_workspace", "msl_conv2d_nhwc", "msl_letterbox_u8", "msl_nms", "msl_volume_consensus", "msl_volume_dice_sums",
     "msl_conv2d_wgrad_nhwc", "msl_bn_act_fwd", "msl_bn_act_bwd", "msl_seg_loss", "msl_adamw",
@@ -119,7 +119,10 @@ class Program:
 
     def capture(self, stream: int) -> None:
         g = C.c_void_p()
-        check(lib().msl_graph_create(self.arr, self.n, C.c_void_p(stream), C.byref(g)), "msl_graph_create")
+        if self.lanes is not None:
+            check(lib().msl_graph_create_lanes(self.arr, self.lanes, self.n, C.c_void_p(stream), C.byref(g)), "msl_graph_create_lanes")
+        else:
+            check(lib().msl_graph_create(self.arr, self.n, C.c_void_p(stream), C.byref(g)), "msl_graph_create")
         self._graph = g
 
     def replay(self, stream: int) -> None:

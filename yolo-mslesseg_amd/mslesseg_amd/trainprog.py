@@ -787,6 +787,7 @@ class TrainPlan(graph.Visitor):
         def prog(ops):
             return hiplib.Program(ops, lanes=[getattr(o, "_lane", 0) for o in ops])
 
+        self._graphs = os.environ.get("MSL_TRAIN_GRAPH", "0") == "1"
         self.forward_segments = [prog(s) if isinstance(s, list) and s else s for s in self._fwd if not (isinstance(s, list) and not s)]
         self.backward_segments = [prog(s) if isinstance(s, list) and s else s for s in bwd_segments if not (isinstance(s, list) and not s)]
         for dt, ar in self._arena.items():
@@ -802,6 +803,11 @@ class TrainPlan(graph.Visitor):
         s = torch.cuda.current_stream(self.device).cuda_stream
         for seg in segments:
             if isinstance(seg, hiplib.Program):
+                if self._graphs and seg.n > 8:  # MSL_TRAIN_GRAPH=1: replay the program (lanes included) as a hipGraph; the first call runs eagerly (kernel attributes are set on first launch)
+                    if getattr(seg, "_warm", False):
+                        seg.replay(s)
+                        continue
+                    seg._warm = True
                 seg.run(s)
             else:
                 seg()
