@@ -73,6 +73,7 @@ enum {
    *    23 (with p 5 = BatchNorm accumulator f64[slots][2*Cout]: the conv also adds (sum z, sum z^2) of the values it stores, raw convs only)
    *       number of accumulator slots (<= 16); store mode 2: the lattice bits above; LDS 3x3 kernel selectors for measurements and tests:
    *       -8 = tile-per-workgroup kernel, -9 = persistent weights-resident kernel (when it exists for the shape), -4 = 16x32 tile,
+   *       -7 = full-width halo image for 8 / 16-channel inputs (default: dense slots where they measure faster), -6 = dense slots wherever they exist,
    *    25 weight layout: 0 = GEMM rows above (generic kernel); 1 = LDS image for the tiled 3x3 kernel (k=3, pad=1, stride 1|2,
    *       Cin % chunk == 0 with chunk = 32 bf16 / 16 fp32, Cout % 16 == 0):
    *       w[cout_blk][chunk][tap=ky*3+kx][g 0..3][COB][16 bytes], element e of (.., g, col, .) = W[cout_blk*COB+ch(col)][chunk*CH*4+g*CH+e][ky][kx],

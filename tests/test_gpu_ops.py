@@ -732,6 +732,31 @@ def test_slice_extract_device_matches_host_restatement(plano, mejora, demo_volum
             assert nd == 0, f"{plano} slice {i} {mejora}: {nd} differing bytes, max |d| {int(np.abs(got[j].astype(int) - want.astype(int)).max())}"
 
 
+@pytest.mark.parametrize("case", [(3, 64, 72, 16, 32, 2), (2, 50, 70, 8, 16, 1), (2, 33, 41, 16, 8, 1), (1, 40, 40, 8, 32, 2), (2, 24, 100, 16, 16, 1)])
+def test_conv3x3_dense_halo_slots_equal_the_full_width_image(case):
+    """Narrow bf16 3x3 layers (8 / 16 input channels) stage a halo image with one or two k-groups per slot (halo_byte_kg) instead of four with
+    the missing ones fetched from the zero page (i[23] = -7 keeps that form): the same MFMAs on the same operands, so the outputs are bit-equal."""
+    N, H, W, Cin, Cout, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    x = _rand_act((N, H, W, Cin), MSL_BF16, g).to(DEV)
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cin * 9) ** 0.5)
+    b = torch.rand(Cout, generator=g) - 0.5
+    wt, bt, m = E.pack_conv3x3_lds(w, b, MSL_BF16, DEV)
+    outs = []
+    for sel in (-6, -7):  # -6: dense slots also where the dispatch rule would not take them (two k-groups at stride 1)
+        y = torch.full((N, Ho, Wo, Cout), 3.0, dtype=torch.bfloat16, device=DEV)
+        op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(x.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.data_ptr()),
+                            i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: Cin, 11: 0, 12: Cout, 13: 0, 14: Cout, 15: 0,
+                               16: m["K"], 17: m["Kpad"], 18: 1, 19: 0, 20: 0, 21: m["Cout_pad"], 23: sel, 24: m["cot"], 25: 1})
+        hiplib.launch(op, _stream())
+        torch.cuda.synchronize()
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = F.silu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b, stride=s, padding=1)).permute(0, 2, 3, 1)
+    _close(outs[0], ref, MSL_BF16, f"dense halo {case}")
+
+
 @pytest.mark.parametrize("kind", ["3x3", "3x3s2", "1x1", "1x1wide"])
 def test_split_precision_products_are_fp32_grade(kind):
     """MSL_F32S (every conv product as three f16 partial products, operands split hi + lo) against a float64 reference, beside the exact fp32

@@ -54,6 +54,18 @@ struct Tile3 {
 
 // byte address of halo slot s, k-group g in the rotated pixel-major image (see the header)
 __device__ __forceinline__ int halo_byte(int s, int g) { return ((s >> 2) << 8) + ((((s & 3) << 2) + ((g + (s >> 2)) & 3)) << 4); }
+// The same image with KG < 4 k-groups per slot (narrow layers: Cin = 8 or 16 bf16 channels fill one or two of a chunk's four 16-byte groups): a slot
+// is 16*KG bytes, a 256-byte row holds 16/KG slots, the group position is still rotated by the row index.  The full-width image staged 64 bytes per
+// pixel for 16 or 32 valid ones — half or three quarters of the LDS-DMA instructions of these layers fetched the zero page (model.1, the 320² -> 160²
+// stride-2 conv, was the longest launch of the step at 26 % of the HBM rate).  16 consecutive slots of one group still fall on 16 distinct 16-byte
+// columns: KG = 2: 8 slots of a row on alternating columns, the next row shifted by one; KG = 1: 16 consecutive columns.
+template <int KG>
+__device__ __forceinline__ int halo_byte_kg(int s, int g) {
+  if constexpr (KG == 4) return halo_byte(s, g);
+  constexpr int SPR = 16 / KG;
+  const int row = s / SPR, q = s - row * SPR;
+  return (row << 8) + ((q * KG + ((g + row) & (KG - 1))) << 4);
+}
 
 // Epilogue of one pixel for a lane: the lane's 4*COT accumulator values are CONSECUTIVE output channels starting at co0 (weight rows are
 // packed in that order, include/mslesseg_hip.h op.i[25]): bias, optional statistics of the stored values, SiLU, residual, 16-byte stores.
@@ -158,11 +170,12 @@ __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co
   store_pixel_b<F32, COT>(a, pix, co0, accp, s1, s2, bias);
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false>  // SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4>  // KG: k-groups per halo slot (halo_byte_kg); SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
 // image arrives pre-split from the host; every lane rewrites the 16 bytes of the halo tile it staged itself as (hi x 4 | lo x 4) once per chunk,
 // so the nine taps read ready-made f16 operands and the MFMA loop carries no conversion
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");
+  static_assert(KG == 4 || (!F32 && (KG == 1 || KG == 2)), "dense halo slots: bf16 layers of 8 or 16 input channels");
   using T = Tile3<S, RW, KH>;
   constexpr int NT = KH * KW;            // taps: 3x3 (pad 1), or the 1x1 / 1x2 / 2x1 / 2x2 kernels (pad 0) of the stride-2 input gradient's parity classes
   constexpr int PAD = KH == 3 ? 1 : 0;
@@ -170,7 +183,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   constexpr int CHUNK = 64 / ES;          // channels per chunk (4 groups x 16 B)
   constexpr int COB = COT * 16;
   constexpr int PT = 2 * RW;              // pixel tiles per wave: RW rows x 2 column halves
-  constexpr int IN_BYTES = T::PIECES * 1024;
+  constexpr int SPP = 64 / KG;            // halo slots per 1-KiB LDS-DMA piece (4 rows of 16 / KG slots)
+  constexpr int IN_PIECES = (T::SLOTS + SPP - 1) / SPP;
+  constexpr int IN_BYTES = IN_PIECES * 1024;
   constexpr int W_BYTES = NT * 4 * COB * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_in = smem;
@@ -202,18 +217,17 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   const int nchunks = (a.Cin + CHUNK - 1) / CHUNK;  // whole chunks, or one partial chunk whose missing k-group planes are staged as zeros
   const char* wblk = a.w + (long)cob * nchunks * W_BYTES;
 
-  // ---- per-lane staging sources, computed once: piece pc covers halo slots 16*pc .. 16*pc+15; lane = (row of 4 pixels, 16-byte position)
-  constexpr int IN_PIECES = T::PIECES;
+  // ---- per-lane staging sources, computed once: piece pc covers halo slots SPP*pc .. SPP*pc + SPP-1; lane = (row of 16 / KG pixels, 16-byte position)
   constexpr int IN_PER_WAVE = (IN_PIECES + 3) / 4;
   constexpr int W_PIECES = W_BYTES / 1024;
   int in_off[IN_PER_WAVE];  // byte offset inside the image view of this lane's 16 bytes (chunk 0), or -1 → zero page
   {
     const int row4 = lane >> 4, pos = lane & 15;
-    const int gq = ((pos & 3) - row4) & 3;  // k-group stored at this position (rotation by the row index; 4*pc is a multiple of 4)
+    const int gq = ((pos & (KG - 1)) - row4) & (KG - 1);  // k-group stored at this position (rotation by the row index; 4*pc is a multiple of 4)
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
       const int pc = wave + 4 * j;
-      const int sl = pc * 16 + row4 * 4 + (pos >> 2);
+      const int sl = pc * SPP + row4 * (16 / KG) + pos / KG;
       int r, c;
       if constexpr (S == 1) {
         r = sl / T::ROWP;
@@ -273,7 +287,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
         int slot;
         if constexpr (S == 1) slot = (row + ty) * T::ROWP + col + tx;
         else slot = ((2 * row + ty) * 2 + (tx & 1)) * T::ROWP + col + (tx >> 1);
-        B[p] = *(const uint4*)(s_in + halo_byte(slot + lp, g));
+        if constexpr (KG == 4) B[p] = *(const uint4*)(s_in + halo_byte(slot + lp, g));
+        else B[p] = g < KG ? *(const uint4*)(s_in + halo_byte_kg<KG>(slot + lp, g)) : make_uint4(0u, 0u, 0u, 0u);  // the chunk's other k-groups: zero input channels
       }
     };
     fetch(0, av[0], bv[0]);
@@ -360,19 +375,19 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4>
 static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<S, RW, KH>;
-  constexpr int LDS = T::PIECES * 1024 + KH * KW * 4 * COT * 16 * 16;
+  constexpr int LDS = (T::SLOTS + 64 / KG - 1) / (64 / KG) * 1024 + KH * KW * 4 * COT * 16 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   Conv3Args b = a;
   b.cout_blocks = cout_blocks;
   dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * cout_blocks));
-  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT>), grid, dim3(256), LDS, s, b);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG>), grid, dim3(256), LDS, s, b);
   MSL_CHECK_LAUNCH("conv3x3_lds");
   return MSL_OK;
 }
@@ -996,6 +1011,21 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     // (measured and rejected: 16 x 32 tiles for whole 64-channel blocks, which halve the weight slab re-staged per pixel — proto.cv2 0.965 -> 1.18 ms)
     if (stride == 2) L3S(2, 1); else L3S(1, 2);
 #undef L3S
+  }
+  // narrow bf16 layers (8 or 16 input channels = one or two of the chunk's four k-groups): dense halo slots (halo_byte_kg); i[23] = -7 keeps the
+  // full-width image (A/B measurements and tests)
+  // measured at batch 128 (scripts/dev_narrow3x3_ab.py, profiles/r03h_narrow3x3_ab.txt): 320² 16->32 s2 0.263 -> 0.199 ms, 160² 8->16 0.094 -> 0.065 ms;
+  // two k-groups at stride 1 are SLOWER than the full-width image (160² 16->8 0.081 -> 0.091, 16->16 0.083 -> 0.093): taken only when i[23] = -6 asks
+  const int kg = (!f32 && a.Cin < chunk && a.Cin % 8 == 0 && op.i[23] != -7) ? a.Cin / 8 : 4;
+  if ((kg == 1 || (kg == 2 && (stride == 2 || op.i[23] == -6))) && cot <= 2 && rw != 4) {
+#define L3D(S_, RW_, KG_)                                                                     \
+  do {                                                                                         \
+    if (cot == 2) return launch3<false, S_, RW_, 2, 3, 3, false, KG_>(a, cout_blocks, s);      \
+    return launch3<false, S_, RW_, 1, 3, 3, false, KG_>(a, cout_blocks, s);                    \
+  } while (0)
+    if (stride == 2) { if (kg == 2) L3D(2, 1, 2); else L3D(2, 1, 1); }
+    else { if (kg == 2) L3D(1, 2, 2); else L3D(1, 2, 1); }
+#undef L3D
   }
   if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else L3(true, 1, 2); }
   else     { if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
