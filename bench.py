@@ -590,7 +590,10 @@ def fit_epoch_bench(args, dev, rank, world, state, dist):
     return {"train_slices": len(tr_ds), "val_slices": len(va_ds), "per_gpu_batch": B, "iterations_per_epoch": tr.nb, "epochs_timed": len(et), "fit_wall_s": round(wall, 2),
             "epoch_s": round(epoch_s, 4), "per_rank_train_val_ckpt_s": [[round(v, 4) for v in r] for r in allr],
             "rank0_only_s": round(allr[0][2], 4), "rank0_only_share_of_epoch": round(allr[0][2] / epoch_s, 4),
-            "note": "medians over the timed epochs; validation is sharded over the ranks (train._validate), checkpoints are written by a thread from a pinned-host snapshot"}, tr
+            "note": "medians over the timed epochs; epoch_s = wall time per epoch (max over ranks).  Nothing synchronises with the host inside an epoch any more, so the "
+                    "per-phase seconds are host ENQUEUE times (the train phase returns early, the validation phase then waits on the queue): read epoch_s.  "
+                    "Validation is sharded over the ranks (train._validate); on one rank its host half (AP curves) and the checkpoints run in a writer "
+                    "thread behind the next epoch's steps"}, tr
 
 
 def train_e2e_bench(args, dev, rank, world, state, B):

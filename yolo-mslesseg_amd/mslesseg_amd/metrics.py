@@ -102,7 +102,9 @@ def ap_per_class(tp: np.ndarray, conf: np.ndarray, pred_cls: np.ndarray, target_
         n_l, n_p = nt[ci], int(i.sum())
         if n_p == 0 or n_l == 0:
             continue
-        fpc, tpc = (1 - tp[i]).cumsum(0), tp[i].cumsum(0)
+        tpi = tp[i]
+        tpc = tpi.cumsum(0)
+        fpc = np.arange(1, n_p + 1, dtype=tpc.dtype)[:, None] - tpc  # = (1 - tp).cumsum(0) for 0/1 matches, without a second pass
         recall = tpc / (n_l + eps)
         precision = tpc / (tpc + fpc)
         r_curve[ci] = np.interp(-px, -conf[i], recall[:, 0], left=0)
@@ -169,10 +171,10 @@ class SegStats:
         self.conf.append(pred_conf.cpu().numpy())
         self.pcls.append(pred_cls.cpu().numpy().astype(np.int64))
 
-    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts=None, first_id=None) -> None:
-        """A whole batch at once, matched on the device (`match_batch`): pred_* [B,P,…] with the first n_pred[b] rows valid, gt_* [B,G,…] with the
-        first n_gt[b] rows valid; masks as [B,·,pixels] {0,1} floats on one pixel grid — or `mask_counts` = (intersection [B,P,G], prediction
-        areas [B,P], ground-truth areas [B,G]) as MSL_OP_MASK_IOU counts them, in which case no mask tensor is needed."""
+    @staticmethod
+    def match_on_device(pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts=None):
+        """Device half of `add_batch`: the whole batch matched by tensor programs (`match_batch`), nothing transferred → the seven tensors
+        `add_matched` takes (box matches [B,P,10], mask matches, confidences, classes, valid-prediction mask, valid-gt mask, gt classes)."""
         B, P = pred_conf.shape
         G = gt_cls.shape[1]
         dev = pred_conf.device
@@ -195,8 +197,12 @@ class SegStats:
             cm = match_batch(mi / (union + 1e-7), same)
         else:
             cb = cm = torch.zeros(B, P, len(IOUV), dtype=torch.bool, device=dev)
-        cb, cm, conf, pcls, pvh = cb.cpu().numpy(), cm.cpu().numpy(), pred_conf.cpu().numpy(), pred_cls.cpu().numpy(), pv.cpu().numpy()
-        gvh, tcls = gv.cpu().numpy(), gt_cls.cpu().numpy()
+        return cb, cm, pred_conf, pred_cls, pv, gv, gt_cls
+
+    def add_matched(self, matched, first_id=None) -> None:
+        """Host half: `matched` = the tensors of `match_on_device`, on the device or already copied to the host."""
+        cb, cm, conf, pcls, pvh, gvh, tcls = (t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t) for t in matched)
+        B = conf.shape[0]
         first = self._next if first_id is None else int(first_id)
         self._next = first + B
         for b in range(B):
@@ -208,6 +214,12 @@ class SegStats:
                 self.tp_m.append(cm[b][pvh[b]])
                 self.conf.append(conf[b][pvh[b]])
                 self.pcls.append(pcls[b][pvh[b]].astype(np.int64))
+
+    def add_batch(self, pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts=None, first_id=None) -> None:
+        """A whole batch at once, matched on the device (`match_batch`): pred_* [B,P,…] with the first n_pred[b] rows valid, gt_* [B,G,…] with the
+        first n_gt[b] rows valid; masks as [B,·,pixels] {0,1} floats on one pixel grid — or `mask_counts` = (intersection [B,P,G], prediction
+        areas [B,P], ground-truth areas [B,G]) as MSL_OP_MASK_IOU counts them, in which case no mask tensor is needed."""
+        self.add_matched(self.match_on_device(pred_boxes, pred_conf, pred_cls, pred_masks, n_pred, gt_boxes, gt_cls, gt_masks, n_gt, mask_counts), first_id)
 
     def result(self) -> Dict[str, float]:
         tcls = np.concatenate(self.tcls) if self.tcls else np.zeros(0, np.int64)

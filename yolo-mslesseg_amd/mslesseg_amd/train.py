@@ -145,7 +145,9 @@ class CheckpointWriter:
             e, self.error = self.error, None
             raise RuntimeError(f"checkpoint writer failed: {e!r}") from e
 
-    def submit(self, extra: dict, is_best: bool):
+    def submit(self, job):
+        """Snapshot the EMA buffers (asynchronous copy on the caller's stream) and run `job(self)` in the writer thread once the copy — and
+        everything queued before it, e.g. the validation pass of the epoch — has finished.  `job` decides what to write and calls `write`."""
         self.wait()
         tr = self.tr
         self.hp.copy_(tr.ema_p, non_blocking=True)
@@ -156,16 +158,21 @@ class CheckpointWriter:
         def work():
             try:
                 ev.synchronize()
-                sd = tr.store.state_dict(p=self.hp, b=self.hb)
-                last, best = tr.wdir / "last.pt", tr.wdir / "best.pt"
-                params.save_checkpoint(last, sd, tr.store.scale, tr.nc, tr.names, extra)
-                if is_best:
-                    shutil.copyfile(last, best)  # the same bytes: one serialisation per epoch
+                job(self)
             except BaseException as e:  # surfaced by wait()
                 self.error = e
 
         self.thread = threading.Thread(target=work, daemon=True)
         self.thread.start()
+
+    def write(self, extra: dict, is_best: bool) -> None:
+        """(writer thread) last.pt from the snapshot; best.pt = the same bytes when the fitness improved."""
+        tr = self.tr
+        sd = tr.store.state_dict(p=self.hp, b=self.hb)
+        last, best = tr.wdir / "last.pt", tr.wdir / "best.pt"
+        params.save_checkpoint(last, sd, tr.store.scale, tr.nc, tr.names, extra)
+        if is_best:
+            shutil.copyfile(last, best)  # the same bytes: one serialisation per epoch
 
 
 class Trainer:
@@ -203,7 +210,7 @@ class Trainer:
         # the slice cache of `cache=True` lives in HBM and batches are augmented there (augment.py); device_augment=False keeps the NumPy path of data.py
         self.aug = self.val_aug = None
         self._aug_stream = None
-        self._val_engine, self._val_loss_ops, self._ckpt = None, None, None
+        self._val_engine, self._val_loss_ops, self._ckpt, self._pin = None, None, None, {}
         if self.hyp["device_augment"]:
             from .augment import DeviceAugmenter, SliceCache
 
@@ -410,7 +417,7 @@ class Trainer:
 
     # ------------------------------------------------------------------ validation (held-out fold, EMA weights, eval-mode BatchNorm)
     @torch.no_grad()
-    def _validate(self):
+    def _validate(self, deferred: bool = False):
         """One eval-mode pass over the held-out fold with the EMA weights → (val losses [4], metrics dict | None)  [UPSTREAM SegmentationValidator:
         the validator runs the EMA model in eval mode (running BatchNorm statistics), accumulates v8SegmentationLoss on its raw head outputs for
         the val/* columns and scores NMS(conf 0.001, IoU 0.7, max_det 300) detections for box/mask P, R, mAP50, mAP50-95].  Masks are compared at
@@ -421,12 +428,17 @@ class Trainer:
         all-gather of the small host-side records (per-image match rows, per-batch loss items) rebuilds on every rank exactly the lists a single
         rank would hold — ultralytics validates on rank 0 alone, which at this trainer's step rate would leave N-1 GPUs idle for a time
         comparable to the epoch's training steps (0.3 s of 0.7 s on one GPU).  Eval-mode outputs do not depend on what else is in the batch, so
-        the metrics equal the single-rank run's (tests/test_gpu_ddp_rehearsal.py)."""
+        the metrics equal the single-rank run's (tests/test_gpu_ddp_rehearsal.py).
+
+        Two halves: the device half (forward, NMS, loss op, mask counts, matching — all enqueued, results copied to pinned host buffers by
+        asynchronous copies) and the host half (per-image rows, AP curves: tens of milliseconds of NumPy).  `deferred=True` returns the host half
+        as a callable instead of running it: a single-rank `fit()` hands it to the checkpoint-writer thread, so the next epoch's steps are
+        queued while the previous epoch's metrics are still being computed."""
         from . import metrics as MT
         from .engine import InferEngine
 
         if self.val_ds is None or len(self.val_ds) == 0:
-            return np.zeros(4), None
+            return (lambda: (np.zeros(4), None)) if deferred else (np.zeros(4), None)
         S, n = self.hyp["imgsz"], len(self.val_ds)
         limit = min(n, self.hyp.get("val_max") or n)
         sd = self.store.state_dict(p=self.ema_p, b=self.ema_b, on_device=True)  # EMA weights stay on the GPU: BN folding and packing run there
@@ -436,10 +448,12 @@ class Trainer:
         else:
             self._val_engine.refresh(sd)
         eng, loss_ops = self._val_engine, self._val_loss_ops
-        stats = MT.SegStats()
         bounds = val_batches(limit, self.batch, self.world)
         mine = list(range(self.rank, len(bounds), self.world))
         items = torch.zeros(max(len(mine), 1), 4, dtype=torch.float32, device=self.device)  # per-batch loss items, one transfer at the end
+        if self._ckpt is not None:
+            self._ckpt.wait()  # the previous epoch's deferred host half still reads the pinned result buffers this pass is about to refill
+        host = []  # per batch: (first slice index, the seven match tensors in pinned host memory)
         for k, bi in enumerate(mine):
             b0, b1 = bounds[bi]
             idx = list(range(b0, b1))
@@ -459,7 +473,7 @@ class Trainer:
                 loss_ops[nb_] = SegLossOp(lv, lv, plan.proto, plan.proto, self.nc, S, S, self.dtype, self.device)  # no_grad: the gradient views are never written
             items[k].copy_(loss_ops[nb_](gt, masks_d, no_grad=True)[:4])
             # metrics: mask areas / intersections counted by MSL_OP_MASK_IOU from the low-res logits, the whole batch matched on the device
-            # (metrics.SegStats.add_batch), one transfer per batch
+            # (metrics.SegStats.match_on_device); the results go to pinned host buffers by asynchronous copies — no host synchronisation here
             mh, mw = plan.proto.H, plan.proto.W
             det = plan.det[:nb_]                                                    # [nb, max_det, 40]: xyxy, conf, cls, coefficients
             G = int(gt.shape[1])
@@ -473,32 +487,61 @@ class Trainer:
                                                                              inter.data_ptr(), parea.data_ptr(), garea.data_ptr()),
                                              i={0: nb_, 1: mh, 2: mw, 3: G, 7: det.shape[1], 8: S, 9: S}), torch.cuda.current_stream(self.device).cuda_stream)
                 counts = (inter, parea, garea)
-            stats.add_batch(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt, mask_counts=counts,
-                            first_id=b0)
-        mine_items = items[: len(mine)].cpu().numpy().astype(np.float64)
-        parts = gather_objects({"batches": mine, "items": mine_items, "stats": stats.export()}, self.world)
-        per_batch = np.zeros((len(bounds), 4))
-        for part in parts:
-            for bi, it in zip(part["batches"], part["items"]):
-                per_batch[bi] = it
-        tot = np.zeros(4)
-        for bi in range(len(bounds)):  # summed in fold order whatever rank computed the batch
-            tot += per_batch[bi]
-        allstats = stats if self.world == 1 else MT.SegStats.merged([part["stats"] for part in parts])
-        return tot / max(len(bounds), 1), allstats.result()
+            matched = MT.SegStats.match_on_device(det[..., :4], det[..., 4], det[..., 5], None, plan.keep_cnt[:nb_].long(), gt[..., 1:5], gt[..., 0], None, n_gt,
+                                                  mask_counts=counts)
+            host.append((b0, tuple(self._pinned(("val", bi, j), t) for j, t in enumerate(matched))))
+        items_h = self._pinned(("val", "items"), items)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        n_mine, n_bounds = len(mine), len(bounds)
+
+        def finish():
+            """Host half (may run in the writer thread): per-image rows, the merge over ranks, AP."""
+            done.synchronize()
+            stats = MT.SegStats()
+            for b0, tensors in host:
+                stats.add_matched(tuple(t.numpy() for t in tensors), first_id=b0)
+            mine_items = items_h[:n_mine].numpy().astype(np.float64)
+            parts = gather_objects({"batches": mine, "items": mine_items, "stats": stats.export()}, self.world)
+            per_batch = np.zeros((n_bounds, 4))
+            for part in parts:
+                for bi, it in zip(part["batches"], part["items"]):
+                    per_batch[bi] = it
+            tot = np.zeros(4)
+            for bi in range(n_bounds):  # summed in fold order whatever rank computed the batch
+                tot += per_batch[bi]
+            allstats = stats if self.world == 1 else MT.SegStats.merged([part["stats"] for part in parts])
+            return tot / max(n_bounds, 1), allstats.result()
+
+        return finish if deferred else finish()
+
+    def _pinned(self, key, t: torch.Tensor) -> torch.Tensor:
+        """Asynchronous device → pinned-host copy of `t` on the current stream (buffers cached per key and shape)."""
+        buf = self._pin.get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            self._pin[key] = buf
+        buf.copy_(t, non_blocking=True)
+        return buf
 
     # ------------------------------------------------------------------ files
-    def _save(self, epoch: int, fitness: float) -> None:
-        """last.pt every epoch, best.pt when the fitness improved [UPSTREAM BaseTrainer.save_model] — written by the CheckpointWriter thread from
-        a pinned-host snapshot of the EMA buffers, so the training stream only pays for the 11 MB device-to-host copy."""
+    def _finish_epoch(self, writer, epoch: int, tl, lr: float, val_finish) -> None:
+        """Host tail of an epoch (rank 0; in the writer thread when validation is deferred): validation's host half → results.csv row →
+        last.pt every epoch, best.pt when the fitness improved [UPSTREAM BaseTrainer.save_model]."""
+        vl, mets = val_finish()
+        fitness = mets["fitness"] if mets else -float(tl.sum())
+        mcols = [float(mets[c]) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
+        row = [epoch + 1, time.time() - self.t0] + [float(x) for x in tl] + mcols + [float(x) for x in vl] + [lr] * 3
+        with open(self.save_dir / "results.csv", "a", newline="") as f:
+            f.write(",".join([str(row[0])] + [f"{v:.6g}" for v in row[1:]]) + "\n")  # six significant digits, as the reference's files carry
         is_best = self.best_fitness is None or fitness >= self.best_fitness
         if is_best:
             self.best_fitness = fitness
         extra = {"epoch": epoch, "best_fitness": self.best_fitness, "train_args": {"data": self.data_path, "epochs": self.epochs, "batch": self.batch,
                                                                                      "imgsz": self.hyp["imgsz"], "optimizer": self.optimizer, "lr0": self.lr0}}
-        if self._ckpt is None:
-            self._ckpt = CheckpointWriter(self)
-        self._ckpt.submit(extra, is_best)
+        writer.write(extra, is_best)
+        if self.verbose:
+            print(f"epoch {epoch + 1}/{self.epochs} train {tl.round(4)} val {np.asarray(vl).round(4)} lr {lr:.6g}", flush=True)
 
     def _write_args(self) -> None:
         """args.yaml with the reference's keys and value types [REF trains/Base/FLAIR_P50c_5folds_50epochs/axial/fold1/args.yaml]: `optimizer` is what
@@ -542,19 +585,20 @@ class Trainer:
                 if self.max_iters is not None and ni >= self.max_iters:
                     done = True
                     break
-            tl = tl_dev.cpu().numpy().astype(np.float64) / max(nb_seen, 1)
             te1 = time.perf_counter()
-            vl, mets = self._validate()  # every rank scores its share of the held-out fold
+            if self._ckpt is not None:
+                self._ckpt.wait()  # the previous epoch's host tail (it ran behind this epoch's steps) is done with the pinned buffers refilled below
+            tl_h = self._pinned(("train", "items"), tl_dev)  # read by the host tail, after the event the writer waits for
+            nb_done = max(nb_seen, 1)
+            # every rank scores its share of the held-out fold.  One rank: only the device half runs here, the host half rides in the writer thread
+            # behind the next epoch's steps; several ranks: the gather of the match records is a collective, so the host half runs here
+            val_finish = self._validate(deferred=(self.world == 1))
             te2 = time.perf_counter()
-            fitness = mets["fitness"] if mets else -float(tl.sum())
             if self.rank == 0:
-                mcols = [float(mets[c]) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
-                row = [epoch + 1, time.time() - self.t0] + [float(x) for x in tl] + mcols + [float(x) for x in vl] + [lr] * 3
-                with open(self.save_dir / "results.csv", "a", newline="") as f:
-                    f.write(",".join([str(row[0])] + [f"{v:.6g}" for v in row[1:]]) + "\n")  # six significant digits, as the reference's files carry
-                self._save(epoch, fitness)
-                if self.verbose:
-                    print(f"epoch {epoch + 1}/{self.epochs} train {tl.round(4)} val {vl.round(4)} lr {lr:.6g}", flush=True)
+                if self._ckpt is None:
+                    self._ckpt = CheckpointWriter(self)
+                fin = val_finish if self.world == 1 else (lambda r=val_finish: r)
+                self._ckpt.submit(lambda w, e=epoch, l=lr, f=fin, n=nb_done: self._finish_epoch(w, e, tl_h.numpy().astype(np.float64) / n, l, f))
             self.epoch_times.append({"train_s": te1 - te0, "val_s": te2 - te1, "ckpt_s": time.perf_counter() - te2, "iterations": nb_seen})
             if done:
                 break
