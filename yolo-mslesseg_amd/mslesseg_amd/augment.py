@@ -90,6 +90,7 @@ class SliceCache:
         for i in range(self.n):
             groups.setdefault(tuple(raw[i][0].shape[:2]), []).append(i)
         st = torch.cuda.current_stream(self.device).cuda_stream
+        keep = []
         for (h, w), idx in groups.items():
             nh, nw, _, Mi = D.resize_geometry(h, w, ds.imgsz)
             for c0 in range(0, len(idx), 1024):
@@ -108,10 +109,17 @@ class SliceCache:
                     out.copy_(src)
                 else:
                     hiplib.launch(hiplib.make_op(hiplib.OP_AUGMENT, hiplib.MSL_F32, p=(src.data_ptr(), recd.data_ptr(), 0, 0, out.data_ptr()), i={0: len(part), 1: nh, 2: nw}), st)
-                flat = out.reshape(len(part), -1)
-                for j, i in enumerate(part):
-                    buf[self.off[i] : self.off[i] + nh * nw * 3] = flat[j]
-                torch.cuda.synchronize(self.device)  # src / recd are released after the launch has consumed them
+                flat = out.reshape(-1)
+                L = nh * nw * 3
+                j = 0
+                while j < len(part):  # runs of slices that are neighbours in the cache too (a dataset lists a plane's slices together): one copy per run
+                    k = j + 1
+                    while k < len(part) and self.off[part[k]] == self.off[part[k - 1]] + L:
+                        k += 1
+                    buf[self.off[part[j]] : self.off[part[j]] + (k - j) * L] = flat[j * L : k * L]
+                    j = k
+                keep.append((src, recd, out))  # released after the one synchronisation below, once every launch has consumed them
+        torch.cuda.synchronize(self.device)
         return buf
 
 

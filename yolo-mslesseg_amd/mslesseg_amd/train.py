@@ -106,12 +106,19 @@ def allreduce_gradients(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
-def gather_objects(obj, world: int):
-    """[obj of rank 0, …, obj of rank world-1] on every rank (small host-side records: validation statistics).  Not on the training data path."""
+def gather_objects(obj, world: int, group=None, to_rank0: bool = False):
+    """[obj of rank 0, …, obj of rank world-1] on every rank — or, with `to_rank0`, on rank 0 only (None elsewhere).  Small host-side records
+    (validation statistics), not on the training data path; `group`: the process group to use (the trainer's validation group, so that the
+    writer threads' gathers never interleave with the main threads' gradient all-reduces)."""
     if world <= 1:
         return [obj]
+    dist = torch.distributed
+    if to_rank0:
+        out = [None] * world if dist.get_rank() == 0 else None
+        dist.gather_object(obj, out, dst=0, group=group)
+        return out
     out = [None] * world
-    torch.distributed.all_gather_object(out, obj)
+    dist.all_gather_object(out, obj, group=group)
     return out
 
 
@@ -133,8 +140,9 @@ class CheckpointWriter:
     def __init__(self, trainer):
         self.tr = trainer
         st = trainer.store
-        self.hp = torch.empty(st.p.numel(), dtype=torch.float32).pin_memory()
-        self.hb = torch.empty(st.b.numel(), dtype=torch.float32).pin_memory()
+        if trainer.rank == 0:  # only rank 0 writes files
+            self.hp = torch.empty(st.p.numel(), dtype=torch.float32).pin_memory()
+            self.hb = torch.empty(st.b.numel(), dtype=torch.float32).pin_memory()
         self.thread, self.error = None, None
 
     def wait(self):
@@ -145,13 +153,15 @@ class CheckpointWriter:
             e, self.error = self.error, None
             raise RuntimeError(f"checkpoint writer failed: {e!r}") from e
 
-    def submit(self, job):
-        """Snapshot the EMA buffers (asynchronous copy on the caller's stream) and run `job(self)` in the writer thread once the copy — and
-        everything queued before it, e.g. the validation pass of the epoch — has finished.  `job` decides what to write and calls `write`."""
+    def submit(self, job, snapshot: bool = True):
+        """Snapshot the EMA buffers (asynchronous copy on the caller's stream; `snapshot=False`: a rank that writes no files) and run `job(self)`
+        in the writer thread once the copy — and everything queued before it, e.g. the validation pass of the epoch — has finished.  `job`
+        decides what to write and calls `write`."""
         self.wait()
         tr = self.tr
-        self.hp.copy_(tr.ema_p, non_blocking=True)
-        self.hb.copy_(tr.ema_b, non_blocking=True)
+        if snapshot:
+            self.hp.copy_(tr.ema_p, non_blocking=True)
+            self.hb.copy_(tr.ema_b, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(tr.device))
 
@@ -195,6 +205,10 @@ class Trainer:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.distributed.init_process_group("nccl", device_id=self.device)
         self.yolo.device = str(self.device)  # predict()/val() after fit() run where the training ran (one process per GPU: never all on cuda:0)
+        # a process group of its own for the per-epoch gather of validation records: it is issued from the writer threads (one gather per epoch on
+        # every rank, in epoch order), so it must not share a communicator with the main threads' gradient all-reduces.  Host objects: gloo.
+        # (created at the start of fit(): gloo announces its connections on stdout, and a Trainer that only steps — bench.py — must stay silent)
+        self._val_group = None
         # ---- data
         self.names, self.nc = {0: "lesion"}, 1
         if dataset is None:
@@ -431,14 +445,15 @@ class Trainer:
         the metrics equal the single-rank run's (tests/test_gpu_ddp_rehearsal.py).
 
         Two halves: the device half (forward, NMS, loss op, mask counts, matching — all enqueued, results copied to pinned host buffers by
-        asynchronous copies) and the host half (per-image rows, AP curves: tens of milliseconds of NumPy).  `deferred=True` returns the host half
-        as a callable instead of running it: a single-rank `fit()` hands it to the checkpoint-writer thread, so the next epoch's steps are
-        queued while the previous epoch's metrics are still being computed."""
+        asynchronous copies) and the host half (per-image rows, the gather over ranks, AP curves: tens of milliseconds of NumPy).
+        `deferred=True` returns the host half as a callable instead of running it: `fit()` hands it to every rank's writer thread, so the next
+        epoch's steps are queued while the previous epoch's metrics are still being gathered and computed (the gather then runs on the trainer's
+        own validation process group, to rank 0 only)."""
         from . import metrics as MT
         from .engine import InferEngine
 
         if self.val_ds is None or len(self.val_ds) == 0:
-            return (lambda: (np.zeros(4), None)) if deferred else (np.zeros(4), None)
+            return (lambda to_rank0=False: (np.zeros(4), None)) if deferred else (np.zeros(4), None)
         S, n = self.hyp["imgsz"], len(self.val_ds)
         limit = min(n, self.hyp.get("val_max") or n)
         sd = self.store.state_dict(p=self.ema_p, b=self.ema_b, on_device=True)  # EMA weights stay on the GPU: BN folding and packing run there
@@ -495,14 +510,17 @@ class Trainer:
         done.record(torch.cuda.current_stream(self.device))
         n_mine, n_bounds = len(mine), len(bounds)
 
-        def finish():
-            """Host half (may run in the writer thread): per-image rows, the merge over ranks, AP."""
+        def finish(to_rank0: bool = False):
+            """Host half (may run in the writer thread): per-image rows, the merge over ranks, AP.  `to_rank0`: gather on the validation group to
+            rank 0 only — the other ranks return (None, None) — instead of an all-gather on the default group."""
             done.synchronize()
             stats = MT.SegStats()
             for b0, tensors in host:
                 stats.add_matched(tuple(t.numpy() for t in tensors), first_id=b0)
             mine_items = items_h[:n_mine].numpy().astype(np.float64)
-            parts = gather_objects({"batches": mine, "items": mine_items, "stats": stats.export()}, self.world)
+            parts = gather_objects({"batches": mine, "items": mine_items, "stats": stats.export()}, self.world, group=self._val_group if to_rank0 else None, to_rank0=to_rank0)
+            if parts is None:
+                return None, None
             per_batch = np.zeros((n_bounds, 4))
             for part in parts:
                 for bi, it in zip(part["batches"], part["items"]):
@@ -561,6 +579,8 @@ class Trainer:
     # ------------------------------------------------------------------ main loop
     def fit(self):
         self.t0 = time.time()
+        if self.world > 1 and self._val_group is None:
+            self._val_group = torch.distributed.new_group(backend="gloo")  # collective: every rank enters fit()
         if self.rank == 0:
             self._write_args()
             with open(self.save_dir / "results.csv", "w", newline="") as f:
@@ -590,15 +610,16 @@ class Trainer:
                 self._ckpt.wait()  # the previous epoch's host tail (it ran behind this epoch's steps) is done with the pinned buffers refilled below
             tl_h = self._pinned(("train", "items"), tl_dev)  # read by the host tail, after the event the writer waits for
             nb_done = max(nb_seen, 1)
-            # every rank scores its share of the held-out fold.  One rank: only the device half runs here, the host half rides in the writer thread
-            # behind the next epoch's steps; several ranks: the gather of the match records is a collective, so the host half runs here
-            val_finish = self._validate(deferred=(self.world == 1))
+            # every rank scores its share of the held-out fold: only the device half runs here; the host half (rows, gather to rank 0, AP, files)
+            # rides in every rank's writer thread behind the next epoch's steps
+            val_finish = self._validate(deferred=True)
             te2 = time.perf_counter()
+            if self._ckpt is None:
+                self._ckpt = CheckpointWriter(self)
             if self.rank == 0:
-                if self._ckpt is None:
-                    self._ckpt = CheckpointWriter(self)
-                fin = val_finish if self.world == 1 else (lambda r=val_finish: r)
-                self._ckpt.submit(lambda w, e=epoch, l=lr, f=fin, n=nb_done: self._finish_epoch(w, e, tl_h.numpy().astype(np.float64) / n, l, f))
+                self._ckpt.submit(lambda w, e=epoch, l=lr, f=val_finish, n=nb_done: self._finish_epoch(w, e, tl_h.numpy().astype(np.float64) / n, l, lambda: f(self.world > 1)))
+            else:
+                self._ckpt.submit(lambda w, f=val_finish: f(True), snapshot=False)
             self.epoch_times.append({"train_s": te1 - te0, "val_s": te2 - te1, "ckpt_s": time.perf_counter() - te2, "iterations": nb_seen})
             if done:
                 break
