@@ -157,9 +157,9 @@ enum {
                                      sums, block 0 writes them to p 1 and updates the running statistics at p 7 | NULL (variance at p7 + i16 floats);
                                      i 21 slots, f 0 eps, f 1 momentum; the accumulator is NOT reset (the caller zeroes it before the next pass) */
   MSL_OP_BN_ACT_BWD_REDUCE = 19,  /* acc f64[slots][2C] += (sum g, sum g*zhat), g = dy*act'(u); i[21] slots */
-  MSL_OP_BN_ACT_BWD_APPLY = 20,   /* dz = gamma*invstd*(g - s1/M - zhat*s2/M); dgamma = s2, dbeta = s1 */
+  MSL_OP_BN_ACT_BWD_APPLY = 20,   /* dz = gamma*invstd*(g - s1/M - zhat*s2/M); dgamma = s2, dbeta = s1 (i 17 = 1: added to what the buffers hold) */
   MSL_OP_COLSUM = 21,             /* acc f64[C] += column sums of a view (bias gradients) */
-  MSL_OP_F64_DRAIN = 22,          /* dst f32[n] = src f64[n*stride]; src = 0 */
+  MSL_OP_F64_DRAIN = 22,          /* dst f32[n] = src f64[n*stride] (i 4 = 1: dst +=); src = 0 */
   MSL_OP_ADD_VIEW = 23,           /* dst view (+)= src view (residual / concat gradient fan-in) */
   MSL_OP_UPSAMPLE2X_BWD = 24,     /* dx += 2x2 sums of dy */
   MSL_OP_SPPF_POOL_BWD = 25,      /* arg-max routing of the three pooled gradients into a fp32 scratch */

@@ -13,9 +13,60 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 
+class Remap:
+    """`ds` seen through an index map (the union-batch equivalence run below)."""
+
+    def __init__(self, ds, index):
+        self.ds, self.index, self.imgsz = ds, index, ds.imgsz
+
+    def __len__(self):
+        return len(self.index)
+
+    def get(self, i):
+        return self.ds.get(int(self.index[i]))
+
+
+def union_run(out, rank, world):
+    """One epoch, two optimizer steps, 16 slices, fp32 engine, no augmentation.  world 2: data parallel, 4 slices per rank and step.  world 1:
+    ONE rank that sees the same 8 slices per step as two micro-batches of 4 with gradient accumulation (nbs 8 / batch 4 → accumulate 2), the
+    micro-batches being exactly the two ranks' batches: the dataset is re-indexed so that the trainer's own dealing (train.shard_indices: a seeded
+    permutation P, rank r takes P[r::2]) puts slice P[8j + 2k + r] where the single rank's sequential batching reads P[8j + 4r + k].  Per-rank
+    BatchNorm statistics = per-micro-batch statistics, the summed gradient and the optimizer step are then the same arithmetic."""
+    import numpy as np
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mslesseg_amd import data as D
+    from mslesseg_amd.train import Trainer, shard_indices
+    from mslesseg_amd.yolo import YOLO
+
+    ds = D.SyntheticSegDataset(16, 128, seed=0)
+    if world == 1:
+        P = shard_indices(16, 0, 0, 0, 1)
+        index = np.zeros(16, np.int64)
+        for j in range(2):
+            for r in range(2):
+                for k in range(4):
+                    index[P[8 * j + 4 * r + k]] = P[8 * j + 2 * k + r]
+        ds = Remap(ds, index)
+    model = YOLO("yolo11n-seg.pt", precision="fp32")
+    tr = Trainer(model, dataset=ds, val_dataset=None, epochs=1, batch=4, project=out, name=f"union_w{world}", imgsz=128, nbs=8, warmup_epochs=0.0,
+                 augment=False, close_mosaic=0, optimizer="SGD")  # SGD: the update is linear in the gradient (Adam's first steps are sign(g): a
+    #                                                                gradient of rounding-noise size would flip a whole learning-rate step)
+    assert tr.sched.accumulate(0) == (1 if world == 2 else 2) and tr.nb == (2 if world == 2 else 4)
+    p0 = tr.store.p.cpu().clone()
+    tr.fit()
+    torch.save({"p0": p0, "p": tr.store.p.cpu(), "ema": tr.ema_p.cpu(), "steps": tr.opt_steps}, out / f"union_rank{rank}_of{world}.pt")
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     out = Path(sys.argv[1])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if len(sys.argv) > 2 and sys.argv[2] == "union":
+        return union_run(out, rank, world)
     import torch.distributed as dist
 
     if world > 1:

@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 WORKER = Path(__file__).with_name("ddp_worker.py")
 
 
-def _launch(out, world, port):
+def _launch(out, world, port, mode=None):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(WORKER), str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, str(WORKER), str(out)] + ([mode] if mode else []), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
@@ -54,3 +54,22 @@ def test_two_trainer_ranks_stay_identical_and_both_contribute(tmp_path):
     _launch(tmp_path, 1, 29532)
     solo = torch.load(tmp_path / "rank0_of1.pt", weights_only=True)
     assert float((solo["p"] - a["p"]).abs().max()) > 0
+
+
+def test_data_parallel_step_equals_one_rank_accumulating_the_union_batch(tmp_path):
+    """Equivalence, not only symmetry: two ranks x 4 slices per step against ONE rank that takes the same 8 slices per step as two micro-batches of
+    4 with gradient accumulation (the ranks' batches, re-created through the trainer's own dealing: tests/ddp_worker.py union_run).  BatchNorm
+    statistics are per rank in the data-parallel run and per micro-batch in the other — the same numbers — so the summed gradient, the AdamW step and
+    the EMA must agree to fp32 rounding (the loss op and the weight-gradient partial sums add in a different order)."""
+    _launch(tmp_path, 2, 29541, "union")
+    _launch(tmp_path, 1, 29542, "union")
+    dp = torch.load(tmp_path / "union_rank0_of2.pt", weights_only=True)
+    one = torch.load(tmp_path / "union_rank0_of1.pt", weights_only=True)
+    assert dp["steps"] == one["steps"] == 2
+    assert torch.equal(dp["p0"], one["p0"])
+    moved = float((dp["p"] - dp["p0"]).abs().max())
+    assert moved > 1e-3, "the two steps must have changed the parameters for the comparison to mean anything"
+    err = float((dp["p"] - one["p"]).abs().max())
+    print(f"union-batch equivalence: max |dp - accumulate| {err:.3e} for a largest parameter change of {moved:.3e}")
+    assert err <= 2e-3 * moved, (err, moved)
+    assert float((dp["ema"] - one["ema"]).abs().max()) <= 2e-3 * moved

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
-                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first) {
+                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first, int pacc) {
   __shared__ float ks[2048];  // (s1, s2) per channel, summed over the accumulator slots
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
@@ -334,7 +334,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
     double a = 0.0;
     for (int j = 0; j < slots; ++j) a += acc[(long)j * 2 * C + v];
     ks[v] = (float)a;
-    if (blockIdx.x == 0 && dgamma) { if (v & 1) dgamma[v >> 1] = (float)a; else dbeta[v >> 1] = (float)a; }
+    if (blockIdx.x == 0 && dgamma) {  // pacc: add to what the flat gradient holds (gradient accumulation over micro-batches), else overwrite
+      float* q = (v & 1) ? dgamma + (v >> 1) : dbeta + (v >> 1);
+      *q = pacc ? *q + (float)a : (float)a;
+    }
   }
   __syncthreads();
   if (pl >= PL) return;
@@ -411,7 +414,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
   }
 }
 
-// BN_ACT_BWD_APPLY: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc, 6 dz, 7 dgamma (dbeta = dgamma + i[20]) ; i as REDUCE + 14 dz_cs,15 dz_co, 20 dbeta offset (elements)
+// BN_ACT_BWD_APPLY: p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc, 6 dz, 7 dgamma (dbeta = dgamma + i[20]) ; i as REDUCE + 14 dz_cs,15 dz_co, 20 dbeta offset (elements),
+// 17 = 1: dgamma / dbeta are ADDED to what the buffers hold (the trainer's flat gradient accumulates over micro-batches), 0: overwritten
 // optional residual fan-out (i 16 = 1): p 4 = gradient view of the residual instead of beta (beta = gamma + i 22 elements), i 24 its stride, 25 its offset, 19 = 1 overwrite
 int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
@@ -433,7 +437,7 @@ int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
   float* dgamma = (float*)op.p[7];
   float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
-#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19]); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19]); } while (0)
+#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17]); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17]); } while (0)
   if (op.dtype == MSL_F32) { if (v8) BB(true, 8); else BB(true, 4); } else { if (v8) BB(false, 8); else BB(false, 4); }
 #undef BB
   MSL_CHECK_LAUNCH("bn_act_bwd_apply");
@@ -457,7 +461,7 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
 }
 
 // F64_TO_F32: dst f32[n] = (float)src f64[n]; src = 0 (drains a reduction accumulator into the flat gradient buffer)
-__global__ void f64_drain_kernel(double* __restrict__ src, float* __restrict__ dst, int n, int stride, int slots, int slot_stride) {
+__global__ void f64_drain_kernel(double* __restrict__ src, float* __restrict__ dst, int n, int stride, int slots, int slot_stride, int accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double a = 0.0;
@@ -466,12 +470,12 @@ __global__ void f64_drain_kernel(double* __restrict__ src, float* __restrict__ d
     a += *q;
     *q = 0.0;
   }
-  dst[i] = (float)a;
+  dst[i] = accumulate ? dst[i] + (float)a : (float)a;
 }
-// p 0 src f64, 4 dst f32 ; i 0 n, 1 stride, 2 slots (0 = 1), 3 elements between slot copies
+// p 0 src f64, 4 dst f32 ; i 0 n, 1 stride, 2 slots (0 = 1), 3 elements between slot copies, 4 = 1: dst += (bias gradients into the accumulating flat gradient)
 int msl_launch_f64_drain(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(op.p[0] && op.p[4] && op.i[0] > 0 && op.i[1] > 0 && op.i[2] >= 0 && (op.i[2] <= 1 || op.i[3] > 0), "f64_drain: bad args");
-  hipLaunchKernelGGL(f64_drain_kernel, dim3((op.i[0] + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[4], op.i[0], op.i[1], op.i[2] > 0 ? op.i[2] : 1, op.i[3]);
+  hipLaunchKernelGGL(f64_drain_kernel, dim3((op.i[0] + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[4], op.i[0], op.i[1], op.i[2] > 0 ? op.i[2] : 1, op.i[3], op.i[4]);
   MSL_CHECK_LAUNCH("f64_drain");
   return MSL_OK;
 }

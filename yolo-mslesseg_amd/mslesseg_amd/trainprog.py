@@ -443,7 +443,9 @@ class TrainPlan(graph.Visitor):
             papply = pcommon[:4] + (gr.t.data_ptr(),) + pcommon[5:]
             extra = {16: 1, 19: 1 if first else 0, 22: st.off(name + ".beta") - st.off(name + ".gamma"), 24: gr.cs, 25: gr.co}
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=papply + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
-                                  i={**dims, 14: z.cs, 15: z.co, 20: st.off(name + ".beta") - st.off(name + ".gamma"), **extra}))
+                                  i={**dims, 14: z.cs, 15: z.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma"), **extra}))  # 17: dgamma / dbeta ADD
+        # to the flat gradient like every weight gradient does (round 3: they used to overwrite it, so under gradient accumulation — batch < nbs = 64 —
+        # only the last micro-batch's BatchNorm gradients reached the optimizer; found by tests/test_gpu_ddp_rehearsal.py's union-batch equivalence)
 
     # ------------------------------------------------------------------ Visitor
     def input(self):
@@ -555,7 +557,7 @@ class TrainPlan(graph.Visitor):
                 acc = self._acc_bwd(cpad, ACC_SLOTS)  # COLSUM uses C doubles per slot: half of each slice stays unused
                 ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gyw.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0, 21: ACC_SLOTS}))
-                ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cpad}))
+                ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cpad, 4: 1}))
                 if self._wgrad_lane(lane) != lane:  # bias gradient: nothing in the program reads it either
                     ops[-2]._force_lane = ops[-1]._force_lane = self.WGRAD_LANE | (lane << 8)
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
@@ -623,7 +625,7 @@ class TrainPlan(graph.Visitor):
             acc = self._acc_bwd(cout, ACC_SLOTS)
             ops.append(hiplib.make_op(hiplib.OP_COLSUM, self.dtype, p=(gy.t.data_ptr(), 0, 0, 0, acc.data_ptr()),
                                       i={0: self.N, 1: y.H, 2: y.W, 3: cout, 10: gy.cs, 11: gy.co, 21: ACC_SLOTS}))
-            ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cout}))
+            ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cout, 4: 1}))
             # dW[ci][(dy,dx,co)] = sum_p x[p][ci] * dy[(2y+dy,2x+dx)][co]: CONV_WGRAD with the operands swapped
             ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(gy.t.data_ptr(), x.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
                                                   i={0: self.N, 1: y.H, 2: y.W, 3: cout, 4: x.H, 5: x.W, 6: cin, 7: 2, 8: 2, 9: 0, 10: gy.cs, 11: gy.co, 12: x.cs, 13: x.co, 21: WG_SCRATCH_FLOATS}), lane))
