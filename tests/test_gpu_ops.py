@@ -757,13 +757,13 @@ def test_conv3x3_dense_halo_slots_equal_the_full_width_image(case):
     _close(outs[0], ref, MSL_BF16, f"dense halo {case}")
 
 
-@pytest.mark.parametrize("kind", ["3x3", "3x3s2", "1x1", "1x1wide"])
+@pytest.mark.parametrize("kind", ["3x3", "3x3b", "3x3c48", "3x3s2", "1x1", "1x1wide"])
 def test_split_precision_products_are_fp32_grade(kind):
     """MSL_F32S (every conv product as three f16 partial products, operands split hi + lo) against a float64 reference, beside the exact fp32
     kernels on the same data: the split mode's error must be of the order of fp32 rounding (a few 1e-7 of the output scale), not of f16 (1e-3)."""
     g = torch.Generator().manual_seed(5)
     N, H, W = 3, 40, 56
-    Cin, Cout, k, s = {"3x3": (64, 64, 3, 1), "3x3s2": (32, 64, 3, 2), "1x1": (128, 64, 1, 1), "1x1wide": (384, 128, 1, 1)}[kind]
+    Cin, Cout, k, s = {"3x3": (64, 64, 3, 1), "3x3b": (32, 32, 3, 1), "3x3c48": (48, 32, 3, 1), "3x3s2": (32, 64, 3, 2), "1x1": (128, 64, 1, 1), "1x1wide": (384, 128, 1, 1)}[kind]
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     x = torch.randn(N, H, W, Cin, generator=g) * 3.0                      # post-SiLU-like scale, both signs

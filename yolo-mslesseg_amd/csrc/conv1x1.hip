@@ -168,17 +168,30 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
     for (int ks = 0; ks < KS; ++ks) {
       const int kb = (ks * KSTEP + EPC * g) * ES;  // 16 bytes per lane either way
       if constexpr (SPLIT) {
-        uint4 bfr[PT];
+        // K-steps in pairs on the K = 32 f16 instruction (msl_mfma_split2: the 16x16x16 form runs at half the matrix rate), an odd last one alone
+        const bool pair = ks + 1 < KS;  // wave-uniform
+        const int kb1 = kb + KSTEP * ES;
+        uint4 bfr[PT], bfr1[PT];
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) bfr[pt] = *(const uint4*)(xs + (pt * 16 + li) * pitch + kb);
+        for (int pt = 0; pt < PT; ++pt) {
+          bfr[pt] = *(const uint4*)(xs + (pt * 16 + li) * pitch + kb);
+          if (pair) bfr1[pt] = *(const uint4*)(xs + (pt * 16 + li) * pitch + kb1);
+        }
 #pragma unroll
         for (int c = 0; c < NCP; ++c)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const uint4 af = *(const uint4*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb);
+            if (pair) {
+              const uint4 af1 = *(const uint4*)(s_w + (c * 32 + arow + 4 * m) * pitch + kb1);
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = msl_mfma_split(af, bfr[pt], acc[pt][c][m]);
+              for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = msl_mfma_split2(af, af1, bfr[pt], bfr1[pt], acc[pt][c][m]);
+            } else {
+#pragma unroll
+              for (int pt = 0; pt < PT; ++pt) acc[pt][c][m] = msl_mfma_split(af, bfr[pt], acc[pt][c][m]);
+            }
           }
+        if (pair) ++ks;
       } else if constexpr (F32) {
         f32x4 bfr[PT];
 #pragma unroll

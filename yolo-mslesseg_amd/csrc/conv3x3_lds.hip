@@ -291,6 +291,25 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
         else B[p] = g < KG ? *(const uint4*)(s_in + halo_byte_kg<KG>(slot + lp, g)) : make_uint4(0u, 0u, 0u, 0u);  // the chunk's other k-groups: zero input channels
       }
     };
+    if constexpr (SPLIT) {  // taps in pairs on the K = 32 f16 instruction (msl_mfma_split2), an odd last tap on the K = 16 one
+#pragma unroll
+      for (int t = 0; t + 1 < NT; t += 2) {
+        fetch(t, av[0], bv[0]);
+        fetch(t + 1, av[1], bv[1]);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) acc[c][p] = msl_mfma_split2(av[0][c], av[1][c], bv[0][p], bv[1][p], acc[c][p]);
+      }
+      if constexpr (NT & 1) {
+        fetch(NT - 1, av[0], bv[0]);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) acc[c][p] = msl_mfma_split(av[0][c], bv[0][p], acc[c][p]);
+      }
+      continue;
+    }
     fetch(0, av[0], bv[0]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1008,7 +1027,10 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (cot == 2) return launch3<true, S_, RW_, 2, 3, 3, true>(a, cout_blocks, s);       \
     return launch3<true, S_, RW_, 1, 3, 3, true>(a, cout_blocks, s);                     \
   } while (0)
-    // (measured and rejected: 16 x 32 tiles for whole 64-channel blocks, which halve the weight slab re-staged per pixel — proto.cv2 0.965 -> 1.18 ms)
+    // Measured and rejected for this mode: 16 x 32 tiles in this kernel, which halve the weight slab re-staged per pixel (proto.cv2 0.965 -> 1.18 ms: 32
+    // accumulator tiles per wave, one wave per SIMD); an 8-wave pipelined persistent kernel (one slab per 16 x 32 pixels shared by 8 waves, (halo + slab)
+    // units double-buffered, asm LDS-DMA): 1.014 ms against 0.965 — and intermittently wrong in one 16-pixel row of a tile (two accumulator registers
+    // of one wave; not resolved), so it was removed.  What did pay is in the kernel itself: taps paired on the K = 32 f16 instruction (0.965 -> 0.81 ms).
     if (stride == 2) L3S(2, 1); else L3S(1, 2);
 #undef L3S
   }

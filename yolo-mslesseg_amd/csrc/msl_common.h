@@ -238,6 +238,17 @@ __device__ __forceinline__ f32x4 msl_mfma_split(uint4 a, uint4 b, f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
 }
+// Two K-steps at once on v_mfma_f32_16x16x32_f16 (8 f16 per lane and operand: elements 0-3 = this lane group's four k of step 0, 4-7 = of step 1).
+// Measured: the 16x16x16 form runs at half the matrix rate on gfx950 (proto.cv2 in split mode sat at 250 TF/s of algorithmic flops = 3 x that in
+// f16 products, whatever the staging did), the 16x16x32 form at the full rate — so K-steps (taps, or channel steps) are paired wherever there are two.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 msl_mfma_split2(uint4 a0, uint4 a1, uint4 b0, uint4 b1, f32x4 acc) {
+  const f16x8 ah = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)), al = __builtin_bit_cast(f16x8, make_uint4(a0.z, a0.w, a1.z, a1.w));
+  const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(b0.x, b0.y, b1.x, b1.y)), bl = __builtin_bit_cast(f16x8, make_uint4(b0.z, b0.w, b1.z, b1.w));
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+}
 // in-place conversion of 16 staged bytes in LDS (the lane that brought them in converts them, before the barrier that publishes the tile)
 __device__ __forceinline__ void msl_split_lds16(unsigned char* p) { *(uint4*)p = msl_split_unit(*(const uint4*)p); }
 
