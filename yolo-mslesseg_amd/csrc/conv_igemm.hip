@@ -81,8 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   int ci = kk - tap * a.Cin;
   int ty = tap / a.kw, tx = tap - ty * a.kw;
 
-  for (int ks = 0; ks < a.Kpad; ks += KSTEP) {
-    uint4 av[COT], bv[PT];
+  auto load_step = [&](int ks, uint4 (&av)[COT], uint4 (&bv)[PT]) {
 #pragma unroll
     for (int c = 0; c < COT; ++c) av[c] = *(const uint4*)(wrow[c] + (long)ks * ES);
     const bool kin = (ks + kk) < a.K;
@@ -101,17 +100,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       if (ok) v = *(const uint4*)(a.x + (xoff[pt] + ((long)iy * a.W + ix) * a.x_cs + ci) * ES);
       bv[pt] = v;
     }
-    if constexpr (SPLIT) {
+  };
+  auto advance = [&]() {
+    ci += KSTEP;
+    while (ci >= a.Cin) {
+      ci -= a.Cin;
+      if (++tx == a.kw) { tx = 0; ++ty; }
+    }
+  };
+  for (int ks = 0; ks < a.Kpad; ks += KSTEP) {
+    uint4 av[COT], bv[PT];
+    load_step(ks, av, bv);
+    if constexpr (SPLIT) {  // K-steps in pairs on the K = 32 f16 instruction (msl_common.h), an odd last one alone
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) bv[pt] = msl_split_unit(bv[pt]);
+      advance();
+      if (ks + KSTEP < a.Kpad) {  // block-uniform
+        uint4 av1[COT], bv1[PT];
+        ks += KSTEP;
+        load_step(ks, av1, bv1);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) bv1[pt] = msl_split_unit(bv1[pt]);
+        advance();
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[c][pt] = msl_mfma_split2(av[c], av1[c], bv[pt], bv1[pt], acc[c][pt]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[c][pt] = msl_mfma_split(av[c], bv[pt], acc[c][pt]);
+      }
+      continue;
     }
 #pragma unroll
     for (int c = 0; c < COT; ++c)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        if constexpr (SPLIT) {
-          acc[c][pt] = msl_mfma_split(av[c], bv[pt], acc[c][pt]);
-        } else if constexpr (F32) {
+        if constexpr (F32) {
           f32x4 af = __builtin_bit_cast(f32x4, av[c]), bf = __builtin_bit_cast(f32x4, bv[pt]);
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[c][pt], 0, 0, 0);
@@ -120,11 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                                                                __builtin_bit_cast(bf16x8, bv[pt]), acc[c][pt], 0, 0, 0);
         }
       }
-    ci += KSTEP;
-    while (ci >= a.Cin) {
-      ci -= a.Cin;
-      if (++tx == a.kw) { tx = 0; ++ty; }
-    }
+    advance();
   }
 
   if constexpr (SPLIT) {
