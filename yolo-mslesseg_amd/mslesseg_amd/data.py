@@ -232,7 +232,9 @@ class SegDataset(_SliceDataset):
             inst = L.read_label_file(root / "labels" / (f.stem + ".txt"))
             return rgb, [(c, p.copy()) for c, p in inst]
 
-        with ThreadPoolExecutor(max_workers=8) as ex:  # zlib and the NumPy filters release the GIL; order = sorted file order
+        import os
+
+        with ThreadPoolExecutor(max_workers=min(32, max(8, os.cpu_count() or 8))) as ex:  # zlib and the NumPy filters release the GIL; order = sorted file order
             self.raw = list(ex.map(load, self.im_files))
 
 
