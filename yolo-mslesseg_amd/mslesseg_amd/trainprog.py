@@ -426,13 +426,20 @@ class TrainPlan(graph.Visitor):
         self._f(hiplib.make_op(hiplib.OP_BN_ACT, self.dtype, p=p, i=i, f=f))
         return stats
 
-    def _bn_backward(self, ops, name, z: View, y: View, C, act, stats, res: Optional[View], res_inplace=False):
+    def _bn_backward(self, ops, name, z: View, y: View, C, act, stats, res: Optional[View], res_inplace=False, lane: Optional[int] = None):
         """dy = G(y) → dz written in place over z; dgamma/dbeta into the flat gradient; residual fan-out."""
         st = self.store
         gy = self.G(y)
         acc = self._acc_bwd(C, ACC_SLOTS)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS}
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
+        # MSL_BN_BWD_FUSE_MAX=<elements> (measurement switch, default off): reduction + apply of small main-lane layers as ONE launch with a grid barrier
+        # (MSL_OP_BN_ACT_BWD_FUSED; at most one such kernel may be in flight, hence lane 0 only; no residual fan-out in that form)
+        fuse_max = int(os.environ.get("MSL_BN_BWD_FUSE_MAX", "0"))
+        if fuse_max > 0 and lane == 0 and (res is None or res_inplace) and self.N * z.H * z.W * C <= fuse_max:
+            ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_FUSED, self.dtype, p=pcommon + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
+                                      i={**dims, 14: z.cs, 15: z.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
+            return
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
         papply, extra = pcommon, {}
         if res is not None and not res_inplace:
@@ -465,7 +472,7 @@ class TrainPlan(graph.Visitor):
 
         def bw():
             ops = []
-            self._bn_backward(ops, name, z, y, cout, True, stats, None)
+            self._bn_backward(ops, name, z, y, cout, True, stats, None, lane=lane)
             ops.append(self._defer(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
                                                   i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS}), lane))
             return ops
@@ -549,7 +556,7 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             if bn:
-                self._bn_backward(ops, name, z, y, cout, act, stats, res)
+                self._bn_backward(ops, name, z, y, cout, act, stats, res, lane=lane)
                 dz, dz_f32 = z, 0
             else:  # plain conv + bias: dz = dy (the loss writes it, zeros in the padding channels)
                 gy = self.G(y)
