@@ -82,7 +82,11 @@ enum {
    *       outputs of one pixel are consecutive channels (16-byte stores; a pixel's four lanes write one whole line).
    *    p 6,7 (LDS 3x3 only, optional) fused 1x1 tail: 6 = W2 [i22 = 32][Cout = 64] row-major in the op dtype (bf16), 7 = bias2 f32[32]; the op
    *       then writes y = act(W2 * act(conv(x) + bias) + bias2) (32 channels) and the 64-channel intermediate never reaches memory
-   *       (Proto.cv2 + Proto.cv3 at predict time); refused unless the persistent weights-resident kernel can take it */
+   *       (Proto.cv2 + Proto.cv3 at predict time); refused unless the persistent weights-resident kernel can take it
+   *    p 6 (1x1 / stride 1 / pad 0, bf16, optional) input transform on load: f32 [Cin][2] = (scale, shift) per INPUT channel; the kernel multiplies
+   *       W by x' = (f 1 != 0 ? SiLU : id)(x * scale + shift), rounded to bf16 — the producer's BatchNorm + activation (scale = gamma * invstd,
+   *       shift = beta - mean * scale) folded into this consumer so that the activated tensor is never written.  Only the streaming kernel
+   *       (weights resident in LDS) has it: refused otherwise.  A measured form (BatchNorm fusion), not emitted by the training program */
   MSL_OP_CONV = 1,
   /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
    * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y

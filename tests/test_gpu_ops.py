@@ -72,6 +72,7 @@ CONV_CASES = [
     (6, 40, 40, 320, 320, 1, 1, 320, 0, 320, 0, 0, 1, 0),    # K tail (320 = 5 chunks), Cout = 320: a partial third channel tile; accumulate
     (5, 40, 48, 512, 384, 1, 1, 512, 0, 384, 0, 0, 0, 1),    # fp32 output, 8 chunks, three channel tiles
     (24, 20, 20, 288, 256, 1, 1, 288, 0, 256, 0, 1, 0, 0),   # K = 288: the last chunk holds 32 channels
+    (6, 40, 40, 272, 192, 1, 1, 272, 0, 192, 0, 1, 1, 0),    # K = 272: fp32 forms (32-channel chunks) end on a half chunk; residual read in the epilogue there
     # YOLO11s-seg widths (BASELINE configs[2])
     (1, 20, 20, 768, 256, 1, 1, 768, 0, 256, 0, 1, 0, 0),    # model.13.cv1 at scale s: K = 768 from the neck concat
     (1, 10, 10, 1024, 512, 1, 1, 1024, 0, 512, 0, 1, 0, 0),  # SPPF.cv2 at scale s: K = 1024, Cout = 512 (2 x 256)
@@ -339,6 +340,32 @@ def test_attention(dtype, hw):
     _close(yd, ref, dtype, "attention")
 
 
+@pytest.mark.parametrize("hw", [(20, 20), (20, 17), (9, 7), (2, 1)])
+def test_attention_fp32_matrix_core_kernel_views_and_valu_kernel(hw):
+    """fp32 attention on v_mfma_f32_16x16x4_f32 (the default of the fp32 engines) out of / into channel slices of wider buffers: against torch, and
+    against the VALU kernel (i[23] = -1) — both are fp32 fma chains in different orders."""
+    g = torch.Generator().manual_seed(29)
+    N, (H, W), heads, kd, hd = 3, hw, 2, 32, 64
+    x_cs, x_co, y_cs, y_co = heads * 128 + 16, 8, heads * hd + 12, 4
+    buf = _rand_act((N, H, W, x_cs), MSL_F32, g, scale=1.5)
+    q4 = buf[..., x_co : x_co + heads * 128].reshape(N, H * W, heads, 128).permute(0, 2, 3, 1)
+    q, k, v = q4.split([kd, kd, hd], 2)
+    attn = ((q.transpose(-2, -1) @ k) * kd**-0.5).softmax(-1)
+    ref = (v @ attn.transpose(-2, -1)).permute(0, 3, 1, 2).reshape(N, H, W, heads * hd)
+    qd = buf.to(DEV)
+    outs = []
+    for sel in (0, -1):
+        yd = torch.full((N, H, W, y_cs), 7.0, dtype=torch.float32, device=DEV)
+        hiplib.launch(hiplib.make_op(hiplib.OP_ATTENTION, MSL_F32, p=(qd.data_ptr(), 0, 0, 0, yd.data_ptr()),
+                                     i={0: N, 1: H, 2: W, 3: heads, 4: kd, 5: hd, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co, 23: sel}, f=(kd**-0.5,)), _stream())
+        torch.cuda.synchronize()
+        out = yd.cpu()
+        _close(out[..., y_co : y_co + heads * hd], ref, MSL_F32, f"attention fp32 sel {sel}")
+        assert (out[..., :y_co] == 7.0).all() and (out[..., y_co + heads * hd :] == 7.0).all(), "attention wrote outside its channel slice"
+        outs.append(out)
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("hw,c", [((218, 182), 3), ((182, 182), 3), ((182, 218), 1), ((640, 640), 3), ((37, 91), 3)])
 def test_letterbox_bit_exact(hw, c):
     from oracle import prepost as P
@@ -537,6 +564,52 @@ def test_conv1x1_batchnorm_statistics_epilogue(case):
     got = acc.cpu().view(slots, Cout, 2).sum(0)
     assert torch.allclose(got[:, 0], z.sum(0), rtol=1e-5, atol=1e-3)
     assert torch.allclose(got[:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 40, 64, 64, 1), (3, 33, 21, 48, 32, 1), (1, 80, 80, 32, 128, 0), (2, 20, 20, 256, 96, 1), (1, 7, 5, 16, 8, 1), (2, 24, 24, 40, 72, 1)])
+def test_conv1x1_input_batchnorm_table_on_load(case):
+    """1x1 conv op with p[6]: y = W * bf16(act(x * scale + shift)) — the producer's BatchNorm + SiLU applied to the staged slice in LDS;
+    against torch on the same bf16-rounded transformed input, and against the two-op form (BN_ACT, then the plain conv) bit for bit."""
+    N, H, W, Cin, Cout, act = case
+    g = torch.Generator().manual_seed(sum(case))
+    xbuf = _rand_act((N, H, W, Cin), MSL_BF16, g)
+    scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.rand(Cin, generator=g) - 0.5
+    tab = torch.stack([scale, shift], 1).reshape(-1).contiguous().to(DEV)
+    w = ((torch.rand((Cout, Cin, 1, 1), generator=g) * 2 - 1) / Cin**0.5).to(torch.bfloat16).float()
+    wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), torch.rand(Cout, generator=g), MSL_BF16, DEV)
+    xd = xbuf.to(DEV)
+    yd = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=DEV)
+    dims = {0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: Cout, 7: 1, 8: 1, 9: 0, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 18: 1, 19: 0, 20: 0, 21: m["Cout_pad"]}
+    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr(), 0, tab.data_ptr()), i=dims, f=(0.0, float(act)))
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    u = torch.addcmul(shift, xbuf.float(), scale)  # one fma per element, as the kernel
+    a = (F.silu(u) if act else u).to(torch.bfloat16)
+    ref = F.silu(F.conv2d(a.float().permute(0, 3, 1, 2), w, bt[:Cout].cpu()).permute(0, 2, 3, 1))
+    _close(yd.cpu(), ref, MSL_BF16, f"conv1x1 on-load BN {case}")
+    # the two-op form on the device's own transformed tensor
+    ad = torch.zeros_like(xd)
+    stats = torch.stack([torch.zeros(Cin), torch.ones(Cin)], 1).reshape(-1).to(DEV)  # mean 0, invstd 1: gamma = scale, beta = shift
+    gd, bd = scale.to(DEV), shift.to(DEV)
+    hiplib.launch(hiplib.make_op(hiplib.OP_BN_ACT, MSL_BF16, p=(xd.data_ptr(), stats.data_ptr(), gd.data_ptr(), 0, ad.data_ptr(), bd.data_ptr()),
+                                 i={0: N, 1: H, 2: W, 3: Cin, 10: Cin, 11: 0, 12: Cin, 13: 0, 18: act}), _stream())
+    y2 = torch.zeros_like(yd)
+    hiplib.launch(hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(ad.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y2.data_ptr()), i=dims), _stream())
+    torch.cuda.synchronize()
+    same = (y2 == yd).float().mean().item()
+    assert same > 0.98, f"on-load form differs from BN_ACT + conv on {1 - same:.3%} of the outputs"  # SiLU rounding: the two kernels use the same silu_f; bf16 ties may differ
+
+
+def test_conv1x1_input_batchnorm_table_is_refused_outside_the_streaming_kernel():
+    N, H, W, Cin, Cout = 24, 20, 20, 384, 256  # the tiled GEMM's shape
+    x = torch.zeros((N, H, W, Cin), dtype=torch.bfloat16, device=DEV)
+    wt, bt, m = E.pack_gemm(torch.zeros(Cout, Cin), torch.zeros(Cout), MSL_BF16, DEV)
+    y = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=DEV)
+    tab = torch.zeros(2 * Cin, device=DEV)
+    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(x.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.data_ptr(), 0, tab.data_ptr()),
+                        i={0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: Cout, 7: 1, 8: 1, 9: 0, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 21: m["Cout_pad"]})
+    with pytest.raises(hiplib.MslError):
+        hiplib.launch(op, _stream())
 
 
 def test_conv_statistics_epilogue_is_refused_outside_the_1x1_kernel():

@@ -82,6 +82,113 @@ __global__ __launch_bounds__(128) void attention_kernel(const void* __restrict__
   }
 }
 
+// ---- fp32 on the matrix cores (the fp32 engines of predict) -----------------------------------------------------------------------
+// The VALU kernel above reads every K / V element back from LDS as a broadcast for ONE fma per lane: 24 ds_read_b128 per key and wave — at batch 128
+// it is LDS-bound (0.32 ms, the third-longest launch of the fp32s program), at batch 1 its 8 workgroups wait out ~10 000 dependent LDS round trips
+// (0.29 ms of a 3.1 ms program).  Here a workgroup owns 64 queries (one 16-query tile per wave), K / V pass through LDS in double-buffered stages of
+// 32 keys, and both products run on v_mfma_f32_16x16x4_f32 (exact fp32 fma chains), transposed like the bf16 kernel so that no layout conversion is needed:
+//   S^T[key][query] = K Q^T : A = K rows from LDS (one 16-byte read = the k-slots of four MFMAs), B = Q^T in registers, loaded once;
+//                             k-slot g of step (h, j) is channel 16h + 4g + j for both operands — any contraction order is a valid dot product
+//   a lane then holds, for ITS query, keys 4g .. 4g+3 of a 16-key tile: in-lane max / sum + two cross-group shuffles; flash-style running max
+//   O^T[d][query]   = V^T P^T: B = exp(S^T - max) as it sits in the accumulator (step r contracts keys 4g + r), A = V[key 4g + r][4 li .. 4 li + 3] from
+//                             ONE 16-byte read per step: its four floats are the A elements of the four d-tiles (tile t' = channels 4 li + t'), so the lane
+//                             ends up with channels 16g + 4r .. +3 of its query in (acc[0..3][r]): four 16-byte stores.
+// 24 MFMAs and 6 ds_read_b128 per 16 keys and wave.
+__global__ __launch_bounds__(256) void attention_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ y, int HW, int x_cs, int x_co, int y_cs, int y_co,
+                                                                 float scale) {
+  constexpr int KD = 32, HD = 64, TK = 32, KP = KD + 4, VP = HD + 4;  // row pitches in floats: + 16 bytes → the 16 rows of a fragment read start in distinct bank groups
+  __shared__ __attribute__((aligned(16))) float sk[2][TK * KP];
+  __shared__ __attribute__((aligned(16))) float sv[2][TK * VP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, n = blockIdx.z;
+  const int query = blockIdx.x * 64 + wave * 16 + li;
+  const long rowbase = (long)n * HW;
+  const int hoff = x_co + head * (2 * KD + HD);
+  f32x4 qv[2];
+  {
+    const float* qp = qkv + (rowbase + (query < HW ? query : HW - 1)) * x_cs + hoff + 4 * g;
+    qv[0] = *(const f32x4*)qp;
+    qv[1] = *(const f32x4*)(qp + 16);
+  }
+  // staging: a stage is 32 keys x (8 + 16) 16-byte units; thread t moves units t, t + 256, t + 512
+  f32x4 st[3];
+  auto gload = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = threadIdx.x + 256 * i, key = idx / 24, c = idx - key * 24;
+      const int kk = j0 + key < HW ? j0 + key : HW - 1;  // clamped: every lane loads, rows beyond HW are masked below
+      st[i] = *(const f32x4*)(qkv + (rowbase + kk) * x_cs + hoff + KD + 4 * c);
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = threadIdx.x + 256 * i, key = idx / 24, c = idx - key * 24;
+      if (c < 8) *(f32x4*)&sk[buf][key * KP + 4 * c] = st[i];
+      else *(f32x4*)&sv[buf][key * VP + 4 * (c - 8)] = st[i];
+    }
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -__builtin_inff(), l = 0.f;
+  const int nst = (HW + TK - 1) / TK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < nst; ++t) {
+    const int buf = t & 1, j0 = t * TK;
+    if (t + 1 < nst) gload(j0 + TK);
+    f32x4 sc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 kf = *(const f32x4*)&sk[buf][(kt * 16 + li) * KP + 16 * h + 4 * g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qv[h][j], sc[kt], 0, 0, 0);
+      }
+    }
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = j0 + kt * 16 + 4 * g + r < HW ? sc[kt][r] * scale : -__builtin_inff();
+        sc[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);        // finite: every stage holds at least one real key
+    const float alpha = __expf(m - mn);   // first stage: exp(-inf) = 0
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __expf(sc[kt][r] - mn);  // masked keys: exp(-inf) = 0
+        l += pr;
+        const f32x4 vf = *(const f32x4*)&sv[buf][(kt * 16 + 4 * g + r) * VP + 4 * li];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[tt], pr, acc[tt], 0, 0, 0);
+      }
+    if (t + 1 < nst) lstore(buf ^ 1);  // everyone left that buffer at the barrier that ended the previous stage
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (query >= HW) return;
+  const float inv = 1.0f / l;
+  float* o = y + (rowbase + query) * y_cs + y_co + head * HD + 16 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *(f32x4*)(o + 4 * r) = (f32x4){acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+}
+
 // ---- bf16: the same attention on the matrix cores ---------------------------------------------------------------------
 // One workgroup per (slice, head): K [HW][32] and V [HW][64] are copied once to LDS (LDS-DMA, padded rows); each wave then
 // takes 16-query tiles.  Everything is computed TRANSPOSED so that no register-layout conversion is needed:
@@ -670,6 +777,12 @@ int msl_launch_attention(const msl_op& op, hipStream_t s) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)heads, (unsigned)N), dim3(256), lds, s, (const unsigned short*)op.p[0], (unsigned short*)op.p[4], HW, x_cs, x_co, y_cs, y_co, op.f[0]);
+    MSL_CHECK_LAUNCH("attention");
+    return MSL_OK;
+  }
+  if (op.dtype == MSL_F32 && op.i[23] != -1) {  // fp32 tensors: matrix-core kernel (i[23] = -1 keeps the VALU kernel: A/B measurements and tests)
+    hipLaunchKernelGGL(attention_f32_mfma_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)heads, (unsigned)N), dim3(256), 0, s, (const float*)op.p[0], (float*)op.p[4], HW, x_cs, x_co,
+                       y_cs, y_co, op.f[0]);
     MSL_CHECK_LAUNCH("attention");
     return MSL_OK;
   }

@@ -32,6 +32,8 @@ struct C1Args {
   long M;
   int Cin, Cout, Kpad, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, slots, w_rows;
   float oscale;       // MSL_F32S: accumulators x this before bias / activation (inverse of the host's power-of-two weight scale)
+  const float* bn_tab;  // measurement form (round 3, verdict #3b): per INPUT channel (scale, shift) = (gamma * invstd, beta - mean * gamma * invstd) — the wave applies
+  int bn_act;           // x <- act(x * scale + shift) to the slice it staged, in LDS, before multiplying: the producer's BN_ACT pass (z -> a) folded into this consumer
   int shuffle, H, W;  // shuffle = 1: pixel-shuffle store of a ConvTranspose2d k2 s2 run as a 1x1 GEMM — channel q*C + c (C = Cout/4, q = dy*2 + dx) of
                       // pixel (y, x) goes to channel c of pixel (2y + dy, 2x + dx) of the 2H x 2W output (same contract as conv_igemm's store mode 1)
 };
@@ -59,6 +61,9 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
   float* s_bias = (float*)(smem + w_bytes + NW * 2 * slice_bytes);    // [NCP * 32]: read per slice with ds_read — a global load in the loop makes hipcc
                                                                       // wait vmcnt(0), i.e. for the next slice's DMA and the previous stores, before every store group
   for (int i = threadIdx.x; i < NCP * 32; i += blockDim.x) s_bias[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;
+  float* s_bn = s_bias + NCP * 32;  // [2 * Kpad] (scale, shift) per input channel; pad channels (0, 0)
+  if (a.bn_tab)
+    for (int i = threadIdx.x; i < 2 * a.Kpad; i += blockDim.x) s_bn[i] = i < 2 * a.Cin ? a.bn_tab[i] : 0.f;
 
   // ---- weights → LDS (rows >= w_rows and the pad chunk read the zero page)
   {
@@ -138,6 +143,26 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
     const unsigned char* xs = s_x + buf * slice_bytes;
     if constexpr (SPLIT) {
       for (int k = 0; k < npieces; ++k) msl_split_lds16(s_x + buf * slice_bytes + k * 1024 + lane * 16);
+    }
+    if constexpr (!F32) {
+      if (a.bn_tab) {  // wave-uniform: BatchNorm + activation of the producer applied to the staged slice (8 bf16 per lane and piece)
+        for (int k = 0; k < npieces; ++k) {
+          const int cidx = k * 64 + lane, px = cidx / cps, ch = cidx - px * cps;
+          if (cidx >= slice_chunks || ch >= xchunks) continue;
+          uint4* q = (uint4*)(s_x + buf * slice_bytes + k * 1024 + lane * 16);
+          const uint4 t = *q;
+          const unsigned w[4] = {t.x, t.y, t.z, t.w};
+          unsigned o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 st4 = *(const float4*)(s_bn + 2 * (ch * 8 + 2 * j));  // (scale, shift) of two consecutive channels
+            float u0 = fmaf(__uint_as_float(w[j] << 16), st4.x, st4.y), u1 = fmaf(__uint_as_float(w[j] & 0xffff0000u), st4.z, st4.w);
+            if (a.bn_act) { u0 = silu_f(u0); u1 = silu_f(u1); }
+            o[j] = f32_to_bf16_bits(u0) | (f32_to_bf16_bits(u1) << 16);
+          }
+          *q = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
     }
     // residual (bf16: an input gradient that adds to what its view already holds): fetched here, before the MFMAs, into registers.  Loaded in the
     // store loop, each group's load made hipcc wait — in order — for the next slice's DMA and for the previous group's stores.
@@ -328,11 +353,18 @@ struct G1Args {
   double* acc;  // optional BatchNorm accumulator f64[slots][2*Cout] (train-mode raw convs: sums of the stored values, as the streaming kernel's epilogue)
   long M;
   int Cin, Cout, Kpad, w_rows, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, ntn, slots;
+  float oscale;  // MSL_F32S: inverse of the host's power-of-two weight scale
 };
 
-template <bool STATS>
+// MODE 0: bf16 tensors.  MODE 1: fp32 tensors on v_mfma_f32_16x16x4_f32 (the parity engine).  MODE 2: fp32 tensors, split-precision products (MSL_F32S:
+// weight rows pre-split by the host, every wave rewrites the x pieces it staged as (hi x 4 | lo x 4) units before the chunk's barrier).  The fp32 forms
+// stage the same 128 bytes per row and chunk, i.e. 32 channels: the wide 1x1 layers of the fp32 engines (K x Cout too large for the streaming kernel's
+// LDS: 192 → 128, 384 → 128, 256 → 256, 384 / 512 → 256 ...) ran through conv_igemm_kernel before, at 50-60 TF/s (fp32) / 65-83 TF/s (split).
+template <bool STATS, int MODE = 0>
 __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
-  constexpr int BM = 128, BN = 128, BK = 64, PITCH = BK * 2 + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
+  static_assert(!(STATS && MODE), "the statistics epilogue is the bf16 training path");
+  constexpr int ES = MODE ? 4 : 2, EPC = 16 / ES;
+  constexpr int BM = 128, BN = 128, BK = 128 / ES, PITCH = BK * ES + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
   constexpr int PIECES = BM * CPR / 64;                                               // 18 per operand tile
   constexpr int TILE = PIECES * 1024, STAGE = 2 * TILE;
   constexpr int KP = (PIECES + 3) / 4;
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
 
   // residual of this lane's 8 store groups (bf16 views), requested first
   uint4 rpre[4][2];
-  if (a.res) {
+  if (MODE == 0 && a.res) {
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       long p = p0 + wm * 64 + pt * 16 + li;
@@ -368,18 +400,18 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   for (int k = 0; k < KP; ++k) {
     const int cidx = (wave + 4 * k) * 64 + lane, row = cidx / CPR, ch = cidx - row * CPR;
     const bool data = row < BM && ch < CPR - 1;
-    xo[k] = (data && p0 + row < a.M) ? (unsigned)(row * a.x_cs * 2 + ch * 16) : OOB;
-    wo[k] = (data && n0 + row < a.w_rows) ? (unsigned)(row * a.Kpad * 2 + ch * 16) : OOB;
-    chn[k] = (unsigned)ch * 8;
+    xo[k] = (data && p0 + row < a.M) ? (unsigned)(row * a.x_cs * ES + ch * 16) : OOB;
+    wo[k] = (data && n0 + row < a.w_rows) ? (unsigned)(row * a.Kpad * ES + ch * 16) : OOB;
+    chn[k] = (unsigned)ch * EPC;
   }
-  const c1_i32x4 rx = c1_rsrc(a.x + (p0 * a.x_cs + a.x_co) * 2);
-  const c1_i32x4 rw = c1_rsrc(a.w + (long)n0 * a.Kpad * 2);
+  const c1_i32x4 rx = c1_rsrc(a.x + (p0 * a.x_cs + a.x_co) * ES);
+  const c1_i32x4 rw = c1_rsrc(a.w + (long)n0 * a.Kpad * ES);
   const unsigned lbase = msl_lds_addr(smem);
   const int nk = (a.Kpad + BK - 1) / BK;
 
   auto stage = [&](int kc, int buf) __attribute__((always_inline)) {
     const unsigned lw = lbase + buf * STAGE, lx = lw + TILE;
-    const unsigned soff = (unsigned)kc * (BK * 2);
+    const unsigned soff = (unsigned)kc * (BK * ES);
     const int xleft = a.Cin - kc * BK, wleft = a.Kpad - kc * BK;  // channels of this chunk that exist (x) / are stored (packed weights)
     const bool tail = xleft < BK || wleft < BK;                    // only the last chunk can be partial
 #pragma unroll
@@ -408,25 +440,78 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   stage(0, 0);
   for (int kc = 0; kc < nk; ++kc) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of chunk kc (and, first time round, the residual) have landed
+    if constexpr (MODE == 2) {  // ... and are rewritten as split units by the wave that staged them (the pad chunk too: never read)
+      unsigned char* cx = smem + (kc & 1) * STAGE + TILE;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int pc = wave + 4 * k;
+        if (pc < PIECES) msl_split_lds16(cx + pc * 1024 + lane * 16);
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone's have, and everyone is done reading the buffer refilled next
     if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
     const unsigned char* sw_ = smem + (kc & 1) * STAGE;
     const unsigned char* sx_ = sw_ + TILE;
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      const int kb = (ks * 32 + 8 * g) * 2;
-      bf16x8 bfr[4];
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        const int kb = (ks * 32 + 8 * g) * 2;
+        bf16x8 bfr[4];
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) bfr[pt] = *(const bf16x8*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+        for (int pt = 0; pt < 4; ++pt) bfr[pt] = *(const bf16x8*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const bf16x8 af = *(const bf16x8*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
+          }
+      }
+    } else if constexpr (MODE == 1) {  // two K-steps of 16 channels: lane group g holds channels 4g..4g+3 of the step, MFMA i contracts element i of every group
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kb = (ks * 16 + 4 * g) * 4;
+        f32x4 bfr[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) bfr[pt] = *(const f32x4*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const f32x4 af = *(const f32x4*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[pt][i], acc[pt][c][m], 0, 0, 0);
+          }
+      }
+    } else {  // the chunk's two K-steps as one pair on the K = 32 f16 instruction (a zero-filled tail step contributes nothing)
+      const int kb = 4 * g * 4, kb1 = kb + 64;
+      uint4 bfr[4], bfr1[4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        bfr[pt] = *(const uint4*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+        bfr1[pt] = *(const uint4*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb1);
+      }
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const bf16x8 af = *(const bf16x8*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
+          const uint4 af = *(const uint4*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
+          const uint4 af1 = *(const uint4*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb1);
 #pragma unroll
-          for (int pt = 0; pt < 4; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
+          for (int pt = 0; pt < 4; ++pt) acc[pt][c][m] = msl_mfma_split2(af, af1, bfr[pt], bfr1[pt], acc[pt][c][m]);
         }
     }
+  }
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[pt][c][m] *= a.oscale;
   }
   // ---- epilogue: lane (li, g) holds channels n0 + wn*64 + c*32 + 8g .. +7 of pixel p0 + wm*64 + 16*pt + li
   float s1[STATS ? 2 : 1][8], s2[STATS ? 2 : 1][8];
@@ -463,7 +548,12 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
       }
-      if (a.res) {
+      if (MODE != 0 && a.res) {
+        float rv[8];
+        ldv<true, 8>(a.res, p * a.res_cs + a.res_co + c0, rv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rv[r];
+      } else if (a.res) {
         const uint4 t = rpre[pt][c];
         v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
         v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
@@ -471,7 +561,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
         v[6] += __uint_as_float(t.w << 16); v[7] += __uint_as_float(t.w & 0xffff0000u);
       }
       const long oi = p * a.y_cs + a.y_co + c0;
-      if (a.out_f32) stv<true, 8>(a.y, oi, v);
+      if (MODE != 0 || a.out_f32) stv<true, 8>(a.y, oi, v);
       else stv<false, 8>(a.y, oi, v);
     }
   }
@@ -499,17 +589,19 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   }
 }
 
-// Eligibility (msl_launch_conv tries this after the streaming kernel): bf16 1x1 / stride 1 / pad 0, plain store, no statistics, 8-aligned views,
-// enough pixels to fill the chip with 128-pixel tiles.
+// Eligibility (msl_launch_conv tries this after the streaming kernel): 1x1 / stride 1 / pad 0, plain store, 16-byte-aligned views, enough pixels to fill
+// the chip with 128-pixel tiles; the statistics epilogue is a bf16 form.
 bool msl_gemm1x1_eligible(const msl_op& op) {
   const int Cin = op.i[3], Cout = op.i[6], Kpad = op.i[17];
-  if (op.dtype != MSL_BF16 || op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0 || !op.p[1]) return false;
-  if (op.p[5] && (op.i[19] || op.p[3] || op.i[18] || op.i[23] > 16)) return false;  // statistics epilogue: raw bf16 convs (no activation / residual / fp32 output), <= 16 slots
-  if (Cin % 8 || Cout % 8 || Kpad % 32 || Kpad < Cin || Cin < 64) return false;
-  if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & 7) return false;
-  if (op.p[3] && ((op.i[14] | op.i[15]) & 7)) return false;
+  const bool f32 = op.dtype != MSL_BF16;
+  const int al = f32 ? 3 : 7, es = f32 ? 4 : 2;  // elements per 16 bytes - 1
+  if (op.i[7] != 1 || op.i[8] != 1 || op.i[9] != 0 || op.i[20] != 0 || !op.p[1]) return false;
+  if (op.p[5] && (f32 || op.i[19] || op.p[3] || op.i[18] || op.i[23] > 16)) return false;  // statistics epilogue: raw bf16 convs (no activation / residual / fp32 output), <= 16 slots
+  if ((Cin & al) || Cout % 8 || Kpad % (f32 ? 16 : 32) || Kpad < Cin || Cin < (f32 ? 32 : 64)) return false;
+  if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & al) return false;
+  if (op.p[3] && ((op.i[14] | op.i[15]) & al)) return false;
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
-  return M >= 128 * 64 && (long)128 * op.i[10] * 2 < (1L << 31) && (long)128 * Kpad * 2 < (1L << 31);
+  return M >= 128 * 64 && (long)128 * op.i[10] * es < (1L << 31) && (long)128 * Kpad * es < (1L << 31);
 }
 
 int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
@@ -521,6 +613,7 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   a.act = op.i[18]; a.out_f32 = op.i[19];
   a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
   a.acc = (double*)op.p[5]; a.slots = op.i[23] > 0 ? op.i[23] : 1;
+  a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
   MSL_REQUIRE(a.x && a.w && a.y && msl_gemm1x1_eligible(op), "gemm1x1: bad args");
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs && (!a.res || a.res_co + a.Cout <= a.res_cs), "gemm1x1: bad dims / views");
   a.ntn = (a.Cout + 127) / 128;
@@ -529,12 +622,16 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     attr = true;
   }
-  if (a.acc) hipLaunchKernelGGL(gemm1x1_kernel<true>, dim3((unsigned)tiles), dim3(256), LDS, s, a);
-  else hipLaunchKernelGGL(gemm1x1_kernel<false>, dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  if (op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else if (op.dtype == MSL_F32) hipLaunchKernelGGL((gemm1x1_kernel<false, 1>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else if (a.acc) hipLaunchKernelGGL((gemm1x1_kernel<true, 0>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL((gemm1x1_kernel<false, 0>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   MSL_CHECK_LAUNCH("gemm1x1");
   return MSL_OK;
 }
@@ -565,7 +662,7 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   constexpr int ES = F32 ? 4 : 2;
   // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
   const int nw = (c1_lds(NCP, a.Kpad, PT, 4, ES) * 3 > 160 * 1024 && c1_lds(NCP, a.Kpad, PT, 8, ES) <= C1_LDS_MAX) ? 8 : 4;
-  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES);
+  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES) + (a.bn_tab ? (size_t)a.Kpad * 8 : 0);  // + the input BatchNorm table behind the bias
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -609,6 +706,9 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
   a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
+  MSL_REQUIRE(!op.p[6] || op.dtype == MSL_BF16, "conv1x1: the input BatchNorm table (p[6]) is a bf16 form");
+  a.bn_tab = (const float*)op.p[6];  // p 6 (bf16, optional): (scale, shift) per input channel f32 [Cin][2]; f 1 != 0: SiLU after it
+  a.bn_act = op.f[1] != 0.f;
   if (op.dtype == MSL_F32S) {
     MSL_REQUIRE(op.f[0] > 0.f && !a.acc, "conv1x1 (MSL_F32S): f[0] must hold the output scale of the pre-split weights; no statistics epilogue");
 #define C1S(N) case N: return c1_launch_f32<N, true>(a, s)

@@ -21,6 +21,28 @@
 // =========================================================================================================
 typedef float f2_t __attribute__((ext_vector_type(2)));
 #define MSL_MAX_SLOTS 16
+// Per-channel constants of a thread's V consecutive channels.  `vec`: the three arrays are 16-byte aligned (the trainer's flat buffers are) → 16-byte
+// loads: 8 instead of 32 load instructions per thread at V = 8 — on the small maps, where a thread streams only 4-16 pixels, the scalar form's
+// address traffic cost as much as the pixels themselves (scripts/dev_bn_act_ppt.py).
+template <int V>
+__device__ __forceinline__ void ld_bn_consts(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int c, bool vec,
+                                             float (&mu)[V], float (&is)[V], float (&ga)[V], float (&be)[V]) {
+  if (vec) {
+#pragma unroll
+    for (int r = 0; r < V; r += 4) {
+      const float4 s0 = *(const float4*)(stats + 2 * (c + r)), s1 = *(const float4*)(stats + 2 * (c + r) + 4);
+      const float4 g = *(const float4*)(gamma + c + r), b = *(const float4*)(beta + c + r);
+      mu[r] = s0.x; is[r] = s0.y; mu[r + 1] = s0.z; is[r + 1] = s0.w; mu[r + 2] = s1.x; is[r + 2] = s1.y; mu[r + 3] = s1.z; is[r + 3] = s1.w;
+      ga[r] = g.x; ga[r + 1] = g.y; ga[r + 2] = g.z; ga[r + 3] = g.w;
+      be[r] = b.x; be[r + 1] = b.y; be[r + 2] = b.z; be[r + 3] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < V; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
+  }
+}
+static inline bool aligned16(const void* a, const void* b, const void* c) { return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0; }
+
 // V = channels per thread: 8 (one 16-byte access of bf16) when the channel count and the views allow it, else 4
 template <bool F32, int MODE, int V>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, const float* __restrict__ stats,
@@ -33,10 +55,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
   float s1[V], s2[V], mu[V], is[V], ga[V], be[V];
 #pragma unroll
   for (int r = 0; r < V; ++r) { s1[r] = 0.f; s2[r] = 0.f; mu[r] = 0.f; is[r] = 1.f; ga[r] = 1.f; be[r] = 0.f; }
-  if (MODE == 1 && pl < PL) {
-#pragma unroll
-    for (int r = 0; r < V; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
-  }
+  if (MODE == 1 && pl < PL) ld_bn_consts<V>(stats, gamma, beta, c, ((((uintptr_t)stats) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, mu, is, ga, be);
   auto accumulate = [&](const float (&va)[V], const float (&vb)[V]) {
     if (MODE == 0) {
 #pragma unroll
@@ -130,7 +149,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict
 
 static int reduce_grid(long M, int C, int slots, int V, long wide_cap = 512) {
   const int PL = 256 / (C / V);
-  long blocks = (M + (long)PL * 16 - 1) / ((long)PL * 16);  // >= 16 pixels per thread before another block (and its atomics) pays off
+  static long env_px = -1;  // experiment switch: MSL_REDUCE_PX (pixels per thread before another block is added)
+  if (env_px < 0) { const char* e = getenv("MSL_REDUCE_PX"); env_px = e ? atol(e) : 0; }
+  const long px = env_px > 0 ? env_px : 16;
+  long blocks = (M + (long)PL * px - 1) / ((long)PL * px);  // >= 16 pixels per thread before another block (and its atomics) pays off
   // measured (batch 128): for the two-stream BatchNorm reductions 256-512 workgroups beat 768 / 1024 / 2048 / 4096 — each one ends in a fold +
   // fp64 atomics; the single-stream column sum (fp32 head gradients, 4 channels per thread) prefers 1024
   static long env_cap = -1;  // experiment switch: MSL_REDUCE_CAP
@@ -201,8 +223,8 @@ struct BnFin { const double* acc; float* stats_out; float* rmean; float* rvar; d
 template <bool F32, int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y, long M, int C,
-                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT, BnFin fin) {
-  __shared__ float ks[2048];
+                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT, BnFin fin, bool cvec) {
+  __shared__ __attribute__((aligned(16))) float ks[2048];
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
   const int c = cq * V;
@@ -227,11 +249,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z,
   }
   if (pl >= PL) return;
   float mu[V], is[V], ga[V], be[V];
-#pragma unroll
-  for (int r = 0; r < V; ++r) {
-    if (fin.acc) { mu[r] = ks[2 * (c + r)]; is[r] = ks[2 * (c + r) + 1]; } else { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; }
-    ga[r] = gamma[c + r]; be[r] = beta[c + r];
-  }
+  if (fin.acc) ld_bn_consts<V>(ks, gamma, beta, c, cvec, mu, is, ga, be);  // ks (LDS) is 16-byte aligned
+  else ld_bn_consts<V>(stats, gamma, beta, c, cvec, mu, is, ga, be);
   // pixel of (k, u) = p0 + (k + u) * PL.  Batches of U pixel groups: the loads of batch k + 1 are issued (every lane, clamped to the last pixel —
   // a load under a per-lane condition is branched around and waited for one by one) before batch k is computed and stored, so a thread always has
   // U (2U with a residual) 16-byte loads in flight and never waits for its own stores.
@@ -285,16 +304,18 @@ int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
   if (op.p[3]) MSL_REQUIRE(op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[15] + C <= op.i[14], "bn_act: bad residual view");
   const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13], op.p[3] ? op.i[14] : 0, op.p[3] ? op.i[15] : 0);
   const int PL = 256 / (C / (v8 ? 8 : 4));
-  const int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;
+  int PPT = M >= (long)PL * 2048 * 16 ? 16 : M >= (long)PL * 2048 * 8 ? 8 : 4;
+  if (op.i[19] > 0 && op.i[19] % 4 == 0) PPT = op.i[19];  // measurement override (scripts/dev_bn_act_ppt.py)
   const long per_block = (long)PL * PPT;
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
   BnFin fin = {nullptr, nullptr, nullptr, nullptr, 0.0, 0.f, 0.f, 0};
+  const bool cvec = aligned16(op.p[6] ? nullptr : op.p[1], op.p[2], op.p[5]);
   if (op.p[6]) {  // fused finalize: p 6 acc f64[slots][2C], p 7 running mean | NULL (running var = p7 + i16 floats), i 21 slots, f 0 eps, f 1 momentum
     MSL_REQUIRE(C <= 1024 && slots_of(op, 21) <= MSL_MAX_SLOTS && (!op.p[7] || op.i[16] != 0), "bn_act: bad fused-finalize arguments");
     fin.acc = (const double*)op.p[6]; fin.stats_out = (float*)op.p[1]; fin.rmean = (float*)op.p[7]; fin.rvar = op.p[7] ? (float*)op.p[7] + op.i[16] : nullptr;
     fin.M = (double)M; fin.eps = op.f[0]; fin.mom = op.f[1]; fin.slots = slots_of(op, 21);
   }
-#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin)
+#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin, cvec)
   if (op.dtype == MSL_F32) { if (v8) BA(true, 8); else BA(true, 4); } else { if (v8) BA(false, 8); else BA(false, 4); }
 #undef BA
   MSL_CHECK_LAUNCH("bn_act");
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
-                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first, int pacc) {
+                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first, int pacc, bool cvec) {
   __shared__ float ks[2048];  // (s1, s2) per channel, summed over the accumulator slots
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
@@ -343,9 +364,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
   if (pl >= PL) return;
   float mu[V], is[V], ga[V], be[V], k0[V], k2[V];
   const float invM = 1.0f / (float)M;
+  ld_bn_consts<V>(stats, gamma, beta, c, cvec, mu, is, ga, be);
 #pragma unroll
   for (int r = 0; r < V; ++r) {
-    mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r];
     k0[r] = ks[2 * (c + r)] * invM;
     k2[r] = ks[2 * (c + r) + 1] * invM;
   }
@@ -437,7 +458,8 @@ int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   dim3 grid((unsigned)((M + per_block - 1) / per_block));
   float* dgamma = (float*)op.p[7];
   float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
-#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17]); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17]); } while (0)
+  const bool cvec = aligned16(op.p[2], op.p[3], beta);
+#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17], cvec); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17], cvec); } while (0)
   if (op.dtype == MSL_F32) { if (v8) BB(true, 8); else BB(true, 4); } else { if (v8) BB(false, 8); else BB(false, 4); }
 #undef BB
   MSL_CHECK_LAUNCH("bn_act_bwd_apply");
