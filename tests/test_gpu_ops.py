@@ -161,7 +161,9 @@ def test_conv3x3_lds(case, dtype, pers):
     if res:
         ref = ref + rbuf[..., y_co : y_co + Cout].float()
     assert E.lds3x3_eligible(Cin, Cout, 3, dtype)
-    wt, bt, m = E.pack_conv3x3_lds(w, b, dtype, DEV)
+    # the fp32 engines pack stride-1 layers of 64 input channels in 32-channel output blocks: four resident chunks in the persistent kernel
+    cot = 2 if pers and dtype != MSL_BF16 and s == 1 and Cin == 64 and Cout % 32 == 0 else None
+    wt, bt, m = E.pack_conv3x3_lds(w, b, dtype, DEV, cot)
     xd, rd, yd = xbuf.to(DEV), rbuf.to(DEV), ybuf.to(DEV)
     op = hiplib.make_op(hiplib.OP_CONV, dtype, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), rd.data_ptr() if res else 0, yd.data_ptr()),
                         i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: s, 9: 1, 10: x_cs, 11: x_co, 12: y_cs, 13: y_co,

@@ -422,8 +422,16 @@ static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
 // its next unit, then runs the MFMAs of the current one; the second group runs one unit behind (two-chunk case), so the VALU-heavy
 // epilogue of one group (stores, SiLU, statistics: about as many issue cycles as the tile's MFMAs) overlaps the other group's MFMAs
 // on the same SIMDs.  BatchNorm statistics stay in registers over all tiles of a wave and are folded once at the end of the kernel.
-template <bool F32, int COT, int NCH, bool FUSE = false, int RING = 2>  // RING: staged units per wave group (2, or 3 where a unit holds few MFMAs and the LDS allows)
+// NCH = 4 (fp32 tensors, 64 input channels = four 16-channel chunks) with 32-channel output blocks is the same 72 KiB of weights + 4 x 22 KiB of halo
+// ring as the bf16 64 -> 64 form.  SPLIT (fp32 tensors, MSL_F32S): the weight image arrives pre-split; every wave rewrites the halo pieces it staged as
+// (hi x 4 | lo x 4) units once they have landed (after its MFMAs, before the step's barrier) and the taps run in pairs on the K = 32 f16 instruction.
+// The tile-per-workgroup kernel re-stages the 36 KiB weight slab of every chunk for every 256 pixels (proto.cv2, 64 -> 64 @160², fp32s: 0.80 ms against
+// 0.31 ms of matrix-core time) — but this form measured slower still on that layer (0.875 vs 0.830 ms on one box): two 32-channel blocks stage and convert
+// every halo twice and a fragment read feeds 2 instead of 4 tiles.  The engines do not pack for it (MSL_F32_COT2=1 does); tests run it.
+template <bool F32, int COT, int NCH, bool FUSE = false, int RING = 2, bool SPLIT = false>  // RING: staged units per wave group (2, or 3 where a unit holds few MFMAs and the LDS allows)
 __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int total_tiles, int steps) {
+  static_assert(!SPLIT || (F32 && !FUSE && RING == 2), "split-precision products: fp32 tensors, plain epilogue, ring of 2");
+  static_assert((NCH & (NCH - 1)) == 0, "chunks per tile: a power of two");
   using T = Tile3<1, 2>;
   constexpr int ES = F32 ? 4 : 2;
   constexpr int CHUNK = 64 / ES;
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   constexpr int PT = 4;
   constexpr int IN_BYTES = T::PIECES * 1024;
   constexpr int W_BYTES = 9 * 4 * COB * 16;
-  constexpr int DELAY = NCH == 2 ? 1 : 0;
+  constexpr int DELAY = NCH / 2;  // group 1 runs half a tile behind group 0
   constexpr int IN_PER_WAVE = (T::PIECES + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_w = smem;                     // [chunk][tap][g][COB][16 B]
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   for (int j = 0; j < IN_PER_WAVE; ++j) st_off[j] = -1;
 
   auto stage = [&](int un, unsigned char* dst) __attribute__((always_inline)) {  // issue the LDS-DMA of unit `un` of this group into `dst`
-    const int cc = NCH == 2 ? (un & 1) : 0;
+    const int cc = un & (NCH - 1);
     if (cc == 0) {  // first chunk of a new tile: gather offsets
       int t = tbase + gi + (un / NCH) * G2;
       const int n = t / tiles_per_img;
@@ -573,6 +581,23 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
 #pragma unroll
       for (int p = 0; p < PT; ++p) B[p] = *(const uint4*)(buf + baddr[(p >> 1) + t / 3][t % 3] + (p & 1) * 1024);
     };
+    if constexpr (SPLIT) {  // taps in pairs on the K = 32 f16 instruction (msl_mfma_split2), the ninth on the K = 16 one
+#pragma unroll
+      for (int t = 0; t + 1 < 9; t += 2) {
+        fetch(t, av[0], bv[0]);
+        fetch(t + 1, av[1], bv[1]);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) acc[c][p] = msl_mfma_split2(av[0][c], av[1][c], bv[0][p], bv[1][p], acc[c][p]);
+      }
+      fetch(8, av[0], bv[0]);
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[c][p] = msl_mfma_split(av[0][c], bv[0][p], acc[c][p]);
+      return;
+    }
     fetch(0, av[0], bv[0]);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -666,7 +691,7 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
       } else if (oy < a.Ho && ox < a.Wo) {
         f32x4 accp[COT];
 #pragma unroll
-        for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
+        for (int c = 0; c < COT; ++c) accp[c] = SPLIT ? acc[c][p] * a.oscale : acc[c][p];
         store_pixel_b<F32, COT>(a, pix, cob * COB + g * (4 * COT), accp, s1, s2, bias_r, RPRE ? rpre[p] : nullptr);
       }
 #pragma unroll
@@ -691,13 +716,23 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
       np = np_wave;
     }
     const bool live = u >= 0 && u < my_units;
-    const int cc = NCH == 2 ? (u & 1) : 0;
+    const int cc = u & (NCH - 1);
     if (live && cc == NCH - 1 && a.res) prefetch_res(u / NCH);
     if (live) compute(cc, ring_g + ub * IN_BYTES);
     // unit u + 1 must have landed before the next barrier: with a ring of 2 that is the DMA issued above (it had the MFMAs to land); with a ring
     // of 3 the one issued a step ago — only the pieces just issued may stay outstanding.  Waited for BEFORE the epilogue so that its stores stay in flight.
     if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else msl_wait_vmcnt(np);
+    if constexpr (SPLIT) {
+      if (np > 0) {  // the pieces this wave has just staged: raw fp32 → split units, in place (visible to the others after the next step's barrier)
+        unsigned char* cb = ring_g + (ub == 0 ? RING - 1 : ub - 1) * IN_BYTES;
+#pragma unroll
+        for (int j = 0; j < IN_PER_WAVE; ++j) {
+          const int pc = wave + 4 * j;
+          if (pc < T::PIECES) msl_split_lds16(cb + pc * 1024 + lane * 16);
+        }
+      }
+    }
     if (live && cc == NCH - 1) epilogue(u / NCH);
     ub = ub + 1 == RING ? 0 : ub + 1;
   };
@@ -731,14 +766,14 @@ __global__ __launch_bounds__(512) void conv3x3_pers_kernel(Conv3Args a, int tota
   }
 }
 
-template <bool F32, int COT, int NCH, bool FUSE = false, int RING = 2>
+template <bool F32, int COT, int NCH, bool FUSE = false, int RING = 2, bool SPLIT = false>
 static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<1, 2>;
   constexpr int LDS = NCH * 9 * 4 * COT * 16 * 16 + 2 * RING * T::PIECES * 1024;
   static_assert(LDS <= 160 * 1024, "conv3x3_pers: LDS");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH, FUSE, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_pers_kernel<F32, COT, NCH, FUSE, RING, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   const long tiles = (long)a.N * a.tiles_y * a.tiles_x;
@@ -748,7 +783,7 @@ static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   long busiest = (tiles + 2 * wgs - 1) / (2 * wgs);  // tiles of the busiest wave group
   if ((wgs & 7) == 0) { const long per = (tiles + 7) / 8, g2 = wgs / 4; busiest = (per + g2 - 1) / g2; }
   const int steps = (int)busiest * NCH;
-  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH, FUSE, RING>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
+  hipLaunchKernelGGL((conv3x3_pers_kernel<F32, COT, NCH, FUSE, RING, SPLIT>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(512), LDS, s, a, (int)tiles, steps);
   MSL_CHECK_LAUNCH("conv3x3_pers");
   return MSL_OK;
 }
@@ -999,19 +1034,28 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
                   "conv3x3 + fused 1x1 tail: needs bf16, stride 1, Cin = Cout = 64, 32 tail channels, plain bf16 output view");
       return launch3p<false, 4, 2, true>(a, cout_blocks, s);
     }
-    if (!split && stride == 1 && rw == 2 && nch <= 2 && fits && (pays || op.i[23] == -9) && op.i[23] != -8) {
-#define L3P(F, NCH_, R1)                                                           \
-  do {                                                                             \
-    if (cot == 4) return launch3p<F, 4, NCH_>(a, cout_blocks, s);                  \
-    if (cot == 2) return launch3p<F, 2, NCH_, false, R1>(a, cout_blocks, s);       \
-    return launch3p<F, 1, NCH_, false, R1>(a, cout_blocks, s);                     \
+    // fp32 tensors with four chunks (64 input channels): 32-channel output blocks fit (the host packs such layers with COT = 2 for the fp32 engines)
+    const bool pays4 = f32 && nch == 4 && cot == 2 && a.Cin % chunk == 0 && tiles >= 1024;
+    if (stride == 1 && rw == 2 && (nch <= 2 || (f32 && nch == 4)) && fits && (pays || pays4 || op.i[23] == -9) && op.i[23] != -8) {
+#define L3P(F, NCH_, SP)                                                             \
+  do {                                                                               \
+    if (cot == 4) return launch3p<F, 4, NCH_, false, 2, SP>(a, cout_blocks, s);      \
+    if (cot == 2) return launch3p<F, 2, NCH_, false, 2, SP>(a, cout_blocks, s);      \
+    return launch3p<F, 1, NCH_, false, 2, SP>(a, cout_blocks, s);                    \
+  } while (0)
+#define L3P4(SP)                                                                     \
+  do {                                                                               \
+    if (cot == 2) return launch3p<true, 2, 4, false, 2, SP>(a, cout_blocks, s);      \
+    return launch3p<true, 1, 4, false, 2, SP>(a, cout_blocks, s);                    \
   } while (0)
       // (a ring of 3 staged units for the one-chunk layers with <= 32 output channels per block — RING = 3 fits their LDS — measured no
       // faster than 2: 160² 8→16 0.0706 vs 0.0716 ms, `scripts/dev_conv3x3_ab.py`; these layers stage 64 bytes per pixel slot for 16 or 32 valid
       // ones, their pace is the LDS-DMA issue count, not the round trip)
-      if (f32) { if (nch == 2) L3P(true, 2, 2); else L3P(true, 1, 2); }
-      else     { if (nch == 2) L3P(false, 2, 2); else L3P(false, 1, 2); }
+      if (split) { if (nch == 4) L3P4(true); else if (nch == 2) L3P(true, 2, true); else L3P(true, 1, true); }
+      else if (f32) { if (nch == 4) L3P4(false); else if (nch == 2) L3P(true, 2, false); else L3P(true, 1, false); }
+      else     { if (nch == 2) L3P(false, 2, false); else L3P(false, 1, false); }
 #undef L3P
+#undef L3P4
     }
   }
 #define L3(F, S_, RW_)                                                   \

@@ -231,17 +231,21 @@ __device__ __forceinline__ uint4 msl_split_unit(uint4 raw) {
   o.w = (unsigned)__builtin_bit_cast(unsigned short, l2) | ((unsigned)__builtin_bit_cast(unsigned short, l3) << 16);
   return o;
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// ONE K-step.  Issued on the K = 32 instruction with a zero second step, never on v_mfma_f32_16x16x16_f16: on gfx950 that instruction runs at half the
+// matrix rate (8 passes, the same time as the K = 32 form), but hipcc schedules its results as a 4-pass instruction's — a VALU read placed right behind
+// it (the epilogue's first packed multiply) saw the accumulator pair r = 0, 1 of the last tile BEFORE the final product had landed, whenever nothing
+// else stalled the wave in between (persistent split kernels: intermittent, one 16-pixel half row, two channels of every eight).
 __device__ __forceinline__ f32x4 msl_mfma_split(uint4 a, uint4 b, f32x4 acc) {
-  const f16x4 ah = __builtin_bit_cast(f16x4, make_uint2(a.x, a.y)), al = __builtin_bit_cast(f16x4, make_uint2(a.z, a.w));
-  const f16x4 bh = __builtin_bit_cast(f16x4, make_uint2(b.x, b.y)), bl = __builtin_bit_cast(f16x4, make_uint2(b.z, b.w));
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+  const f16x8 ah = __builtin_bit_cast(f16x8, make_uint4(a.x, a.y, 0u, 0u)), al = __builtin_bit_cast(f16x8, make_uint4(a.z, a.w, 0u, 0u));
+  const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(b.x, b.y, 0u, 0u)), bl = __builtin_bit_cast(f16x8, make_uint4(b.z, b.w, 0u, 0u));
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
 }
 // Two K-steps at once on v_mfma_f32_16x16x32_f16 (8 f16 per lane and operand: elements 0-3 = this lane group's four k of step 0, 4-7 = of step 1).
 // Measured: the 16x16x16 form runs at half the matrix rate on gfx950 (proto.cv2 in split mode sat at 250 TF/s of algorithmic flops = 3 x that in
 // f16 products, whatever the staging did), the 16x16x32 form at the full rate — so K-steps (taps, or channel steps) are paired wherever there are two.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 msl_mfma_split2(uint4 a0, uint4 a1, uint4 b0, uint4 b1, f32x4 acc) {
   const f16x8 ah = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)), al = __builtin_bit_cast(f16x8, make_uint4(a0.z, a0.w, a1.z, a1.w));
   const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(b0.x, b0.y, b1.x, b1.y)), bl = __builtin_bit_cast(f16x8, make_uint4(b0.z, b0.w, b1.z, b1.w));

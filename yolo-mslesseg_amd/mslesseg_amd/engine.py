@@ -106,8 +106,10 @@ def lds_col_perm(cot: int) -> torch.Tensor:
     return g * (4 * cot) + c * 4 + r
 
 
-def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
-    """[Cout,Cin,3,3] → the LDS image of conv3x3_lds.hip: [cout_blk][chunk][tap][g][COB rows, lds_col_perm order][CH] (include/mslesseg_hip.h)."""
+def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device, cot: Optional[int] = None):
+    """[Cout,Cin,3,3] → the LDS image of conv3x3_lds.hip: [cout_blk][chunk][tap][g][COB rows, lds_col_perm order][CH] (include/mslesseg_hip.h).
+    `cot` (16-channel output tiles per block) defaults to the widest block Cout allows; the fp32 engines ask for 2 on stride-1 layers of 64 input
+    channels: their four 16-channel chunks of 32-output-channel weights stay resident in LDS (persistent kernel) instead of being re-staged per tile."""
     cout, cin, _, _ = w.shape
     ch = 8 if dtype == MSL_BF16 else 4
     chunk = 4 * ch
@@ -115,7 +117,9 @@ def pack_conv3x3_lds(w: torch.Tensor, b: torch.Tensor, dtype: int, device):
     if cout == 8:  # pad to one 16-row block
         w = torch.cat([w, torch.zeros_like(w)], 0)
         cout = 16
-    cot = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
+    widest = 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
+    cot = widest if cot is None else cot
+    assert cot in (1, 2, 4) and cot <= widest
     # (measured: narrower channel blocks — smaller LDS slab, 3 workgroups per CU instead of 2 — are slower: 0.29 vs 0.25 ms on 64→64 @160²,
     # the halo is then staged once per block of 32 output channels)
     cob = 16 * cot
@@ -156,7 +160,12 @@ class PackedWeights:
             else:
                 cout, cin, k = s["cout"], s["cin"], s["k"]
                 if use_lds3x3 and lds3x3_eligible(cin, cout, k, dtype):
-                    self.t[name] = pack_conv3x3_lds(w, b, dtype, device)
+                    # MSL_F32_COT2=1 (measurement switch): fp32 tensors, stride 1, 64 input channels (proto.cv2, the 80² head convs) in 32-channel blocks → the
+                    # weights-resident kernel with four chunks.  Measured SLOWER than the tile kernel on the same box (fp32s, batch 128: proto.cv2 0.875 vs
+                    # 0.830 ms, cv2.0.0 0.272 vs 0.250): no weight slab per tile, but the halo is staged and converted once per 32-channel block and every
+                    # fragment read feeds half as many matrix instructions.  Off.
+                    cot = 2 if dtype != MSL_BF16 and s["s"] == 1 and cin == 64 and cout % 32 == 0 and os.environ.get("MSL_F32_COT2", "0") == "1" else None
+                    self.t[name] = pack_conv3x3_lds(w, b, dtype, device, cot)
                 else:
                     self._pack_gemm(name, pack_conv_weight(w), b, kstep)
 
