@@ -72,6 +72,8 @@ CONV_CASES = [
     (6, 40, 40, 320, 320, 1, 1, 320, 0, 320, 0, 0, 1, 0),    # K tail (320 = 5 chunks), Cout = 320: a partial third channel tile; accumulate
     (5, 40, 48, 512, 384, 1, 1, 512, 0, 384, 0, 0, 0, 1),    # fp32 output, 8 chunks, three channel tiles
     (24, 20, 20, 288, 256, 1, 1, 288, 0, 256, 0, 1, 0, 0),   # K = 288: the last chunk holds 32 channels
+    (4, 80, 80, 256, 64, 1, 1, 256, 0, 64, 0, 1, 0, 0),      # model.16.cv1: 64 output channels — the fp32 forms' 64-channel tile (four waves x 32 pixels)
+    (2, 70, 66, 192, 48, 1, 1, 256, 64, 64, 16, 0, 1, 0),    # ... with 48 of them, out of / into concat slices, residual, ragged pixel count
     (6, 40, 40, 272, 192, 1, 1, 272, 0, 192, 0, 1, 1, 0),    # K = 272: fp32 forms (32-channel chunks) end on a half chunk; residual read in the epilogue there
     # YOLO11s-seg widths (BASELINE configs[2])
     (1, 20, 20, 768, 256, 1, 1, 768, 0, 256, 0, 1, 0, 0),    # model.13.cv1 at scale s: K = 768 from the neck concat

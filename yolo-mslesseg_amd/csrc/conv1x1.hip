@@ -360,19 +360,24 @@ struct G1Args {
 // weight rows pre-split by the host, every wave rewrites the x pieces it staged as (hi x 4 | lo x 4) units before the chunk's barrier).  The fp32 forms
 // stage the same 128 bytes per row and chunk, i.e. 32 channels: the wide 1x1 layers of the fp32 engines (K x Cout too large for the streaming kernel's
 // LDS: 192 → 128, 384 → 128, 256 → 256, 384 / 512 → 256 ...) ran through conv_igemm_kernel before, at 50-60 TF/s (fp32) / 65-83 TF/s (split).
-template <bool STATS, int MODE = 0>
+// BN = 64 (fp32 forms): layers of at most 64 output channels (model.16.cv1, 256 -> 64 @80²) — the four waves take 32 pixels x 64 channels each instead of
+// computing a half-empty 128-channel tile (the fp32 form is matrix-core bound: 0.45 ms for that layer with BN = 128).
+template <bool STATS, int MODE = 0, int BN = 128>
 __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   static_assert(!(STATS && MODE), "the statistics epilogue is the bf16 training path");
+  static_assert(BN == 128 || (BN == 64 && MODE != 0), "64-channel tiles: fp32 forms");
   constexpr int ES = MODE ? 4 : 2, EPC = 16 / ES;
-  constexpr int BM = 128, BN = 128, BK = 128 / ES, PITCH = BK * ES + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
-  constexpr int PIECES = BM * CPR / 64;                                               // 18 per operand tile
-  constexpr int TILE = PIECES * 1024, STAGE = 2 * TILE;
+  constexpr int BM = 128, BK = 128 / ES, PITCH = BK * ES + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
+  constexpr int PIECES = BM * CPR / 64, PIECES_W = BN * CPR / 64;                    // 18 per pixel tile, 18 | 9 per weight tile
+  constexpr int TILE = PIECES_W * 1024, STAGE = TILE + PIECES * 1024;                // stage image: weight tile | pixel tile
+  constexpr int NPT = BN == 128 ? 4 : 2;                                             // 16-pixel tiles per wave
   constexpr int KP = (PIECES + 3) / 4;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_bias = (float*)(smem + 2 * STAGE);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, g = lane >> 4, wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 15, g = lane >> 4, wm = BN == 128 ? (wave & 1) : wave, wn = BN == 128 ? (wave >> 1) : 0;
+  const int pw0 = wm * NPT * 16;  // first pixel of this wave inside the tile
   const int tn = blockIdx.x % a.ntn;
   const long tm = blockIdx.x / a.ntn;
   const long p0 = tm * BM;
@@ -380,11 +385,11 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   for (int i = threadIdx.x; i < BN; i += 256) s_bias[i] = (a.bias && n0 + i < a.Cout) ? a.bias[n0 + i] : 0.f;
 
   // residual of this lane's 8 store groups (bf16 views), requested first
-  uint4 rpre[4][2];
+  uint4 rpre[NPT][2];
   if (MODE == 0 && a.res) {
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      long p = p0 + wm * 64 + pt * 16 + li;
+    for (int pt = 0; pt < NPT; ++pt) {
+      long p = p0 + pw0 + pt * 16 + li;
       p = p < a.M ? p : a.M - 1;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
     const int cidx = (wave + 4 * k) * 64 + lane, row = cidx / CPR, ch = cidx - row * CPR;
     const bool data = row < BM && ch < CPR - 1;
     xo[k] = (data && p0 + row < a.M) ? (unsigned)(row * a.x_cs * ES + ch * 16) : OOB;
-    wo[k] = (data && n0 + row < a.w_rows) ? (unsigned)(row * a.Kpad * ES + ch * 16) : OOB;
+    wo[k] = (data && row < BN && n0 + row < a.w_rows) ? (unsigned)(row * a.Kpad * ES + ch * 16) : OOB;
     chn[k] = (unsigned)ch * EPC;
   }
   const c1_i32x4 rx = c1_rsrc(a.x + (p0 * a.x_cs + a.x_co) * ES);
@@ -423,14 +428,14 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
         vx = (int)chn[k] < xleft ? vx : OOB;
         vw = (int)chn[k] < wleft ? vw : OOB;
       }
-      c1_dma16(rw, __builtin_amdgcn_readfirstlane(lw + pc * 1024), vw, soff);
+      if (pc < PIECES_W) c1_dma16(rw, __builtin_amdgcn_readfirstlane(lw + pc * 1024), vw, soff);
       c1_dma16(rx, __builtin_amdgcn_readfirstlane(lx + pc * 1024), vx, soff);
     }
   };
 
-  f32x4 acc[4][2][2];
+  f32x4 acc[NPT][2][2];
 #pragma unroll
-  for (int pt = 0; pt < 4; ++pt)
+  for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -456,43 +461,43 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
 #pragma unroll
       for (int ks = 0; ks < BK / 32; ++ks) {
         const int kb = (ks * 32 + 8 * g) * 2;
-        bf16x8 bfr[4];
+        bf16x8 bfr[NPT];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) bfr[pt] = *(const bf16x8*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+        for (int pt = 0; pt < NPT; ++pt) bfr[pt] = *(const bf16x8*)(sx_ + (pw0 + pt * 16 + li) * PITCH + kb);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const bf16x8 af = *(const bf16x8*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
+            for (int pt = 0; pt < NPT; ++pt) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[pt], acc[pt][c][m], 0, 0, 0);
           }
       }
     } else if constexpr (MODE == 1) {  // two K-steps of 16 channels: lane group g holds channels 4g..4g+3 of the step, MFMA i contracts element i of every group
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int kb = (ks * 16 + 4 * g) * 4;
-        f32x4 bfr[4];
+        f32x4 bfr[NPT];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) bfr[pt] = *(const f32x4*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
+        for (int pt = 0; pt < NPT; ++pt) bfr[pt] = *(const f32x4*)(sx_ + (pw0 + pt * 16 + li) * PITCH + kb);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const f32x4 af = *(const f32x4*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc[pt][c][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[pt][i], acc[pt][c][m], 0, 0, 0);
           }
       }
     } else {  // the chunk's two K-steps as one pair on the K = 32 f16 instruction (a zero-filled tail step contributes nothing)
       const int kb = 4 * g * 4, kb1 = kb + 64;
-      uint4 bfr[4], bfr1[4];
+      uint4 bfr[NPT], bfr1[NPT];
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        bfr[pt] = *(const uint4*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb);
-        bfr1[pt] = *(const uint4*)(sx_ + (wm * 64 + pt * 16 + li) * PITCH + kb1);
+      for (int pt = 0; pt < NPT; ++pt) {
+        bfr[pt] = *(const uint4*)(sx_ + (pw0 + pt * 16 + li) * PITCH + kb);
+        bfr1[pt] = *(const uint4*)(sx_ + (pw0 + pt * 16 + li) * PITCH + kb1);
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -501,13 +506,13 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
           const uint4 af = *(const uint4*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb);
           const uint4 af1 = *(const uint4*)(sw_ + (wn * 64 + c * 32 + arow + 4 * m) * PITCH + kb1);
 #pragma unroll
-          for (int pt = 0; pt < 4; ++pt) acc[pt][c][m] = msl_mfma_split2(af, af1, bfr[pt], bfr1[pt], acc[pt][c][m]);
+          for (int pt = 0; pt < NPT; ++pt) acc[pt][c][m] = msl_mfma_split2(af, af1, bfr[pt], bfr1[pt], acc[pt][c][m]);
         }
     }
   }
   if constexpr (MODE == 2) {
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
+    for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -522,8 +527,8 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
       for (int r = 0; r < 8; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
   }
 #pragma unroll
-  for (int pt = 0; pt < 4; ++pt) {
-    const long p = p0 + wm * 64 + pt * 16 + li;
+  for (int pt = 0; pt < NPT; ++pt) {
+    const long p = p0 + pw0 + pt * 16 + li;
     if (p >= a.M) continue;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -616,19 +621,24 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
   MSL_REQUIRE(a.x && a.w && a.y && msl_gemm1x1_eligible(op), "gemm1x1: bad args");
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs && (!a.res || a.res_co + a.Cout <= a.res_cs), "gemm1x1: bad dims / views");
-  a.ntn = (a.Cout + 127) / 128;
+  const bool f32 = op.dtype != MSL_BF16, narrow = f32 && a.Cout <= 64;
+  a.ntn = narrow ? 1 : (a.Cout + 127) / 128;
   const long tiles = (a.M + 127) / 128 * a.ntn;
   MSL_REQUIRE(tiles < (1L << 31), "gemm1x1: too many tiles");
-  constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4;
+  constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4;  // (the 64-channel forms use 2 x 27 KiB of it)
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     attr = true;
   }
-  if (op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  if (narrow && op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else if (narrow) hipLaunchKernelGGL((gemm1x1_kernel<false, 1, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else if (op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   else if (op.dtype == MSL_F32) hipLaunchKernelGGL((gemm1x1_kernel<false, 1>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   else if (a.acc) hipLaunchKernelGGL((gemm1x1_kernel<true, 0>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   else hipLaunchKernelGGL((gemm1x1_kernel<false, 0>), dim3((unsigned)tiles), dim3(256), LDS, s, a);

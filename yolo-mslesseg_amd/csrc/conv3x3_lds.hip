@@ -1035,8 +1035,9 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
       return launch3p<false, 4, 2, true>(a, cout_blocks, s);
     }
     // fp32 tensors with four chunks (64 input channels): 32-channel output blocks fit (the host packs such layers with COT = 2 for the fp32 engines)
+    // (split-precision layers take this kernel for four chunks only — the one shape it was measured on; the others keep the tile kernel unless i[23] = -9 asks)
     const bool pays4 = f32 && nch == 4 && cot == 2 && a.Cin % chunk == 0 && tiles >= 1024;
-    if (stride == 1 && rw == 2 && (nch <= 2 || (f32 && nch == 4)) && fits && (pays || pays4 || op.i[23] == -9) && op.i[23] != -8) {
+    if (stride == 1 && rw == 2 && (nch <= 2 || (f32 && nch == 4)) && fits && ((pays && !split) || pays4 || op.i[23] == -9) && op.i[23] != -8) {
 #define L3P(F, NCH_, SP)                                                             \
   do {                                                                               \
     if (cot == 4) return launch3p<F, 4, NCH_, false, 2, SP>(a, cout_blocks, s);      \
