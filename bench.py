@@ -390,6 +390,11 @@ def train_roofline(tr, dbatch, args, value_per_gpu):
                     shape = f"  N{I[0]} {I[1]}x{I[2]} C{I[3]}" + (f" -> {I[4]}x{I[5]} C{I[6]} k{I[7]} s{I[8]}" if kind in (hiplib.OP_CONV, hiplib.OP_CONV_WGRAD, hiplib.OP_DW_WGRAD, hiplib.OP_DWCONV) else "")
                     if kind in (hiplib.OP_CONV, hiplib.OP_CONV_WGRAD):
                         shape += f"  {conv_flops(it, kind == hiplib.OP_CONV_WGRAD) / (ms_ * 1e-3) / 1e12:7.1f} TF/s" + ("  dgrad" if kind == hiplib.OP_CONV and I[22] else "")
+                    by = op_bytes(kind, it)
+                    if by > 0:  # algorithmic bytes, their rate, and the launch's time beyond max(bytes at the copy rate, flops at the MFMA peak)
+                        fl = conv_flops(it, kind == hiplib.OP_CONV_WGRAD) if kind in (hiplib.OP_CONV, hiplib.OP_CONV_WGRAD) else 0.0
+                        floor = max(by / 5.5e12, fl / (PEAK[args.dtype] * 1e12)) * 1e3
+                        shape += f"  | {by / 1e6:8.1f} MB {by / (ms_ * 1e-3) / 1e9:7.0f} GB/s  excess {ms_ - floor:7.4f} ms"
                 f.write(f"{tag:5s} {names.get(kind, 'torch-attention'):22s} {ms_:9.4f} ms{shape}\n")
     return roof
 

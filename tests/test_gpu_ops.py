@@ -297,18 +297,21 @@ def test_dwconv_lds_tiled_form_equals_the_pixel_pair_form(case):
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 def test_sppf_pool_equals_three_chained_maxpools(dtype):
+    """Both kernels (64 bytes per pixel and workgroup: the default; 4 channels per workgroup: i[23] = -1), plain and inside a wider buffer."""
     g = torch.Generator().manual_seed(11)
-    N, H, W, C = 2, 20, 17, 32
-    buf = _rand_act((N, H, W, 4 * C), dtype, g)
-    y0 = buf[..., :C].float().permute(0, 3, 1, 2)
-    y1 = F.max_pool2d(y0, 5, 1, 2)
-    y2 = F.max_pool2d(y1, 5, 1, 2)
-    y3 = F.max_pool2d(y2, 5, 1, 2)
-    ref = torch.cat([y0, y1, y2, y3], 1).permute(0, 2, 3, 1)
-    bd = buf.to(DEV)
-    hiplib.launch(hiplib.make_op(hiplib.OP_SPPF_POOL, dtype, p=(bd.data_ptr(),), i={0: N, 1: H, 2: W, 3: C, 10: 4 * C, 11: 0}), _stream())
-    torch.cuda.synchronize()
-    assert torch.equal(bd.float().cpu(), ref)  # max is exact in any dtype
+    for (N, H, W, C, cs, co) in [(2, 20, 17, 32, 128, 0), (3, 20, 20, 128, 512, 0), (2, 13, 9, 24, 112, 16), (1, 5, 3, 8, 40, 8)]:
+        buf = _rand_act((N, H, W, cs), dtype, g)
+        y0 = buf[..., co : co + C].float().permute(0, 3, 1, 2)
+        y1 = F.max_pool2d(y0, 5, 1, 2)
+        y2 = F.max_pool2d(y1, 5, 1, 2)
+        y3 = F.max_pool2d(y2, 5, 1, 2)
+        ref = buf.float().clone()
+        ref[..., co : co + 4 * C] = torch.cat([y0, y1, y2, y3], 1).permute(0, 2, 3, 1)
+        for sel in (0, -1):
+            bd = buf.to(DEV)
+            hiplib.launch(hiplib.make_op(hiplib.OP_SPPF_POOL, dtype, p=(bd.data_ptr(),), i={0: N, 1: H, 2: W, 3: C, 10: cs, 11: co, 23: sel}), _stream())
+            torch.cuda.synchronize()
+            assert torch.equal(bd.float().cpu(), ref), f"sppf {(N, H, W, C, cs, co)} kernel {sel}"  # max is exact in any dtype; nothing outside the view is touched
 
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])

@@ -495,10 +495,92 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(void* __restrict__ buf, 
   }
 }
 
+// The same pools as upstream computes them — y1 = m(x), y2 = m(y1), y3 = m(y2), m = 5x5 / s1 / p2 — on 64 contiguous bytes per pixel and workgroup.
+// The kernel above gives a workgroup 4 channels: every thread's 8-byte (bf16) access sits in its own 1-KiB-strided pixel, so each 64-byte sector was
+// fetched for 8 bytes by 8 different workgroups (20² x 128 at batch 128: 0.085 ms for 52 MB of tensor, 0.6 TB/s).  Here four consecutive threads move
+// one pixel's 64 bytes, a stage is a 5-tap row pass and a 5-tap column pass between two LDS planes of 16-byte units (30 LDS reads per unit for the
+// three outputs instead of 52), and maxima are taken on the raw units (exact in any dtype).
+__device__ __forceinline__ uint4 unit_max_f32(uint4 a, uint4 b) {
+  return make_uint4(__float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))), __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y))),
+                    __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))), __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w))));
+}
+__device__ __forceinline__ unsigned pair_max_bf16(unsigned a, unsigned b) {
+  const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16)), hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
+  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+template <bool F32>
+__device__ __forceinline__ uint4 unit_max(uint4 a, uint4 b) {
+  if constexpr (F32) return unit_max_f32(a, b);
+  else return make_uint4(pair_max_bf16(a.x, b.x), pair_max_bf16(a.y, b.y), pair_max_bf16(a.z, b.z), pair_max_bf16(a.w, b.w));
+}
+template <bool F32>
+__global__ __launch_bounds__(256) void sppf_pool_chain_kernel(void* __restrict__ buf, int N, int H, int W, int C, int cs, int co) {
+  constexpr int EPC = F32 ? 4 : 8, ES = F32 ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_[];
+  const int HW = H * W, units = C / EPC, ug = (units + 3) >> 2;
+  const int n = blockIdx.x / ug, u0 = (blockIdx.x - n * ug) * 4, nu = min(4, units - u0);
+  uint4* A = (uint4*)sm_;
+  uint4* B = A + HW * 4;
+  char* base = (char*)buf + ((long)n * HW * cs + co) * ES + u0 * 16;
+  const long pstride = (long)cs * ES;
+  const int items = HW * 4;
+  for (int idx = threadIdx.x; idx < items; idx += 256) {
+    const int p = idx >> 2, u = idx & 3;
+    if (u < nu) A[idx] = *(const uint4*)(base + p * pstride + u * 16);
+  }
+  __syncthreads();
+  for (int st = 1; st <= 3; ++st) {
+    for (int idx = threadIdx.x; idx < items; idx += 256) {  // row pass: A -> B
+      const int p = idx >> 2, u = idx & 3;
+      if (u >= nu) continue;
+      const int y = p / W, x = p - y * W;
+      uint4 m = A[idx];
+#pragma unroll
+      for (int dx = -2; dx <= 2; ++dx) {
+        if (dx == 0 || (unsigned)(x + dx) >= (unsigned)W) continue;
+        m = unit_max<F32>(m, A[idx + dx * 4]);
+      }
+      B[idx] = m;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < items; idx += 256) {  // column pass: B -> A (the next stage's input) and the output view
+      const int p = idx >> 2, u = idx & 3;
+      if (u >= nu) continue;
+      const int y = p / W;
+      uint4 m = B[idx];
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+        if (dy == 0 || (unsigned)(y + dy) >= (unsigned)H) continue;
+        m = unit_max<F32>(m, B[idx + dy * W * 4]);
+      }
+      A[idx] = m;
+      *(uint4*)(base + p * pstride + u * 16 + (long)st * C * ES) = m;
+    }
+    __syncthreads();
+  }
+}
+
 int msl_launch_sppf_pool(const msl_op& op, hipStream_t s) {
   int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], cs = op.i[10], co = op.i[11];
   MSL_REQUIRE(op.p[0], "sppf: null pointer");
   MSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && co + 4 * C <= cs, "sppf: bad dims/view");
+  {
+    const int epc = op.dtype == MSL_BF16 ? 8 : 4;
+    const size_t lds2 = (size_t)H * W * 128;
+    if (C % epc == 0 && cs % epc == 0 && co % epc == 0 && lds2 <= 150 * 1024 && op.i[23] != -1) {  // i[23] = -1 keeps the 4-channel kernel (A/B measurements and tests)
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)sppf_pool_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)sppf_pool_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr2 = true;
+      }
+      const unsigned grid2 = (unsigned)(N * ((C / epc + 3) / 4));
+      if (op.dtype == MSL_BF16) hipLaunchKernelGGL(sppf_pool_chain_kernel<false>, dim3(grid2), dim3(256), lds2, s, op.p[0], N, H, W, C, cs, co);
+      else hipLaunchKernelGGL(sppf_pool_chain_kernel<true>, dim3(grid2), dim3(256), lds2, s, op.p[0], N, H, W, C, cs, co);
+      MSL_CHECK_LAUNCH("sppf_pool");
+      return MSL_OK;
+    }
+  }
   const size_t lds = (size_t)H * W * 64;
   MSL_REQUIRE(lds <= 150 * 1024, "sppf: plane too large for LDS (H*W <= 2400)");
   static bool attr = false;
