@@ -90,8 +90,11 @@ enum {
   MSL_OP_CONV = 1,
   /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
    * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y
-   * i: 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout(16|32),12 y_cs,13 y_co,18 act, 19 = 9 selects the thread-per-pixel kernel instead of the LDS-tile one
-   *    (bit-identical results; A/B measurements and tests) */
+   * i: 0 N,1 H,2 W,4 Ho,5 Wo,6 Cout(16|32),12 y_cs,13 y_co,18 act, 19 kernel selector: 0 = default (bf16 tensors: matrix-core kernel — patch bytes as exact
+   *    bf16 integers, fp32 weights as hi + lo bf16 halves, 1/255 on the fp32 accumulator; fp32 tensors: the VALU LDS-tile kernel), 8 = the VALU LDS-tile kernel,
+   *    9 = the thread-per-pixel kernel (8 and 9 give bit-identical results; A/B measurements and tests)
+   * p 5 (optional, bf16 matrix-core kernel only, act = 0): BatchNorm accumulator f64[slots][2*Cout] with i 23 = slots — per-channel (sum, sum of squares) of the
+   *    stored values, as MSL_OP_CONV's statistics epilogue */
   MSL_OP_STEM = 2,
   /* Depthwise 3x3 stride-1 pad-1: y = act(dw(x) + bias) [+ res].
    * p: 0 x, 1 w f32 [9][C], 2 bias f32[C], 3 res|NULL, 4 y

@@ -209,7 +209,7 @@ def test_conv_rejects_bad_descriptor():
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
 @pytest.mark.parametrize("cout", [16, 32])
 def test_stem(dtype, cout):
-    for N, H, W in ((2, 64, 96), (3, 45, 71), (1, 17, 130)):  # even; odd sizes with rows that are not dword multiples; one wide tile row
+    for N, H, W in ((2, 64, 96), (3, 45, 71), (1, 17, 130), (2, 100, 67)):  # even; odd sizes with rows that are not dword multiples; one wide tile row; ragged tiles
         g = torch.Generator().manual_seed(7 + H)
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
@@ -218,16 +218,49 @@ def test_stem(dtype, cout):
         ref = F.silu(F.conv2d(img.float().permute(0, 3, 1, 2) / 255, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
         wd = w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV)
         bd, xd = b.to(DEV), img.to(DEV)
-        outs = []
-        for form in (0, 9):  # LDS-tile kernel, thread-per-pixel kernel (i[19] = 9)
+        outs = {}
+        for form in (0, 8, 9):  # default (bf16: matrix-core kernel; fp32: the LDS-tile kernel), LDS-tile kernel, thread-per-pixel kernel
             yd = torch.zeros((N, Ho, Wo, cout), dtype=_tdt(dtype), device=DEV)
             op = hiplib.make_op(hiplib.OP_STEM, dtype, p=(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 0, yd.data_ptr()),
                                 i={0: N, 1: H, 2: W, 4: Ho, 5: Wo, 6: cout, 12: cout, 13: 0, 18: 1, 19: form})
             hiplib.launch(op, _stream())
             torch.cuda.synchronize()
             _close(yd, ref, dtype, f"stem {(N, H, W)} form {form}")
-            outs.append(yd.float().cpu())
-        assert torch.equal(outs[0], outs[1]), "the two stem kernels must agree bit for bit (same taps, same fma order)"
+            outs[form] = yd.float().cpu()
+        assert torch.equal(outs[8], outs[9]), "the two VALU stem kernels must agree bit for bit (same taps, same fma order)"
+        if dtype == MSL_F32:
+            assert torch.equal(outs[0], outs[8])
+        else:  # the matrix-core kernel: exact patch bytes x (hi + lo bf16) weights, fp32 accumulation — within one bf16 rounding of the fp32 VALU kernel's output
+            err = (outs[0] - outs[8]).abs().max().item()
+            assert err <= 2.0**-8 * (1 + outs[8].abs().max().item()), f"stem matrix-core kernel vs the VALU kernel: {err:.3e}"
+            assert (outs[0] != outs[8]).float().mean().item() < 0.02  # ... and different only where the fp32 sums straddle a rounding boundary
+
+
+@pytest.mark.parametrize("cout", [16, 32])
+def test_stem_batchnorm_statistics_epilogue(cout):
+    """bf16 matrix-core stem with p[5]: per-channel (sum, sum of squares) of the stored (bf16-rounded) raw outputs in the slot-replicated fp64 accumulators."""
+    g = torch.Generator().manual_seed(31 + cout)
+    N, H, W, slots = 3, 90, 70, 8
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    img = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+    w = (torch.rand((cout, 3, 3, 3), generator=g) * 2 - 1) / 27**0.5
+    wd = w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV)
+    zeros, xd = torch.zeros(cout, device=DEV), img.to(DEV)
+    yd = torch.zeros((N, Ho, Wo, cout), dtype=torch.bfloat16, device=DEV)
+    acc = torch.zeros(slots * 2 * cout, dtype=torch.float64, device=DEV)
+    op = hiplib.make_op(hiplib.OP_STEM, MSL_BF16, p=(xd.data_ptr(), wd.data_ptr(), zeros.data_ptr(), 0, yd.data_ptr(), acc.data_ptr()),
+                        i={0: N, 1: H, 2: W, 4: Ho, 5: Wo, 6: cout, 12: cout, 13: 0, 18: 0, 23: slots})
+    hiplib.launch(op, _stream())
+    torch.cuda.synchronize()
+    z = yd.float().cpu().reshape(-1, cout).double()
+    ref = F.conv2d(img.float().permute(0, 3, 1, 2) / 255, w, None, stride=2, padding=1).permute(0, 2, 3, 1)
+    _close(yd.cpu(), ref, MSL_BF16, "stem raw")
+    got = acc.cpu().view(slots, cout, 2).sum(0)
+    assert torch.allclose(got[:, 0], z.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(got[:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)
+    with pytest.raises(hiplib.MslError):  # the epilogue exists in that kernel only
+        hiplib.launch(hiplib.make_op(hiplib.OP_STEM, MSL_F32, p=(xd.data_ptr(), wd.data_ptr(), zeros.data_ptr(), 0, yd.data_ptr(), acc.data_ptr()),
+                                     i={0: N, 1: H, 2: W, 4: Ho, 5: Wo, 6: cout, 12: cout, 13: 0, 18: 0, 23: slots}), _stream())
 
 
 @pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])

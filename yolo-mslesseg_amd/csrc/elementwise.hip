@@ -144,6 +144,201 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const uint8_t* __restric
   }
 }
 
+// Matrix-core form (bf16 tensors): the 27 taps x 16 output channels of a pixel are 432 fp32 fmas on the VALU — 11.3 GFLOP per 128-slice batch, 0.14 ms at the
+// VALU's full fma rate, so the tile kernel above (0.24 ms) is VALU-bound while the tensors it touches (577 MB) are worth 0.10 ms.  Here a 16-pixel run x 16 channels
+// is ONE v_mfma_f32_16x16x32_bf16: B = the pixel's 27 patch bytes as bf16 (integers 0..255 are exact in bf16; the 1/255 is applied to the fp32 accumulator),
+// picked from the same LDS patch image (contraction order chosen so that a lane's 8 bytes are one run of a patch row: three dword reads + two funnel shifts; taps outside the image zeroed),
+// A = the weight rows as hi + lo bf16 halves (fp32-grade weights, two MFMAs; held in registers for the life of the workgroup).  Persistent workgroups walk the tiles
+// (the next tile's patch is fetched into registers under the current tile's arithmetic), which also lets the train-mode BatchNorm statistics of the stored
+// values ride in the epilogue (p 5 / i 23 as MSL_OP_CONV: the separate BN_STATS pass over the 320² x 16 tensor — 0.096 ms — disappears).
+template <int COUT, bool STATS>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        unsigned short* __restrict__ y, int N, int H, int W, int Ho, int Wo, int y_cs, int y_co, int act,
+                                                        int tiles_x, int tiles_y, int total_tiles, double* __restrict__ accd, int slots) {
+  constexpr int TH = 16, TW = 32, ROWS = 2 * TH + 1, RD = 52, NT = COUT / 16, PER = (ROWS * 50 + 255) / 256;  // 16 x 32 output pixels per tile: 33 patch rows
+  __shared__ __attribute__((aligned(16))) uint32_t tile[ROWS * RD + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  // ---- contraction order (free, as long as both operands use it): lane group g < 3 holds the first 8 of the 9 patch bytes of row ky = g (bytes kx*3 + ci:
+  // ONE unaligned 8-byte run in LDS), group 3 holds byte 8 (kx = 2, ci = 2) of rows 0, 1, 2 and five zeros.
+  // A operand: lane (li, g), element j ↔ tap-channel k(g, j) of output channel t*16 + li
+  // The fp32 weights enter as hi + lo bf16 halves (two MFMAs per run; the patch bytes are exact): the stem keeps fp32-grade weights like the VALU kernels —
+  // the first layer's rounding is what every later layer amplifies (tests/test_gpu_e2e.py::test_forward_bf16_close_to_oracle).
+  bf16x8 af[NT], afl[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    unsigned pk[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      unsigned hb[2], lb[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int jj = j + e;
+        const int k = g < 3 ? g * 9 + jj : (jj < 3 ? jj * 9 + 8 : -1);
+        const float wv = k >= 0 ? w[k * COUT + t * 16 + li] : 0.f;
+        hb[e] = f32_to_bf16_bits(wv);
+        lb[e] = f32_to_bf16_bits(wv - bf16_bits_to_f32(hb[e]));
+      }
+      pk[j >> 1] = hb[0] | (hb[1] << 16);
+      pl[j >> 1] = lb[0] | (lb[1] << 16);
+    }
+    af[t] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    afl[t] = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+  }
+  float bv[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[t][r] = bias[t * 16 + 4 * g + r];
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+  const long total = (long)N * H * W * 3;
+  // patch staging: 33 rows x 50 dwords; thread t moves dwords t, t + 256, ... — row / column of each are fixed over the tiles
+  int pr[PER], pd[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    pr[q] = i < ROWS * 50 ? i / 50 : -1;
+    pd[q] = i - (i / 50) * 50;
+  }
+  const long last4 = (total - 4) & ~3L;
+  auto fetch = [&](int tl, uint32_t (&pre)[PER]) __attribute__((always_inline)) {  // tile tl's patch → registers: every lane loads (clamped address), nothing is waited for here
+    int b = tl < total_tiles ? tl : total_tiles - 1;
+    const int txi = b % tiles_x; b /= tiles_x;
+    const int tyi = b % tiles_y;
+    const int n = b / tiles_y;
+    const long img0 = (long)n * H * W * 3;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int iy = 2 * tyi * TH - 1 + pr[q];
+      const long b0 = img0 + ((long)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W + (2 * txi * TW - 1)) * 3;
+      long off = (b0 & ~3L) + 4 * pd[q];
+      off = off < 0 ? 0 : (off > last4 ? last4 : off);  // bytes before / behind the buffer only ever belong to taps outside the image (masked below); the
+                                                        // buffer is a whole number of dwords (launcher), so no dword straddles its end
+      pre[q] = *(const uint32_t*)(x + off);
+    }
+  };
+  auto commit = [&](int tl, uint32_t (&pre)[PER]) __attribute__((always_inline)) {
+    const int tyi = (tl / tiles_x) % tiles_y;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (pr[q] < 0) continue;
+      const int iy = 2 * tyi * TH - 1 + pr[q];
+      tile[pr[q] * RD + pd[q]] = (unsigned)iy < (unsigned)H ? pre[q] : 0u;  // rows outside the image are zeros
+    }
+  };
+  auto compute = [&](int tl) __attribute__((always_inline)) {
+    int b = tl;
+    const int txi = b % tiles_x; b /= tiles_x;
+    const int tyi = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const long img0 = (long)n * H * W * 3;
+#pragma unroll  // (a real loop here makes hipcc drain vmcnt(0) in its preheader — i.e. wait for the patch prefetch just issued: SIInsertWaitcnts flushes before loops with stores)
+    for (int q = 0; q < 2 * (TH / 4); ++q) {  // this wave's 16-pixel runs: rows (TH/4)*wave .. + TH/4 - 1 x two halves
+      const int ly = (TH / 4) * wave + (q >> 1), lx = (q & 1) * 16 + li;
+      const int oy = oy0 + ly, ox = ox0 + lx;
+      int al[3];  // byte alignment of the three patch rows inside their dword-aligned LDS rows
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) al[ky] = (int)((img0 + ((long)(2 * oy - 1 + ky) * W + (2 * ox0 - 1)) * 3) & 3);
+      // groups 0-2: bytes 0..7 of row g from three aligned dwords + two funnel shifts; group 3: byte 8 of the three rows
+      const int rg = g < 3 ? g : 0;
+      const int ba = (2 * ly + rg) * (RD * 4) + (rg == 0 ? al[0] : (rg == 1 ? al[1] : al[2])) + 6 * lx;
+      const uint32_t* dq = tile + (ba >> 2);
+      const uint32_t u0 = dq[0], u1 = dq[1], u2 = dq[2];
+      const unsigned sh = (unsigned)ba & 3u;
+      unsigned lo = __builtin_amdgcn_alignbyte(u1, u0, sh), hi = __builtin_amdgcn_alignbyte(u2, u1, sh);
+      const uint8_t* b8 = (const uint8_t*)tile + (2 * ly) * (RD * 4) + 6 * lx + 8;
+      const unsigned t0 = b8[al[0]], t1 = b8[RD * 4 + al[1]], t2 = b8[2 * RD * 4 + al[2]];
+      const bool left = 2 * ox - 1 >= 0, right = 2 * ox + 1 < W;  // tap columns kx = 0 / kx = 2 inside the image (rows outside it were staged as zeros)
+      if (g == 3) { lo = right ? (t0 | (t1 << 8) | (t2 << 16)) : 0u; hi = 0u; }
+      else {
+        if (!left) lo &= 0xff000000u;   // bytes 0..2 = column kx = 0
+        if (!right) hi &= 0x0000ffffu;  // bytes 6, 7 = column kx = 2 (ci 0, 1)
+      }
+      unsigned pk[4];  // integers 0..255 → bf16 bits: exact
+      pk[0] = (__float_as_uint((float)(lo & 0xffu)) >> 16) | (__float_as_uint((float)((lo >> 8) & 0xffu)) & 0xffff0000u);
+      pk[1] = (__float_as_uint((float)((lo >> 16) & 0xffu)) >> 16) | (__float_as_uint((float)(lo >> 24)) & 0xffff0000u);
+      pk[2] = (__float_as_uint((float)(hi & 0xffu)) >> 16) | (__float_as_uint((float)((hi >> 8) & 0xffu)) & 0xffff0000u);
+      pk[3] = (__float_as_uint((float)((hi >> 16) & 0xffu)) >> 16) | (__float_as_uint((float)(hi >> 24)) & 0xffff0000u);
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      const bool inside = oy < Ho && ox < Wo;
+      const long oi = (((long)n * Ho + oy) * Wo + ox) * y_cs + y_co + 4 * g;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[t], bf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf, acc, 0, 0, 0);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[r], 1.0f / 255.0f, bv[t][r]);
+        if constexpr (STATS) {
+          if (inside) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float vr = bf16_bits_to_f32(f32_to_bf16_bits(v[r]));  // statistics of the values actually stored
+              s1[t][r] += vr;
+              s2[t][r] = fmaf(vr, vr, s2[t][r]);
+            }
+          }
+        }
+        if (act) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        }
+        if (inside) {
+          uint2 o;
+          o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+          o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+          *(uint2*)(y + oi + t * 16) = o;
+        }
+      }
+    }
+  };
+  // two tiles' patches in flight per workgroup (a tile's arithmetic is a fraction of a memory round trip)
+  uint32_t preA[PER], preB[PER];
+  const int G = (int)gridDim.x;
+  int tl = (int)blockIdx.x;
+  fetch(tl, preA);
+  fetch(tl + G, preB);
+  while (tl < total_tiles) {
+    __syncthreads();  // everyone is done with the previous tile's image
+    commit(tl, preA);
+    __syncthreads();
+    fetch(tl + 2 * G, preA);
+    compute(tl);
+    tl += G;
+    if (tl >= total_tiles) break;
+    __syncthreads();
+    commit(tl, preB);
+    __syncthreads();
+    fetch(tl + 2 * G, preB);
+    compute(tl);
+    tl += G;
+  }
+  if constexpr (STATS) {  // fold: the 16 pixel lanes (DPP), the 4 waves (LDS), one fp64 atomic per channel and statistic
+    __syncthreads();
+    float* red = (float*)tile;  // [4 waves][2][COUT]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = row16_sum(s1[t][r]), t2 = row16_sum(s2[t][r]);
+        if (li == 0) {
+          red[(wave * 2 + 0) * COUT + t * 16 + 4 * g + r] = t1;
+          red[(wave * 2 + 1) * COUT + t * 16 + 4 * g + r] = t2;
+        }
+      }
+    __syncthreads();
+    double* dst = accd + (long)(blockIdx.x % slots) * 2 * COUT;
+    for (int i = threadIdx.x; i < 2 * COUT; i += 256) {
+      const int st = i / COUT, ch = i - st * COUT;
+      atomicAdd(dst + 2 * ch + st, (double)(red[(0 * 2 + st) * COUT + ch] + red[(1 * 2 + st) * COUT + ch] + red[(2 * 2 + st) * COUT + ch] + red[(3 * 2 + st) * COUT + ch]));
+    }
+  }
+}
+
 int msl_launch_stem(const msl_op& op, hipStream_t s) {
   const uint8_t* x = (const uint8_t*)op.p[0];
   const float* w = (const float*)op.p[1];
@@ -155,6 +350,24 @@ int msl_launch_stem(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(Cout == 16 || Cout == 32, "stem: Cout=%d unsupported (16|32)", Cout);
   MSL_REQUIRE(y_cs % 4 == 0 && y_co % 4 == 0 && y_co + Cout <= y_cs, "stem: bad output view");
   const bool f32 = op.dtype == MSL_F32;
+  MSL_REQUIRE(!op.p[5] || (op.dtype == MSL_BF16 && op.i[19] == 0 && ((uintptr_t)x & 3) == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && op.i[23] >= 1 && op.i[23] <= 16 && act == 0),
+              "stem: the BatchNorm-statistics epilogue (p[5], i[23] slots) exists in the bf16 matrix-core kernel only (raw conv, 4-byte-aligned image)");
+  const bool whole_dwords = ((long)N * H * W * 3) % 4 == 0;  // the patch loads are aligned dwords, clamped to the buffer: it must end on one (else: the VALU kernels)
+  MSL_REQUIRE(!op.p[5] || whole_dwords, "stem: the statistics epilogue needs an image buffer of whole dwords (N*H*W*3 %% 4 == 0)");
+  if (op.dtype == MSL_BF16 && op.i[19] == 0 && ((uintptr_t)x & 3) == 0 && whole_dwords) {  // matrix-core kernel (i[19] = 8: the VALU tile kernel, 9: the thread-per-pixel kernel)
+    const int tiles_x = (Wo + 31) / 32, tiles_y = (Ho + 15) / 16;
+    const long tiles = (long)N * tiles_x * tiles_y;
+    MSL_REQUIRE(tiles < (1L << 31) - 8192 && (long)N * H * W * 3 >= 8, "stem: too many tiles / image too small");
+    long wgs = tiles < 2048 ? tiles : 2048;  // persistent: up to 8 workgroups per CU
+    double* accd = (double*)op.p[5];
+    const int slots = op.i[23] > 0 ? op.i[23] : 1;
+#define STEMM(C, ST) hipLaunchKernelGGL((stem_mfma_kernel<C, ST>), dim3((unsigned)wgs), dim3(256), 0, s, x, w, b, (unsigned short*)y, N, H, W, Ho, Wo, y_cs, y_co, act, tiles_x, tiles_y, (int)tiles, accd, slots)
+    if (accd) { if (Cout == 16) STEMM(16, true); else STEMM(32, true); }
+    else      { if (Cout == 16) STEMM(16, false); else STEMM(32, false); }
+#undef STEMM
+    MSL_CHECK_LAUNCH("stem_mfma");
+    return MSL_OK;
+  }
   if (op.i[19] != 9 && ((uintptr_t)x & 3) == 0) {  // tile kernel (i[19] = 9 keeps the thread-per-pixel form: A/B tests)
     const int tiles_x = (Wo + 31) / 32, tiles_y = (Ho + 7) / 8;
     const unsigned tgrid = (unsigned)((long)N * tiles_x * tiles_y);

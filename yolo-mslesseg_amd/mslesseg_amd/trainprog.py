@@ -465,9 +465,11 @@ class TrainPlan(graph.Visitor):
         st = self.store
         Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
         z, y = self._new(Ho, Wo, cout), self._new(Ho, Wo, cout)
-        self._f(hiplib.make_op(hiplib.OP_STEM, self.dtype, p=(x.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), 0, z.t.data_ptr()),
-                               i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 18: 0}))
-        stats = self._bn_forward(name, z, y, cout, True, None)
+        # bf16: the matrix-core stem kernel accumulates the BatchNorm sums of the values it stores (p 5 / i 23 as the conv ops): no BN_STATS pass
+        acc = self._acc(cout) if self.dtype == MSL_BF16 and os.environ.get("MSL_STEM_STATS", "1") == "1" else None
+        self._f(hiplib.make_op(hiplib.OP_STEM, self.dtype, p=(x.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), 0, z.t.data_ptr(), 0 if acc is None else acc.data_ptr()),
+                               i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 18: 0, 23: 0 if acc is None else ACC_SLOTS}))
+        stats = self._bn_forward(name, z, y, cout, True, None, acc=acc)
         self.taps[name] = y
 
         def bw():
