@@ -253,15 +253,13 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       const int pc = wave + 4 * j;
       if (pc < IN_PIECES) {
         const char* src = in_off[j] >= 0 ? ximg + in_off[j] + cc * (CHUNK * ES) : (const char*)msl_zero_page;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(s_in + pc * 1024), 16, 0, 0);
+        msl_glds16(src, msl_lds_addr(s_in + pc * 1024));
       }
     }
     // ---- weights: contiguous copy of this (cout block, chunk) slab
     const char* wsrc = wlane + (long)cc * W_BYTES;
     for (int pc = wave; pc < W_PIECES; pc += 4, wsrc += 4096) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
-                                       (__attribute__((address_space(3))) void*)(s_w + pc * 1024), 16, 0, 0);
+      msl_glds16(wsrc, msl_lds_addr(s_w + pc * 1024));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (SPLIT) {
@@ -1015,7 +1013,9 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   if (a.res) MSL_REQUIRE(a.res_cs % oal == 0 && a.res_co % oal == 0 && a.res_co + a.Cout <= a.res_cs, "conv3x3_lds: bad residual view");
   const int cout_blocks = (a.Cout + 16 * cot - 1) / (16 * cot);  // Cout = 8: one block of 16 rows, the upper 8 zero
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
-  const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : 1;  // i[23]=-4 opts into the 16x32 tile (measured slower: kept for experiments)
+  // i[23]=-4 opts into the 16x32 tile at stride 1 (measured slower: kept for experiments); i[23]=-5 into the 8x32 tile at stride 2 (17-row halo, 73 KiB: one
+  // workgroup per CU, but the weight slab and the halo's shared rows are staged once per 256 instead of 128 output pixels)
+  const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : (op.i[23] == -5 ? 2 : 1);
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1084,7 +1084,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   // measured at batch 128 (scripts/dev_narrow3x3_ab.py, profiles/r03h_narrow3x3_ab.txt): 320² 16->32 s2 0.263 -> 0.199 ms, 160² 8->16 0.094 -> 0.065 ms;
   // two k-groups at stride 1 are SLOWER than the full-width image (160² 16->8 0.081 -> 0.091, 16->16 0.083 -> 0.093): taken only when i[23] = -6 asks
   const int kg = (!f32 && a.Cin < chunk && a.Cin % 8 == 0 && op.i[23] != -7) ? a.Cin / 8 : 4;
-  if ((kg == 1 || (kg == 2 && (stride == 2 || op.i[23] == -6))) && cot <= 2 && rw != 4) {
+  if ((kg == 1 || (kg == 2 && (stride == 2 || op.i[23] == -6))) && cot <= 2 && rw != 4 && !(stride == 2 && rw == 2)) {
 #define L3D(S_, RW_, KG_)                                                                     \
   do {                                                                                         \
     if (cot == 2) return launch3<false, S_, RW_, 2, 3, 3, false, KG_>(a, cout_blocks, s);      \
@@ -1095,7 +1095,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
 #undef L3D
   }
   if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else L3(true, 1, 2); }
-  else     { if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
+  else     { if (stride == 2 && rw == 2) L3(false, 2, 2); else if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
 #undef L3
   return MSL_OK;
 }
