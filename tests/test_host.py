@@ -32,6 +32,22 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert hiplib.lib().msl_abi_version() == 1
 
 
+def test_no_kernel_uses_the_k16_f16_matrix_instruction():
+    """`v_mfma_f32_16x16x16_f16` runs at half rate on gfx950 and hipcc schedules VALU accesses behind it as for a 4-pass instruction: the 8-wave
+    split-precision kernels that used it were intermittently wrong.  Single K-steps go through the K = 32 form with a zero
+    second step (`msl_mfma_split`); nothing in the library's sources may bring the K = 16 f16 / bf16 forms back."""
+    import re
+    from pathlib import Path
+
+    src = Path(__file__).resolve().parents[1] / "yolo-mslesseg_amd" / "csrc"
+    bad = []
+    for f in sorted(src.glob("*.h*")):
+        code = re.sub(r"//[^\n]*", "", f.read_text())  # comments may name the instruction
+        if re.search(r"mfma_f32_16x16x16_?(f16|bf16)", code):
+            bad.append(f.name)
+    assert not bad, bad
+
+
 def test_op_struct_layout_matches_header(built_lib):
     # int32 kind, dtype; 8 pointers; 26 int32; 4 floats  → 8 + 64 + 104 + 16
     assert ctypes.sizeof(hiplib.MslOp) == 192
