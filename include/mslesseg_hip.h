@@ -106,13 +106,15 @@ enum {
   MSL_OP_DWCONV = 3,
   /* SPPF pooling: from the C-channel view at co, write the 5x5, 9x9, 13x13 stride-1 max pools
    * (= three chained 5x5 pools with -inf padding) at co+C, co+2C, co+3C of the same buffer.
-   * p: 0 buf ; i: 0 N,1 H,2 W,3 C,10 cs,11 co */
+   * p: 0 buf ; i: 0 N,1 H,2 W,3 C,10 cs,11 co, 23 = -1 selects the 4-channels-per-workgroup kernel instead of the 64-bytes-per-pixel one
+   *    (bit-identical results; A/B measurements and tests) */
   MSL_OP_SPPF_POOL = 4,
   /* Nearest 2x upsample of a view into another view.  p: 0 x, 4 y ; i: 0 N,1 H,2 W,3 C,10 x_cs,11 x_co,12 y_cs,13 y_co */
   MSL_OP_UPSAMPLE2X = 5,
   /* PSA attention core: qkv view laid out per head as [q(kd) | k(kd) | v(hd)]; out[n,i,h*hd+d] =
    * sum_j softmax_j(scale * q_i.k_j) v_j[d].   p: 0 qkv, 4 y ; i: 0 N,1 H,2 W,3 heads,4 kd,5 hd,10 x_cs,11 x_co,
-   * 12 y_cs,13 y_co ; f: 0 scale */
+   * 12 y_cs,13 y_co, 23 = -1 (fp32 tensors) selects the VALU kernel instead of the matrix-core one (v_mfma_f32_16x16x4_f32; both are fp32 fma
+   * chains, in different orders) ; f: 0 scale */
   MSL_OP_ATTENTION = 6,
   /* Head decode: DFL softmax-expectation, dist2bbox*stride, sigmoid class score, gather mask coefficients.
    * p: 0 box f32 [N,HW,64], 1 cls f32 [N,HW,nc], 2 coef f32 [N,HW,nm], 4 pred f32 [N,A,MSL_PRED_STRIDE]
