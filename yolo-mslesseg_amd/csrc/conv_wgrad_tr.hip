@@ -496,6 +496,15 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
     const double operands = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout);
     const double partials256 = 256.0 * 4.0 * (a.Cout < 64 ? a.Cout : 64) * (a.Cin < 64 ? a.Cin : 64) * k * k;
     wgs_total = operands > 8.0 * partials256 ? 256 : 128;
+    // third tier: layers whose operands are smaller than the partial matrices of 256 workgroups (the nine 20² 64 -> 64 bottleneck convs: 13 MB of operands
+    // against 147 KB of partials per workgroup — 19 MB written and read back at 128 workgroups) take 32.  Measured over the step on two boxes
+    // (MSL_WGRAD_SMALL=<workgroups>, MSL_WGRAD_SMALL_T=<threshold multiplier>; 0 = the two-tier rule): 23.33 / 23.17 → 23.20 / 23.02 ms and 22.90 / 22.80 →
+    // 22.77 ms; 64 workgroups: half of that; 16: no better than 32; a wider threshold (2x, 4x): the same.
+    static int small_env = -1;
+    if (small_env < 0) { const char* e = getenv("MSL_WGRAD_SMALL"); small_env = e ? atoi(e) : 32; }
+    static double small_t = -1.0;
+    if (small_t < 0) { const char* e = getenv("MSL_WGRAD_SMALL_T"); small_t = e ? atof(e) : 1.0; }
+    if (small_env > 0 && operands < small_t * partials256) wgs_total = small_env;
   }
   long want = wgs_total / ny;  // one 8-wave workgroup per CU (its ring of staged tiles takes the LDS): never more workgroups than CUs, a second round doubles the time
   if (want < 1) want = 1;
