@@ -424,6 +424,13 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
   __shared__ const float* s_cptr[CH];
   __shared__ int s_use[CH];
   __shared__ double s_red[4];
+  // bf16 prototypes: d(loss)/d(coef[e][k]) = sum over the tile's pixels of dpm[px][e] * proto[px][k] is a [16 anchors x 64 pixels] x [64 pixels x 32] product per
+  // wave and chunk: on v_mfma_f32_16x16x32_bf16 with dpm as hi + lo bf16 halves (the prototype values ARE bf16) — 8 MFMAs and ~50 LDS accesses per wave and
+  // chunk.  The form this replaces transpose-reduced the 32 products of every anchor over the 64 lanes with 31 cross-lane shuffles per anchor and wave:
+  // 0.27 ms of the 0.92 ms loss phase at batch 128.  fp32 prototypes keep that form.
+  __shared__ __attribute__((aligned(16))) unsigned short s_pt[F32 ? 1 : 4][F32 ? 1 : 64][F32 ? 2 : 32];  // this wave's prototype values [pixel][channel], bf16 bits
+  __shared__ __attribute__((aligned(16))) unsigned short s_dh[F32 ? 1 : 4][F32 ? 1 : 64][CH], s_dl[F32 ? 1 : 4][F32 ? 1 : 64][CH];  // dpm [pixel][anchor of the chunk], hi / lo
+  const int wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int tiles_x = (s.mw + 15) / 16;
   const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
@@ -438,6 +445,23 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
     if (live) ld4<F32>(s.proto, pix * s.p_cs + s.p_co + k, v);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pr[k + r] = v[r]; gp[k + r] = 0.f; }
+  }
+  bf16x8 bp[2][2];  // B operands of the coefficient-gradient product: [K-step of 32 pixels][channel tile]: lane (li = channel, g) holds pixels 8g .. 8g+7 of the step
+  if constexpr (!F32) {
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) *(unsigned*)&s_pt[wave][lane][k] = (__float_as_uint(pr[k]) >> 16) | (__float_as_uint(pr[k + 1]) & 0xffff0000u);  // exact: pr came from bf16
+    __builtin_amdgcn_wave_barrier();  // (LDS executes a wave's accesses in order; this only pins the compiler)
+    const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        unsigned pk[4];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+          pk[j >> 1] = (unsigned)s_pt[wave][32 * st + 8 * g + j][16 * t + li] | ((unsigned)s_pt[wave][32 * st + 8 * g + j + 1][16 * t + li] << 16);
+        bp[st][t] = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      }
   }
   const int mv = live ? (int)s.masks[pix] : -1;
   const float fx = (float)x, fy = (float)y;
@@ -477,6 +501,15 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
       if (s_use[e]) { s_cf[e][k] = s_cptr[e][k]; s_gc[e][k] = 0.f; }
     }
     __syncthreads();
+    bool wave_any = false;  // (wave-uniform) some anchor of the chunk has pixels of this wave in its box
+    if constexpr (!F32) {
+      if (!s.no_grad) {
+        uint4* zh = (uint4*)&s_dh[wave][lane][0];
+        uint4* zl = (uint4*)&s_dl[wave][lane][0];
+        zh[0] = make_uint4(0, 0, 0, 0); zh[1] = make_uint4(0, 0, 0, 0);
+        zl[0] = make_uint4(0, 0, 0, 0); zl[1] = make_uint4(0, 0, 0, 0);
+      }
+    }
     for (int e = 0; e < nc_; ++e) {
       if (!s_use[e]) continue;  // tile vs crop box (block-uniform)
       const float x1 = s_box[e][0], y1 = s_box[e][1], x2 = s_box[e][2], y2 = s_box[e][3];
@@ -495,6 +528,14 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
       if (s.no_grad) continue;
 #pragma unroll
       for (int k = 0; k < 32; ++k) gp[k] = fmaf(dpm, s_cf[e][k], gp[k]);
+      if constexpr (!F32) {  // bf16 prototypes: the coefficient gradients of the whole chunk go through the matrix cores after this loop
+        if (lane == 0) s_hit[e] = 1;
+        const unsigned hb = f32_to_bf16_bits(dpm);
+        s_dh[wave][lane][e] = (unsigned short)hb;
+        s_dl[wave][lane][e] = (unsigned short)f32_to_bf16_bits(dpm - bf16_bits_to_f32(hb));
+        wave_any = true;
+        continue;
+      }
       // d(loss)/d(coef[k]) = sum over pixels of dpm * proto[k]: transpose-reduce the 32 values over the 64 lanes
       // (31 + 1 shuffles; the products are formed inside the first exchange so only 16 live values remain)
       float v[16];
@@ -523,6 +564,33 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
         const int k = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
         atomicAdd(&s_gc[e][k], tot);
         if (lane == 0) s_hit[e] = 1;
+      }
+    }
+    if constexpr (!F32) {
+      if (wave_any) {  // wave-uniform: D[anchor][channel] = sum over this wave's 64 pixels; lane (li = channel, g) ends with anchors 4g .. 4g+3
+        __builtin_amdgcn_wave_barrier();
+        const int li = lane & 15, g = lane >> 4;
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          unsigned ph[4], pl[4];
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            ph[j >> 1] = (unsigned)s_dh[wave][32 * st + 8 * g + j][li] | ((unsigned)s_dh[wave][32 * st + 8 * g + j + 1][li] << 16);
+            pl[j >> 1] = (unsigned)s_dl[wave][32 * st + 8 * g + j][li] | ((unsigned)s_dl[wave][32 * st + 8 * g + j + 1][li] << 16);
+          }
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3])), al = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[st][t], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[st][t], acc[t], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g + r < nc_ && s_use[4 * g + r] && acc[t][r] != 0.f) atomicAdd(&s_gc[4 * g + r][16 * t + li], acc[t][r]);
       }
     }
     __syncthreads();
