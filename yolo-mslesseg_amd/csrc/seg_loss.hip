@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void sl_main_kernel(SlArgs s) {
 // Block = one 16x16 tile of prototype pixels of one slice; thread = pixel (32 prototype values in registers).
 template <bool F32>
 __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two tiles per CU (no spills at <= 256 VGPRs)
-  constexpr int CH = 16;  // foreground anchors staged per pass
+  constexpr int CH = 16;  // foreground anchors staged per pass (32 — two anchor tiles of the matrix-core reduction — measured no faster: 0.67 vs 0.63 ms loss phase)
   __shared__ float s_cf[CH][32];
   __shared__ float s_box[CH][4];
   __shared__ float s_w[CH];
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
       if (!s.no_grad) {
         uint4* zh = (uint4*)&s_dh[wave][lane][0];
         uint4* zl = (uint4*)&s_dl[wave][lane][0];
-        zh[0] = make_uint4(0, 0, 0, 0); zh[1] = make_uint4(0, 0, 0, 0);
-        zl[0] = make_uint4(0, 0, 0, 0); zl[1] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < CH / 8; ++q) { zh[q] = make_uint4(0, 0, 0, 0); zl[q] = make_uint4(0, 0, 0, 0); }
       }
     }
     for (int e = 0; e < nc_; ++e) {
@@ -570,27 +570,33 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
       if (wave_any) {  // wave-uniform: D[anchor][channel] = sum over this wave's 64 pixels; lane (li = channel, g) ends with anchors 4g .. 4g+3
         __builtin_amdgcn_wave_barrier();
         const int li = lane & 15, g = lane >> 4;
-        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          unsigned ph[4], pl[4];
+        for (int at = 0; at < CH / 16; ++at) {  // 16-anchor tiles of the chunk
+          if (16 * at >= nc_) break;
+          f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            ph[j >> 1] = (unsigned)s_dh[wave][32 * st + 8 * g + j][li] | ((unsigned)s_dh[wave][32 * st + 8 * g + j + 1][li] << 16);
-            pl[j >> 1] = (unsigned)s_dl[wave][32 * st + 8 * g + j][li] | ((unsigned)s_dl[wave][32 * st + 8 * g + j + 1][li] << 16);
+          for (int st = 0; st < 2; ++st) {
+            unsigned ph[4], pl[4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              ph[j >> 1] = (unsigned)s_dh[wave][32 * st + 8 * g + j][16 * at + li] | ((unsigned)s_dh[wave][32 * st + 8 * g + j + 1][16 * at + li] << 16);
+              pl[j >> 1] = (unsigned)s_dl[wave][32 * st + 8 * g + j][16 * at + li] | ((unsigned)s_dl[wave][32 * st + 8 * g + j + 1][16 * at + li] << 16);
+            }
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3])), al = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[st][t], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[st][t], acc[t], 0, 0, 0);
+            }
           }
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3])), al = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[st][t], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[st][t], acc[t], 0, 0, 0);
-          }
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = 16 * at + 4 * g + r;
+              if (e < nc_ && s_use[e] && acc[t][r] != 0.f) atomicAdd(&s_gc[e][16 * t + li], acc[t][r]);
+            }
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * g + r < nc_ && s_use[4 * g + r] && acc[t][r] != 0.f) atomicAdd(&s_gc[4 * g + r][16 * t + li], acc[t][r]);
       }
     }
     __syncthreads();
