@@ -414,15 +414,18 @@ __global__ __launch_bounds__(256) void sl_main_kernel(SlArgs s) {
 template <bool F32>
 __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two tiles per CU (no spills at <= 256 VGPRs)
   constexpr int CH = 16;  // foreground anchors staged per pass (32 — two anchor tiles of the matrix-core reduction — measured no faster: 0.67 vs 0.63 ms loss phase)
+  constexpr int SC = 64;  // foreground anchors whose boxes / weights / pointers are staged per pass: ONE chain of dependent loads (list entry → level table → ground
+                          // truth) and one block-wide vote per 64 anchors — staged 16 at a time, every tile paid that chain for every 16 anchors of its slice whether
+                          // or not any of them touched it (~0.1 ms of the batch-128 loss phase)
   __shared__ float s_cf[CH][32];
-  __shared__ float s_box[CH][4];
-  __shared__ float s_w[CH];
-  __shared__ int s_j[CH];
+  __shared__ float s_box[SC][4];
+  __shared__ float s_w[SC];
+  __shared__ int s_j[SC];
   __shared__ float s_gc[CH][32];
   __shared__ int s_hit[CH];
-  __shared__ float* s_gptr[CH];
-  __shared__ const float* s_cptr[CH];
-  __shared__ int s_use[CH];
+  __shared__ float* s_gptr[SC];
+  __shared__ const float* s_cptr[SC];
+  __shared__ int s_use[SC];
   __shared__ double s_red[4];
   // bf16 prototypes: d(loss)/d(coef[e][k]) = sum over the tile's pixels of dpm[px][e] * proto[px][k] is a [16 anchors x 64 pixels] x [64 pixels x 32] product per
   // wave and chunk: on v_mfma_f32_16x16x32_bf16 with dpm as hi + lo bf16 halves (the prototype values ARE bf16) — 8 MFMAs and ~50 LDS accesses per wave and
@@ -471,13 +474,13 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
   const float S = SL_GAIN_BOX * (float)s.B / fgsum;
   const float inv_px = 1.0f / ((float)s.mh * (float)s.mw);
   double lseg = 0.0;
-  for (int c0 = 0; c0 < nf; c0 += CH) {
-    const int nc_ = min(CH, nf - c0);
+  for (int c0 = 0; c0 < nf; c0 += SC) {
+    const int ns = min(SC, nf - c0);
     __syncthreads();
     // ---- stage the chunk: crop box (prototype pixels), weight 1 / (mh*mw*area) and pointers first; the coefficient rows are
     // gathered only for anchors whose crop box meets this tile, and tiles that meet none skip the chunk altogether
     int hit = 0;
-    if (threadIdx.x < nc_) {
+    if (threadIdx.x < ns) {
       const int e = threadIdx.x;
       const int2 ent = s.flist[(long)b * cap + c0 + e];
       const SlLoc lc = sl_locate(s.tab, s.nlev, ent.x);
@@ -489,17 +492,23 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
       s_box[e][0] = x1; s_box[e][1] = y1; s_box[e][2] = x2; s_box[e][3] = y2;
       s_w[e] = inv_px / fmaxf((n2 - n0) * (n3 - n1), 1e-12f);
       s_j[e] = ent.y;
-      s_hit[e] = 0;
       s_gptr[e] = (float*)tb[5] + ap * tb[12] + tb[13];
       s_cptr[e] = (const float*)tb[2] + ap * tb[12] + tb[13];
       hit = (float)(tx0 + 15) >= x1 && (float)tx0 < x2 && (float)(ty0 + 15) >= y1 && (float)ty0 < y2;
       s_use[e] = hit;
     }
     if (!__syncthreads_or(hit)) continue;  // block-uniform
+    for (int sc = 0; sc < ns; sc += CH) {  // 16 anchors at a time through the coefficient / gradient rows
+    const int nc_ = min(CH, ns - sc);
+    int any = 0;
+    for (int i = 0; i < nc_; ++i) any |= s_use[sc + i];  // block-uniform (broadcast reads)
+    if (!any) continue;
+    __syncthreads();  // the previous group's rows are no longer read
     for (int i = threadIdx.x; i < nc_ * 32; i += 256) {
       const int e = i >> 5, k = i & 31;
-      if (s_use[e]) { s_cf[e][k] = s_cptr[e][k]; s_gc[e][k] = 0.f; }
+      if (s_use[sc + e]) { s_cf[e][k] = s_cptr[sc + e][k]; s_gc[e][k] = 0.f; }
     }
+    if (threadIdx.x < nc_) s_hit[threadIdx.x] = 0;
     __syncthreads();
     bool wave_any = false;  // (wave-uniform) some anchor of the chunk has pixels of this wave in its box
     if constexpr (!F32) {
@@ -511,8 +520,8 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
       }
     }
     for (int e = 0; e < nc_; ++e) {
-      if (!s_use[e]) continue;  // tile vs crop box (block-uniform)
-      const float x1 = s_box[e][0], y1 = s_box[e][1], x2 = s_box[e][2], y2 = s_box[e][3];
+      if (!s_use[sc + e]) continue;  // tile vs crop box (block-uniform)
+      const float x1 = s_box[sc + e][0], y1 = s_box[sc + e][1], x2 = s_box[sc + e][2], y2 = s_box[sc + e][3];
       const bool in = live && fx >= x1 && fx < x2 && fy >= y1 && fy < y2;
       if (__ballot(in) == 0ull) continue;  // wave-uniform
       float dpm = 0.f;
@@ -520,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
         float pm = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) pm = fmaf(s_cf[e][k], pr[k], pm);
-        const float gtv = mv == s_j[e] + 1 ? 1.0f : 0.f;
-        const float w = s_w[e];
+        const float gtv = mv == s_j[sc + e] + 1 ? 1.0f : 0.f;
+        const float w = s_w[sc + e];
         lseg += (double)((fmaxf(pm, 0.f) - pm * gtv + log1pf(expf(-fabsf(pm)))) * w);
         dpm = (sl_sigmoid(pm) - gtv) * w * S;
       }
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int e = 16 * at + 4 * g + r;
-              if (e < nc_ && s_use[e] && acc[t][r] != 0.f) atomicAdd(&s_gc[e][16 * t + li], acc[t][r]);
+              if (e < nc_ && s_use[sc + e] && acc[t][r] != 0.f) atomicAdd(&s_gc[e][16 * t + li], acc[t][r]);
             }
         }
       }
@@ -603,8 +612,9 @@ __global__ __launch_bounds__(256, 2) void sl_mask_kernel(SlArgs s) {  // two til
     if (!s.no_grad)
       for (int i = threadIdx.x; i < nc_ * 32; i += 256) {
         const int e = i >> 5, k = i & 31;
-        if (s_hit[e]) atomicAdd(s_gptr[e] + k, s_gc[e][k]);
+        if (s_hit[e]) atomicAdd(s_gptr[sc + e] + k, s_gc[e][k]);
       }
+    }
   }
   if (live && !s.no_grad) {
 #pragma unroll
