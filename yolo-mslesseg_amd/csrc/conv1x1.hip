@@ -32,8 +32,9 @@ struct C1Args {
   long M;
   int Cin, Cout, Kpad, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, slots, w_rows;
   float oscale;       // MSL_F32S: accumulators x this before bias / activation (inverse of the host's power-of-two weight scale)
-  const float* bn_tab;  // measurement form (round 3, verdict #3b): per INPUT channel (scale, shift) = (gamma * invstd, beta - mean * gamma * invstd) — the wave applies
-  int bn_act;           // x <- act(x * scale + shift) to the slice it staged, in LDS, before multiplying: the producer's BN_ACT pass (z -> a) folded into this consumer
+  const float* bn_tab;  // input BatchNorm table of the x BUFFER (msl_common.h: f32 [x_cs][2] (scale, shift), then u8 [x_cs / 8] group flags) or NULL: the wave applies
+                        // x <- act(x * scale + shift) to the flagged 8-channel groups of the slice it staged, in LDS, before multiplying — the producer's BN_ACT pass
+                        // (z -> a) folded into this consumer
   int shuffle, H, W;  // shuffle = 1: pixel-shuffle store of a ConvTranspose2d k2 s2 run as a 1x1 GEMM — channel q*C + c (C = Cout/4, q = dy*2 + dx) of
                       // pixel (y, x) goes to channel c of pixel (2y + dy, 2x + dx) of the 2H x 2W output (same contract as conv_igemm's store mode 1)
 };
@@ -61,9 +62,13 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
   float* s_bias = (float*)(smem + w_bytes + NW * 2 * slice_bytes);    // [NCP * 32]: read per slice with ds_read — a global load in the loop makes hipcc
                                                                       // wait vmcnt(0), i.e. for the next slice's DMA and the previous stores, before every store group
   for (int i = threadIdx.x; i < NCP * 32; i += blockDim.x) s_bias[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;
-  float* s_bn = s_bias + NCP * 32;  // [2 * Kpad] (scale, shift) per input channel; pad channels (0, 0)
-  if (a.bn_tab)
-    for (int i = threadIdx.x; i < 2 * a.Kpad; i += blockDim.x) s_bn[i] = i < 2 * a.Cin ? a.bn_tab[i] : 0.f;
+  float* s_bn = s_bias + NCP * 32;  // [2 * Kpad] (scale, shift) per input channel of the view, then [Kpad / 8] group flags (as floats' bytes: 1 byte each)
+  unsigned char* s_fl = (unsigned char*)(s_bn + 2 * a.Kpad);
+  if (a.bn_tab) {
+    const MslBnTab bt = msl_bn_tab(a.bn_tab, a.x_cs);
+    for (int i = threadIdx.x; i < 2 * a.Kpad; i += blockDim.x) s_bn[i] = i < 2 * a.Cin ? bt.tab[2 * a.x_co + i] : 0.f;
+    for (int i = threadIdx.x; i < a.Kpad / 8; i += blockDim.x) s_fl[i] = i < a.Cin / 8 ? bt.flags[a.x_co / 8 + i] : 0;
+  }
 
   // ---- weights → LDS (rows >= w_rows and the pad chunk read the zero page)
   {
@@ -149,18 +154,11 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
         for (int k = 0; k < npieces; ++k) {
           const int cidx = k * 64 + lane, px = cidx / cps, ch = cidx - px * cps;
           if (cidx >= slice_chunks || ch >= xchunks) continue;
-          uint4* q = (uint4*)(s_x + buf * slice_bytes + k * 1024 + lane * 16);
-          const uint4 t = *q;
-          const unsigned w[4] = {t.x, t.y, t.z, t.w};
-          unsigned o[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 st4 = *(const float4*)(s_bn + 2 * (ch * 8 + 2 * j));  // (scale, shift) of two consecutive channels
-            float u0 = fmaf(__uint_as_float(w[j] << 16), st4.x, st4.y), u1 = fmaf(__uint_as_float(w[j] & 0xffff0000u), st4.z, st4.w);
-            if (a.bn_act) { u0 = silu_f(u0); u1 = silu_f(u1); }
-            o[j] = f32_to_bf16_bits(u0) | (f32_to_bf16_bits(u1) << 16);
-          }
-          *q = make_uint4(o[0], o[1], o[2], o[3]);
+          const unsigned fl = s_fl[ch];
+          if (!(fl & 1)) continue;  // an ordinary activation group of a concat: left alone
+          float sc[8], sh[8];
+          msl_bn_ld8(s_bn, ch * 8, sc, sh);
+          msl_bn_lds16(s_x + buf * slice_bytes + k * 1024 + lane * 16, sc, sh, (fl & 2) != 0);
         }
       }
     }
@@ -354,6 +352,8 @@ struct G1Args {
   long M;
   int Cin, Cout, Kpad, w_rows, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, out_f32, ntn, slots;
   float oscale;  // MSL_F32S: inverse of the host's power-of-two weight scale
+  const float* bn_tab;  // input BatchNorm table of the x buffer (bf16 form; msl_common.h) or NULL: every wave rewrites the flagged 8-channel groups of the pixel pieces
+                        // it staged as act(x * scale + shift) before the chunk's barrier (the staging lane converts its own 16 bytes, like the split mode)
 };
 
 // MODE 0: bf16 tensors.  MODE 1: fp32 tensors on v_mfma_f32_16x16x4_f32 (the parity engine).  MODE 2: fp32 tensors, split-precision products (MSL_F32S:
@@ -383,6 +383,14 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   const long p0 = tm * BM;
   const int n0 = tn * BN;
   for (int i = threadIdx.x; i < BN; i += 256) s_bias[i] = (a.bias && n0 + i < a.Cout) ? a.bias[n0 + i] : 0.f;
+  float* s_bn = s_bias + BN;  // [2 * Kpad] (scale, shift) per input channel of the view, then one flag byte per 8-channel group
+  unsigned char* s_fl = (unsigned char*)(s_bn + 2 * a.Kpad);
+  if (MODE == 0 && a.bn_tab) {
+    const MslBnTab bt = msl_bn_tab(a.bn_tab, a.x_cs);
+    for (int i = threadIdx.x; i < 2 * a.Kpad; i += 256) s_bn[i] = i < 2 * a.Cin ? bt.tab[2 * a.x_co + i] : 0.f;
+    for (int i = threadIdx.x; i < a.Kpad / 8; i += 256) s_fl[i] = i < a.Cin / 8 ? bt.flags[a.x_co / 8 + i] : 0;
+    __syncthreads();  // the first chunk's pieces are converted before the loop's first barrier
+  }
 
   // residual of this lane's 8 store groups (bf16 views), requested first
   uint4 rpre[NPT][2];
@@ -451,6 +459,24 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
       for (int k = 0; k < KP; ++k) {
         const int pc = wave + 4 * k;
         if (pc < PIECES) msl_split_lds16(cx + pc * 1024 + lane * 16);
+      }
+    }
+    if constexpr (MODE == 0) {
+      if (a.bn_tab) {  // block-uniform
+        unsigned char* cx = smem + (kc & 1) * STAGE + TILE;
+        const int xleft = a.Cin - kc * BK;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const int pc = wave + 4 * k;
+          if (pc >= PIECES) break;
+          if (xo[k] == OOB || (int)chn[k] >= xleft) continue;  // rows beyond M, the pad chunk, channels beyond Cin: zeros stay zeros
+          const int grp = (kc * BK + (int)chn[k]) >> 3;
+          const unsigned fl = s_fl[grp];
+          if (!(fl & 1)) continue;
+          float sc[8], sh[8];
+          msl_bn_ld8(s_bn, grp * 8, sc, sh);
+          msl_bn_lds16(cx + pc * 1024 + lane * 16, sc, sh, (fl & 2) != 0);
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone's have, and everyone is done reading the buffer refilled next
@@ -619,13 +645,15 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   a.w_rows = op.i[21] > 0 ? op.i[21] : (a.Cout + 15) / 16 * 16;
   a.acc = (double*)op.p[5]; a.slots = op.i[23] > 0 ? op.i[23] : 1;
   a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
+  a.bn_tab = (const float*)op.p[8];
+  MSL_REQUIRE(!a.bn_tab || (op.dtype == MSL_BF16 && a.Kpad <= 2048 && a.x_co % 8 == 0 && a.x_cs % 8 == 0), "gemm1x1: the input BatchNorm table (p[8]) is a bf16 form (K <= 2048)");
   MSL_REQUIRE(a.x && a.w && a.y && msl_gemm1x1_eligible(op), "gemm1x1: bad args");
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs && (!a.res || a.res_co + a.Cout <= a.res_cs), "gemm1x1: bad dims / views");
   const bool f32 = op.dtype != MSL_BF16, narrow = f32 && a.Cout <= 64;
   a.ntn = narrow ? 1 : (a.Cout + 127) / 128;
   const long tiles = (a.M + 127) / 128 * a.ntn;
   MSL_REQUIRE(tiles < (1L << 31), "gemm1x1: too many tiles");
-  constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4;  // (the 64-channel forms use 2 x 27 KiB of it)
+  constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4 + 2048 * 8 + 256;  // (the 64-channel forms use 2 x 27 KiB of it) + the input BatchNorm table (K <= 2048) and its group flags
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -672,7 +700,7 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   constexpr int ES = F32 ? 4 : 2;
   // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
   const int nw = (c1_lds(NCP, a.Kpad, PT, 4, ES) * 3 > 160 * 1024 && c1_lds(NCP, a.Kpad, PT, 8, ES) <= C1_LDS_MAX) ? 8 : 4;
-  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES) + (a.bn_tab ? (size_t)a.Kpad * 8 : 0);  // + the input BatchNorm table behind the bias
+  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES) + (a.bn_tab ? (size_t)a.Kpad * 8 + (size_t)((a.Kpad / 8 + 15) & ~15) : 0);  // + the input BatchNorm table and group flags behind the bias
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -716,9 +744,8 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(!a.acc || (a.slots <= 16 && !a.out_f32), "conv1x1: the statistics epilogue needs bf16 output and at most 16 slots");
   const int ncp = (a.Cout + 31) / 32;
   a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
-  MSL_REQUIRE(!op.p[6] || op.dtype == MSL_BF16, "conv1x1: the input BatchNorm table (p[6]) is a bf16 form");
-  a.bn_tab = (const float*)op.p[6];  // p 6 (bf16, optional): (scale, shift) per input channel f32 [Cin][2]; f 1 != 0: SiLU after it
-  a.bn_act = op.f[1] != 0.f;
+  MSL_REQUIRE(!op.p[8] || (op.dtype == MSL_BF16 && a.x_co % 8 == 0 && a.Cin % 8 == 0 && a.x_cs % 8 == 0), "conv1x1: the input BatchNorm table (p[8]) is a bf16 form over whole 8-channel groups");
+  a.bn_tab = (const float*)op.p[8];  // p 8 (bf16, optional): input BatchNorm table of the x buffer (msl_common.h)
   if (op.dtype == MSL_F32S) {
     MSL_REQUIRE(op.f[0] > 0.f && !a.acc, "conv1x1 (MSL_F32S): f[0] must hold the output scale of the pre-split weights; no statistics epilogue");
 #define C1S(N) case N: return c1_launch_f32<N, true>(a, s)

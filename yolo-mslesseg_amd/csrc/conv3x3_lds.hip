@@ -41,6 +41,8 @@ struct Conv3Args {
   int lat, full_h, full_w;  // lat >= 0: output pixel (Y,X) is stored at (2Y + (lat&1), 2X + (lat>>1)) of a full_h x full_w image (parity class of a stride-2 input gradient)
   double* acc;  // optional BatchNorm accumulator f64[slots][2*Cout]: per-channel (sum, sum of squares) of the stored outputs
   int slots;
+  const float* bn_tab;  // input BatchNorm table of the x buffer (bf16; msl_common.h) or NULL: the lane that staged a 16-byte unit of the halo rewrites it as
+                        // act(x * scale + shift) before the tile is published — units that came from the zero page (padding) stay zero
 };
 
 template <int S, int RW, int KH = 3>
@@ -170,12 +172,13 @@ __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co
   store_pixel_b<F32, COT>(a, pix, co0, accp, s1, s2, bias);
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4>  // KG: k-groups per halo slot (halo_byte_kg); SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4, bool BNT = false>  // BNT: input BatchNorm table (its own instantiation: ~20 registers); KG: k-groups per halo slot (halo_byte_kg); SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
 // image arrives pre-split from the host; every lane rewrites the 16 bytes of the halo tile it staged itself as (hi x 4 | lo x 4) once per chunk,
 // so the nine taps read ready-made f16 operands and the MFMA loop carries no conversion
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");
   static_assert(KG == 4 || (!F32 && (KG == 1 || KG == 2)), "dense halo slots: bf16 layers of 8 or 16 input channels");
+  static_assert(!BNT || (!F32 && KH == 3 && KW == 3), "input BatchNorm table: the plain bf16 3x3 forward conv");
   using T = Tile3<S, RW, KH>;
   constexpr int NT = KH * KW;            // taps: 3x3 (pad 1), or the 1x1 / 1x2 / 2x1 / 2x2 kernels (pad 0) of the stride-2 input gradient's parity classes
   constexpr int PAD = KH == 3 ? 1 : 0;
@@ -244,9 +247,22 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     }
   }
   const char* wlane = wblk + wave * 1024 + lane * 16;
+  // input BatchNorm table: this lane always stages k-group gq_l of a chunk, i.e. buffer channels x_co + cc * CHUNK + 8 * gq_l .. + 7
+  const int gq_l = (((lane & 15) & (KG - 1)) - (lane >> 4)) & (KG - 1);
+  const MslBnTab bt = msl_bn_tab(BNT ? a.bn_tab : nullptr, a.x_cs);
 
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();  // previous chunk's fragment reads are done before the tile is overwritten
+    float bsc[8], bsh[8];
+    unsigned bfl = 0;
+    if constexpr (BNT) {
+      if (bt.tab) {  // block-uniform; requested with the chunk's DMA, consumed after the wait below
+        const int c0 = a.x_co + cc * CHUNK + 8 * gq_l;
+        const bool in = cc * CHUNK + 8 * gq_l < a.Cin;
+        bfl = in ? bt.flags[c0 >> 3] : 0u;
+        msl_bn_ld8(bt.tab, in ? c0 : a.x_co, bsc, bsh);
+      }
+    }
     // ---- input halo: 16 pixels x 4 k-groups (1 KiB) per LDS-DMA piece, pieces dealt round-robin to the 4 waves
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
@@ -267,6 +283,15 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       for (int j = 0; j < IN_PER_WAVE; ++j) {
         const int pc = wave + 4 * j;
         if (pc < IN_PIECES) msl_split_lds16(s_in + pc * 1024 + lane * 16);
+      }
+    }
+    if constexpr (BNT) {
+      if (bfl & 1) {
+#pragma unroll
+        for (int j = 0; j < IN_PER_WAVE; ++j) {
+          const int pc = wave + 4 * j;
+          if (pc < IN_PIECES && in_off[j] >= 0) msl_bn_lds16(s_in + pc * 1024 + lane * 16, bsc, bsh, (bfl & 2) != 0);
+        }
       }
     }
     __syncthreads();
@@ -392,19 +417,19 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4, bool BNT = false>
 static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
   using T = Tile3<S, RW, KH>;
   constexpr int LDS = (T::SLOTS + 64 / KG - 1) / (64 / KG) * 1024 + KH * KW * 4 * COT * 16 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   Conv3Args b = a;
   b.cout_blocks = cout_blocks;
   dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * cout_blocks));
-  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG>), grid, dim3(256), LDS, s, b);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG, BNT>), grid, dim3(256), LDS, s, b);
   MSL_CHECK_LAUNCH("conv3x3_lds");
   return MSL_OK;
 }
@@ -946,6 +971,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   a.act = op.i[18]; a.out_f32 = op.i[19];
   a.lat = -1; a.full_h = a.full_w = 0;
   a.w2 = (const char*)op.p[6]; a.bias2 = (const float*)op.p[7];
+  a.bn_tab = (const float*)op.p[8];  // p 8 (bf16 forward forms, optional): input BatchNorm table of the x buffer (msl_common.h)
+  if (a.bn_tab) MSL_REQUIRE(op.dtype == MSL_BF16 && op.i[20] == 0 && !a.w2 && a.x_co % 8 == 0 && a.x_cs % 8 == 0, "conv3x3_lds: the input BatchNorm table (p[8]) is a form of the plain bf16 3x3 conv");
   if (op.i[20] == 3) {  // all four parity classes of a 3x3 / stride-2 / pad-1 input gradient in one pass (conv_s2dgrad_lds_kernel)
     a.acc = nullptr; a.slots = 1;
     MSL_REQUIRE(op.dtype == MSL_BF16 && !op.p[5] && !op.p[6] && !a.out_f32 && a.act == 0, "conv s2 dgrad (LDS): bf16, no statistics / tail / activation / fp32 output");
@@ -1037,7 +1064,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     // fp32 tensors with four chunks (64 input channels): 32-channel output blocks fit (the host packs such layers with COT = 2 for the fp32 engines)
     // (split-precision layers take this kernel for four chunks only — the one shape it was measured on; the others keep the tile kernel unless i[23] = -9 asks)
     const bool pays4 = f32 && nch == 4 && cot == 2 && a.Cin % chunk == 0 && tiles >= 1024;
-    if (stride == 1 && rw == 2 && (nch <= 2 || (f32 && nch == 4)) && fits && ((pays && !split) || pays4 || op.i[23] == -9) && op.i[23] != -8) {
+    // (an input BatchNorm table keeps the tile kernel: the persistent 64 -> 64 form has neither the registers — 254 of 256 — nor a byte of LDS left for it)
+    if (stride == 1 && rw == 2 && (nch <= 2 || (f32 && nch == 4)) && fits && ((pays && !split) || pays4 || op.i[23] == -9) && op.i[23] != -8 && !a.bn_tab) {
 #define L3P(F, NCH_, SP)                                                             \
   do {                                                                               \
     if (cot == 4) return launch3p<F, 4, NCH_, false, 2, SP>(a, cout_blocks, s);      \
@@ -1085,15 +1113,30 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   // two k-groups at stride 1 are SLOWER than the full-width image (160² 16->8 0.081 -> 0.091, 16->16 0.083 -> 0.093): taken only when i[23] = -6 asks
   const int kg = (!f32 && a.Cin < chunk && a.Cin % 8 == 0 && op.i[23] != -7) ? a.Cin / 8 : 4;
   if ((kg == 1 || (kg == 2 && (stride == 2 || op.i[23] == -6))) && cot <= 2 && rw != 4 && !(stride == 2 && rw == 2)) {
-#define L3D(S_, RW_, KG_)                                                                     \
-  do {                                                                                         \
-    if (cot == 2) return launch3<false, S_, RW_, 2, 3, 3, false, KG_>(a, cout_blocks, s);      \
-    return launch3<false, S_, RW_, 1, 3, 3, false, KG_>(a, cout_blocks, s);                    \
+#define L3D(S_, RW_, KG_)                                                                                   \
+  do {                                                                                                       \
+    if (a.bn_tab) {                                                                                          \
+      if (cot == 2) return launch3<false, S_, RW_, 2, 3, 3, false, KG_, true>(a, cout_blocks, s);            \
+      return launch3<false, S_, RW_, 1, 3, 3, false, KG_, true>(a, cout_blocks, s);                          \
+    }                                                                                                        \
+    if (cot == 2) return launch3<false, S_, RW_, 2, 3, 3, false, KG_>(a, cout_blocks, s);                    \
+    return launch3<false, S_, RW_, 1, 3, 3, false, KG_>(a, cout_blocks, s);                                  \
   } while (0)
     if (stride == 2) { if (kg == 2) L3D(2, 1, 2); else L3D(2, 1, 1); }
     else { if (kg == 2) L3D(1, 2, 2); else L3D(1, 2, 1); }
 #undef L3D
   }
+#define L3B(S_, RW_)                                                                          \
+  do {                                                                                         \
+    if (cot == 4) return launch3<false, S_, RW_, 4, 3, 3, false, 4, true>(a, cout_blocks, s);  \
+    if (cot == 2) return launch3<false, S_, RW_, 2, 3, 3, false, 4, true>(a, cout_blocks, s);  \
+    return launch3<false, S_, RW_, 1, 3, 3, false, 4, true>(a, cout_blocks, s);                \
+  } while (0)
+  if (a.bn_tab) {  // bf16 (checked above), the two tile shapes the training program uses
+    MSL_REQUIRE(rw != 4 && !(stride == 2 && rw == 2), "conv3x3_lds: the input BatchNorm table exists for the 8x32 (stride 1) and 4x32 (stride 2) tiles");
+    if (stride == 2) L3B(2, 1); else L3B(1, 2);
+  }
+#undef L3B
   if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else L3(true, 1, 2); }
   else     { if (stride == 2 && rw == 2) L3(false, 2, 2); else if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
 #undef L3

@@ -284,8 +284,8 @@ int msl_launch_conv(const msl_op& op, hipStream_t s) {
       return MSL_OK;
     }
   }
-  MSL_REQUIRE(!(op.i[7] == 1 && op.p[6]), "conv: the input BatchNorm table (p[6] of a 1x1 op) exists only in the bf16 1x1 streaming kernel and this op is not eligible for it");
-  if (msl_gemm1x1_eligible(op)) return msl_launch_gemm1x1(op, s);  // wide 1x1 whose weights do not fit the streaming kernel's LDS: tiled GEMM (conv1x1.hip)
+  if (msl_gemm1x1_eligible(op)) return msl_launch_gemm1x1(op, s);
+  MSL_REQUIRE(!op.p[8], "conv: the input BatchNorm table (p[8]) exists in the bf16 1x1 streaming / tiled kernels and the LDS-tiled 3x3 kernels; this op is not eligible for them");  // wide 1x1 whose weights do not fit the streaming kernel's LDS: tiled GEMM (conv1x1.hip)
   MSL_REQUIRE(!op.p[5], "conv: the BatchNorm-statistics epilogue (p[5]) exists only in the 1x1 streaming kernel and this op is not eligible for it");
   ConvArgs a;
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2];

@@ -31,6 +31,9 @@ struct WgTrArgs {
   int tiles_x, tiles_y, tiles_per_block;
   long total_tiles, M;
   float* scratch;  // [gridDim.x][Cout][K] per-workgroup partial sums (NULL: flush with atomics)
+  const float* bn_tab;  // input BatchNorm table of the x buffer (msl_common.h) or NULL: x holds the producer's raw conv output z and the activated tensor this
+                        // weight gradient contracts with is act(z * scale + shift) — every wave rewrites the x pieces it staged once they have landed, before the
+                        // barrier that publishes the tile (units staged as zeros — padding, image edges, missing channels — stay zero)
 #ifdef WG_STAMPS
   unsigned long long* dbg;  // diagnostic build (scripts/dev_wgrad_stamps.hip): [workgroup][wave][8] cycle sums per loop phase
 #endif
@@ -155,28 +158,42 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
   // tile → (image, origin): tiles of an image are walked column-major — vertical neighbours share 2 of the 6 (4-row tile) halo rows of x and are
   // staged back to back, so the shared rows are still in L2 (row-major order revisits them tiles_x tiles later — 200 KB per workgroup, x 32
   // workgroups per XCD, more than its 4 MB L2).  1x1: the pixels are a flat list, a "row" is just 32 consecutive ones.
-  auto stage = [&](int tile, unsigned char* buf) __attribute__((always_inline)) {
-    unsigned char* s_z = buf;
-    unsigned char* s_x = buf + C::Z_PIECES * 1024;
-    long zpix, xpix;
-    int zr_lim, zc_lim, y_lo = 0, x_lo = 0;
-    bool z_in, x_in;
+  struct Geom { long zpix, xpix; int zr_lim, zc_lim, y_lo, x_lo; bool z_in, x_in; };
+  auto geom = [&](int tile) __attribute__((always_inline)) -> Geom {
+    Geom gm;
+    gm.y_lo = 0; gm.x_lo = 0;
     if constexpr (TAPS == 1) {
-      zpix = xpix = (long)tile * (TH * TW);
-      const long left = a.M - zpix;
-      zr_lim = 1; zc_lim = left < TH * TW ? (int)left : TH * TW;
-      z_in = x_in = left >= TH * TW;
+      gm.zpix = gm.xpix = (long)tile * (TH * TW);
+      const long left = a.M - gm.zpix;
+      gm.zr_lim = 1; gm.zc_lim = left < TH * TW ? (int)left : TH * TW;
+      gm.z_in = gm.x_in = left >= TH * TW;
     } else {
       const int tyi = tile % a.tiles_y, tq = tile / a.tiles_y;
       const int txi = tq % a.tiles_x, n = tq / a.tiles_x;
       const int oy0 = tyi * TH, ox0 = txi * TW;
-      zpix = ((long)n * a.Ho + oy0) * a.Wo + ox0;
-      zr_lim = a.Ho - oy0; zc_lim = a.Wo - ox0;
-      z_in = zr_lim >= TH && zc_lim >= TW;
-      y_lo = oy0 * S - C::PAD; x_lo = ox0 * S - C::PAD;
-      xpix = ((long)n * a.H + y_lo) * a.W + x_lo;  // may lie before the image (top / left edge): only lanes that pass the edge test use it
-      x_in = y_lo >= 0 && x_lo >= 0 && y_lo + C::ROWS <= a.H && x_lo + XCOLS <= a.W;
+      gm.zpix = ((long)n * a.Ho + oy0) * a.Wo + ox0;
+      gm.zr_lim = a.Ho - oy0; gm.zc_lim = a.Wo - ox0;
+      gm.z_in = gm.zr_lim >= TH && gm.zc_lim >= TW;
+      gm.y_lo = oy0 * S - C::PAD; gm.x_lo = ox0 * S - C::PAD;
+      gm.xpix = ((long)n * a.H + gm.y_lo) * a.W + gm.x_lo;  // may lie before the image (top / left edge): only lanes that pass the edge test use it
+      gm.x_in = gm.y_lo >= 0 && gm.x_lo >= 0 && gm.y_lo + C::ROWS <= a.H && gm.x_lo + XCOLS <= a.W;
     }
+    return gm;
+  };
+  // does this lane's x unit of piece k hold data (as opposed to zeros from the bounds check) for a tile of geometry gm?
+  auto x_live = [&](const Geom& gm, int k) __attribute__((always_inline)) -> bool {
+    if (xoff[k] == OOB) return false;
+    if (gm.x_in) return true;
+    if constexpr (TAPS == 1) return (int)(xrc[k] & 0xffff) < gm.zc_lim;
+    else return (unsigned)((int)(xrc[k] >> 16) + gm.y_lo) < (unsigned)a.H && (unsigned)((int)(xrc[k] & 0xffff) + gm.x_lo) < (unsigned)a.W;
+  };
+  auto stage = [&](int tile, unsigned char* buf) __attribute__((always_inline)) {
+    unsigned char* s_z = buf;
+    unsigned char* s_x = buf + C::Z_PIECES * 1024;
+    const Geom gm = geom(tile);
+    const long zpix = gm.zpix, xpix = gm.xpix;
+    const int zr_lim = gm.zr_lim, zc_lim = gm.zc_lim;
+    const bool z_in = gm.z_in;
     const wg_i32x4 rz = wg_rsrc(a.dz + (zpix * a.z_cs + a.z_co + cob * 64) * 2);
     const wg_i32x4 rx = wg_rsrc(a.x + (xpix * a.x_cs + a.x_co + cib * 64) * 2);
     const unsigned lz = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)s_z, lx = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)s_x;
@@ -192,12 +209,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
     for (int k = 0; k < XK; ++k) {
       const int pc = wave + 8 * k;
       if (pc >= C::X_PIECES) break;
-      unsigned vo = xoff[k];
-      if (!x_in) {
-        if constexpr (TAPS == 1) vo = (int)(xrc[k] & 0xffff) < zc_lim ? vo : OOB;
-        else vo = ((unsigned)((int)(xrc[k] >> 16) + y_lo) < (unsigned)a.H && (unsigned)((int)(xrc[k] & 0xffff) + x_lo) < (unsigned)a.W) ? vo : OOB;
-      }
+      const unsigned vo = x_live(gm, k) ? xoff[k] : OOB;
       wg_dma16(rx, __builtin_amdgcn_readfirstlane(lx + pc * 1024), vo);
+    }
+  };
+
+  // input BatchNorm table of this block's (<= 64) input channels: (scale, shift) pairs + group flags in LDS behind the ring
+  float* s_bn = (float*)(smem + D * C::BUF);             // [64][2]
+  unsigned char* s_fl = (unsigned char*)(s_bn + 128);    // [8]
+  if (a.bn_tab) {
+    const MslBnTab bt = msl_bn_tab(a.bn_tab, a.x_cs);
+    const int c0 = a.x_co + cib * 64;
+    for (int i = threadIdx.x; i < 128; i += 512) s_bn[i] = cib * 64 + (i >> 1) < a.Cin ? bt.tab[2 * c0 + i] : 0.f;
+    if (threadIdx.x < 8) s_fl[threadIdx.x] = cib * 64 + 8 * (int)threadIdx.x < a.Cin ? bt.flags[(c0 >> 3) + threadIdx.x] : 0;
+    __syncthreads();
+  }
+  // convert this wave's own x pieces of a staged tile (they have landed: the caller waited for them) — z -> act(z * scale + shift) in place
+  auto convert = [&](int tile, unsigned char* buf) __attribute__((always_inline)) {
+    unsigned char* s_x = buf + C::Z_PIECES * 1024;
+    const Geom gm = geom(tile);
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+      const int pc = wave + 8 * k;
+      if (pc >= C::X_PIECES) break;
+      if (!x_live(gm, k)) continue;
+      const int ch = ((wave + 8 * k) * 64 + lane) % C::CPX;  // 16-byte chunk = 8-channel group of the block
+      const unsigned fl = s_fl[ch];
+      if (!(fl & 1)) continue;
+      float sc[8], sh[8];
+      msl_bn_ld8(s_bn, ch * 8, sc, sh);
+      msl_bn_lds16(s_x + pc * 1024 + lane * 16, sc, sh, (fl & 2) != 0);
     }
   };
 
@@ -276,6 +317,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       int later = tile_end - 1 - tile0;
       later = later < D - 2 ? later : D - 2;
       wg_wait_vmcnt(np * later);
+      if (a.bn_tab) { convert(tile0, smem); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
       asm volatile("s_barrier" ::: "memory");
     }
     int cur = 0;
@@ -291,6 +333,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       int later = tile_end - 2 - tile;
       later = later < D - 2 ? later : D - 2;
       wg_wait_vmcnt(later > 0 ? np * later : 0);
+      if (a.bn_tab && tile + 1 < tile_end) convert(tile + 1, smem + (cur + 1 == D ? 0 : cur + 1) * C::BUF);  // tile + 1 has landed (this wave's pieces): convert before it is published
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WG_STAMP(2)
       asm volatile("s_barrier" ::: "memory");
@@ -411,7 +454,7 @@ template <int TAPS, int S, int ZC, int XC, int D>
 static int launch_tr_d(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
   typedef WgCfg<TAPS, S, ZC, XC> C;
   constexpr int RED = (C::WR - 1) * C::WCO * C::WCI * (TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1)) * C::TCO * C::TCI * 4 * 256;  // cross-wave fold
-  constexpr int LDS = D * C::BUF > RED ? D * C::BUF : RED;
+  constexpr int LDS = D * C::BUF + 1024 > RED ? D * C::BUF + 1024 : RED;  // ring | input BatchNorm table (1 KiB)
   static_assert(LDS <= 160 * 1024, "tile ring does not fit in LDS");
   static bool attr = false;
   if (!attr) {
@@ -425,7 +468,7 @@ static int launch_tr_d(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
 template <int TAPS, int S, int ZC, int XC>
 static int launch_tr(const WgTrArgs& a, int ny, long gx, hipStream_t s) {
   typedef WgCfg<TAPS, S, ZC, XC> C;
-  constexpr int FIT = 160 * 1024 / C::BUF;  // staged tiles the CU's LDS holds
+  constexpr int FIT = (160 * 1024 - 1024) / C::BUF;  // staged tiles the CU's LDS holds (beside the 1-KiB input BatchNorm table)
   constexpr int DMAX = FIT >= 4 ? 4 : (FIT >= 3 ? 3 : 2);
   constexpr int DDEF = DMAX >= 3 ? 3 : 2;  // measured: 3 staged tiles beat 2 on the bandwidth-bound shapes by up to 1.5x, 4 adds nothing
   static int depth = -1;
@@ -513,6 +556,7 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   a.tiles_per_block = (int)tpb;
   const long gx = (a.total_tiles + tpb - 1) / tpb;
   a.scratch = (float*)op.p[5];
+  a.bn_tab = (const float*)op.p[8];  // p 8 (optional): input BatchNorm table of the x buffer (msl_common.h)
 #ifdef WG_STAMPS
   a.dbg = wg_dbg_ptr;
 #endif

@@ -258,6 +258,46 @@ __device__ __forceinline__ void msl_split_lds16(unsigned char* p) { *(uint4*)p =
 
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// ---- input BatchNorm table ("BatchNorm on load", round 4).  A train-mode Conv = conv -> BatchNorm(batch statistics) -> SiLU used to write the raw conv
+// output z, then a BN_ACT pass read z and wrote the activated tensor a, which every consumer read.  With a table the producer's raw z stays where a used
+// to go and every consumer (1x1 / 3x3 forward conv, weight gradient, residual read) applies a = act(z * scale + shift) to the 16-byte unit a lane has
+// just staged into LDS, in place, before the barrier that publishes the tile: a is never written nor read as a tensor.
+// Layout, one table per activation BUFFER (not per view): f32 [cs][2] = (scale, shift) per buffer channel (scale = gamma * invstd, shift = beta - mean * scale,
+// written every step by MSL_OP_BN_FINALIZE), then u8 [cs / 8] flags per 8-channel group (written once by the host): bit 0 = the group holds raw z of a
+// pending BatchNorm (transform it), bit 1 = SiLU after the affine map.  Groups with flag 0 hold ordinary activations and are left alone, so one consumer
+// can read a concat of both kinds.  Zero padding must stay zero: lanes whose unit came from outside the image / beyond the tensor skip the transform.
+typedef float msl_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 msl_bf2 __attribute__((ext_vector_type(2)));
+struct MslBnTab { const float* tab; const unsigned char* flags; };  // flags = (const unsigned char*)(tab + 2 * cs)
+__device__ __forceinline__ MslBnTab msl_bn_tab(const void* p, int cs) { return {(const float*)p, p ? (const unsigned char*)((const float*)p + 2 * cs) : nullptr}; }
+// (scale, shift) of the 8 channels starting at buffer channel c0 (multiple of 8) → registers; `t` may be global or LDS
+__device__ __forceinline__ void msl_bn_ld8(const float* t, int c0, float (&sc)[8], float (&sh)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; r += 2) {
+    const float4 q = *(const float4*)(t + 2 * (c0 + r));
+    sc[r] = q.x; sh[r] = q.y; sc[r + 1] = q.z; sh[r + 1] = q.w;
+  }
+}
+// 8 bf16 values (one 16-byte unit) -> act(x * scale + shift), rounded to bf16; float pairs so that hipcc emits packed fp32 ops beside the two transcendentals
+__device__ __forceinline__ uint4 msl_bn_unit(uint4 t, const float (&sc)[8], const float (&sh)[8], bool act) {
+  const unsigned w[4] = {t.x, t.y, t.z, t.w};
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const msl_f2 x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+    const msl_f2 s2 = {sc[2 * j], sc[2 * j + 1]}, h2 = {sh[2 * j], sh[2 * j + 1]};
+    msl_f2 u = x * s2 + h2;
+    if (act) {
+      const msl_f2 e = u * -1.44269504088896f;
+      const msl_f2 den = (msl_f2){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + 1.0f;
+      u = u * (msl_f2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    }
+    o[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(u, msl_bf2));  // one v_cvt_pk_bf16_f32 (RNE, like the scalar cast)
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void msl_bn_lds16(unsigned char* p, const float (&sc)[8], const float (&sh)[8], bool act) { *(uint4*)p = msl_bn_unit(*(const uint4*)p, sc, sh, act); }
+
 // op launchers (one per translation unit)
 int msl_launch_conv(const msl_op& op, hipStream_t s);
 int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s);

@@ -183,7 +183,7 @@ int msl_launch_bn_stats(const msl_op& op, hipStream_t s) {
 
 // BN_FINALIZE: mean / invstd from the sums (all slots), running-stat update, accumulator reset.
 __global__ void bn_finalize_kernel(double* __restrict__ acc, float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar, int C,
-                                   double M, float eps, float mom, int slots) {
+                                   double M, float eps, float mom, int slots, float* __restrict__ tab, const float* __restrict__ gamma, const float* __restrict__ beta) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double a1 = 0.0, a2 = 0.0;
@@ -195,8 +195,14 @@ __global__ void bn_finalize_kernel(double* __restrict__ acc, float* __restrict__
   const double mean = a1 / M;
   double var = a2 / M - mean * mean;
   if (var < 0) var = 0;
-  stats[2 * c] = (float)mean;
-  stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  const float fm = (float)mean, fi = (float)(1.0 / sqrt(var + (double)eps));
+  stats[2 * c] = fm;
+  stats[2 * c + 1] = fi;
+  if (tab) {  // input BatchNorm table row of this channel (msl_common.h): consumers apply act(z * scale + shift) on load
+    const float sc = gamma[c] * fi;
+    tab[2 * c] = sc;
+    tab[2 * c + 1] = fmaf(-fm, sc, beta[c]);
+  }
   if (rmean) {
     rmean[c] = (1.f - mom) * rmean[c] + mom * (float)mean;
     rvar[c] = (1.f - mom) * rvar[c] + mom * (float)(var * (M > 1 ? M / (M - 1) : 1.0));
@@ -204,11 +210,14 @@ __global__ void bn_finalize_kernel(double* __restrict__ acc, float* __restrict__
 }
 
 // BN_FINALIZE: p 0 acc, 1 stats f32[2C], 2 running_mean|NULL, 3 running_var ; i 0 N,1 H,2 W,3 C,21 slots ; f 0 eps, 1 momentum
+//   optional p 4 = input-BatchNorm-table rows of these C channels (f32 [C][2], i.e. table base + 2 * first buffer channel), 5 gamma, 6 beta: (scale, shift) for the consumers
 int msl_launch_bn_finalize(const msl_op& op, hipStream_t s) {
   const double M = (double)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3], slots = slots_of(op, 21);
   MSL_REQUIRE(op.p[0] && op.p[1] && M > 0 && C > 0 && (!op.p[2] || op.p[3]) && slots <= MSL_MAX_SLOTS, "bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[1], (float*)op.p[2], (float*)op.p[3], C, M, op.f[0], op.f[1], slots);
+  MSL_REQUIRE(!op.p[4] || (op.p[5] && op.p[6]), "bn_finalize: the table form needs gamma (p 5) and beta (p 6)");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (double*)op.p[0], (float*)op.p[1], (float*)op.p[2], (float*)op.p[3], C, M, op.f[0], op.f[1], slots,
+                     (float*)op.p[4], (const float*)op.p[5], (const float*)op.p[6]);
   MSL_CHECK_LAUNCH("bn_finalize");
   return MSL_OK;
 }
@@ -223,7 +232,8 @@ struct BnFin { const double* acc; float* stats_out; float* rmean; float* rvar; d
 template <bool F32, int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y, long M, int C,
-                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT, BnFin fin, bool cvec) {
+                                                     int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT, BnFin fin, bool cvec,
+                                                     const float* __restrict__ rtab) {  // rtab: input BatchNorm table of the RESIDUAL's buffer (msl_common.h) or NULL
   __shared__ __attribute__((aligned(16))) float ks[2048];
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
@@ -251,6 +261,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z,
   float mu[V], is[V], ga[V], be[V];
   if (fin.acc) ld_bn_consts<V>(ks, gamma, beta, c, cvec, mu, is, ga, be);  // ks (LDS) is 16-byte aligned
   else ld_bn_consts<V>(stats, gamma, beta, c, cvec, mu, is, ga, be);
+  // residual held as the raw conv output of a pending BatchNorm: res = act(r * scale + shift) of its own layer, applied here on load
+  float rsc[V], rsh[V];
+  unsigned rfl = 0;
+  if (res && rtab) {
+    const MslBnTab bt = msl_bn_tab(rtab, r_cs);
+    rfl = bt.flags[(r_co + c) >> 3];
+#pragma unroll
+    for (int r = 0; r < V; ++r) { rsc[r] = bt.tab[2 * (r_co + c + r)]; rsh[r] = bt.tab[2 * (r_co + c + r) + 1]; }
+  }
   // pixel of (k, u) = p0 + (k + u) * PL.  Batches of U pixel groups: the loads of batch k + 1 are issued (every lane, clamped to the last pixel —
   // a load under a per-lane condition is branched around and waited for one by one) before batch k is computed and stored, so a thread always has
   // U (2U with a residual) 16-byte loads in flight and never waits for its own stores.
@@ -282,6 +301,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z,
       float v[V], rv[V];
       cvtraw<F32, V>(za[u], v);
       if (res) cvtraw<F32, V>(ra[u], rv);
+      if (rfl & 1) {
+#pragma unroll
+        for (int r = 0; r < V; ++r) {
+          float t = fmaf(rv[r], rsc[r], rsh[r]);
+          if (rfl & 2) t = silu_f(t);
+          rv[r] = F32 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));  // the value BN_ACT would have stored for the residual's layer
+        }
+      }
 #pragma unroll
       for (int r = 0; r < V; ++r) {
         const float t = fmaf(ga[r], (v[r] - mu[r]) * is[r], be[r]);  // same expression as the backward's zhat: no cancellation against the mean
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z,
 }
 
 // BN_ACT: p 0 z, 1 stats, 2 gamma, 3 res|NULL, 4 y, 5 beta ; i 0 N,1 H,2 W,3 C,10 z_cs,11 z_co,12 y_cs,13 y_co,14 r_cs,15 r_co,18 act
+//   p 8 (optional): input BatchNorm table of the residual's buffer — the residual is stored as the raw conv output of a pending BatchNorm
 int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
   const int C = op.i[3];
@@ -315,7 +343,8 @@ int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
     fin.acc = (const double*)op.p[6]; fin.stats_out = (float*)op.p[1]; fin.rmean = (float*)op.p[7]; fin.rvar = op.p[7] ? (float*)op.p[7] + op.i[16] : nullptr;
     fin.M = (double)M; fin.eps = op.f[0]; fin.mom = op.f[1]; fin.slots = slots_of(op, 21);
   }
-#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin, cvec)
+#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin, cvec, (const float*)op.p[8])
+  MSL_REQUIRE(!op.p[8] || (op.p[3] && op.i[14] % 8 == 0 && op.i[15] % 4 == 0), "bn_act: the residual's input BatchNorm table (p 8) needs a residual view inside whole 8-channel groups");
   if (op.dtype == MSL_F32) { if (v8) BA(true, 8); else BA(true, 4); } else { if (v8) BA(false, 8); else BA(false, 4); }
 #undef BA
   MSL_CHECK_LAUNCH("bn_act");

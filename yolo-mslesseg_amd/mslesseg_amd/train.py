@@ -20,6 +20,7 @@ One process per GPU.  Data parallelism = ONE RCCL all-reduce(SUM) of the flat gr
 from __future__ import annotations
 
 import csv
+import datetime
 import math
 import os
 import shutil
@@ -90,6 +91,30 @@ class Schedule:
 def shard_indices(n: int, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
     """Slices seen by `rank` in `epoch`: a seeded permutation dealt round-robin — disjoint across ranks, identical on every rank."""
     return np.random.default_rng([seed, epoch]).permutation(n)[rank::world]
+
+
+def collective_selfcheck(device, n: int = 1 << 18) -> dict:
+    """Start-up check of the gradient collective on the REAL backend (RCCL over xGMI on a GPU node): every rank contributes (rank + 1) x a known ramp, the
+    all-reduce must return sum(1..world) x the ramp on every element.  → {rank, world, backend, device, ok, ms}; raises when the sum is wrong — a
+    mis-wired communicator (wrong device per rank, a peer on another job's port) then stops the run at once instead of training on garbage."""
+    dist = torch.distributed
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    on_dev = backend != "gloo"
+    ramp = torch.arange(n, dtype=torch.float32, device=device if on_dev else "cpu") % 251
+    buf = ramp * float(rank + 1)
+    if on_dev:
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if on_dev:
+        torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) * 1e3
+    ok = bool(torch.equal(buf, ramp * float(world * (world + 1) // 2)))
+    rec = {"rank": rank, "world": world, "backend": backend, "device": str(device), "ok": ok, "first_allreduce_ms": round(ms, 3)}
+    if not ok:
+        raise RuntimeError(f"gradient collective self-check failed: {rec}")
+    return rec
 
 
 def allreduce_gradients(flat: torch.Tensor) -> torch.Tensor:
@@ -167,9 +192,10 @@ class CheckpointWriter:
 
         def work():
             try:
+                torch.cuda.set_device(tr.device)  # a new thread starts on cuda:0 whatever the trainer's device is: events and pinned copies belong to the rank's own GPU
                 ev.synchronize()
                 job(self)
-            except BaseException as e:  # surfaced by wait()
+            except BaseException as e:  # surfaced by wait() in the main thread: the rank then leaves fit() with an exception and the launcher ends the job
                 self.error = e
 
         self.thread = threading.Thread(target=work, daemon=True)
@@ -180,9 +206,14 @@ class CheckpointWriter:
         tr = self.tr
         sd = tr.store.state_dict(p=self.hp, b=self.hb)
         last, best = tr.wdir / "last.pt", tr.wdir / "best.pt"
-        params.save_checkpoint(last, sd, tr.store.scale, tr.nc, tr.names, extra)
+        # written beside the target and renamed into place: a reader (or a crash of this process) never sees a truncated checkpoint
+        tmp = last.with_name(last.name + ".tmp")
+        params.save_checkpoint(tmp, sd, tr.store.scale, tr.nc, tr.names, extra)
+        os.replace(tmp, last)
         if is_best:
-            shutil.copyfile(last, best)  # the same bytes: one serialisation per epoch
+            tmpb = best.with_name(best.name + ".tmp")
+            shutil.copyfile(last, tmpb)  # the same bytes: one serialisation per epoch
+            os.replace(tmpb, best)
 
 
 class Trainer:
@@ -204,6 +235,7 @@ class Trainer:
         if self.world > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.distributed.init_process_group("nccl", device_id=self.device)
+        self.collective = collective_selfcheck(self.device) if self.world > 1 else None  # first use of the communicator: a known sum, checked
         self.yolo.device = str(self.device)  # predict()/val() after fit() run where the training ran (one process per GPU: never all on cuda:0)
         # a process group of its own for the per-epoch gather of validation records: it is issued from the writer threads (one gather per epoch on
         # every rank, in epoch order), so it must not share a communicator with the main threads' gradient all-reduces.  Host objects: gloo.
@@ -253,7 +285,12 @@ class Trainer:
         self.store.load_state(state)
         self.dtype = getattr(yolo, "train_dtype", yolo.dtype)  # training arithmetic (bf16 by default: the counterpart of the reference's amp=True)
         S = self.hyp["imgsz"]
-        self.plan = TrainPlan(self.store, self.batch, S, S, self.dtype)
+        # data parallel: the backward program is cut behind the head + neck layers (model.11..) so that their gradient bucket is reduced beside the backbone's
+        # backward (forward_backward(reduce_now=True)); MSLESSEG_GRAD_BUCKETS=1 keeps one program and one all-reduce behind it
+        cut = 11 if (self.world > 1 and os.environ.get("MSLESSEG_GRAD_BUCKETS", "2") != "1") else None
+        self.plan = TrainPlan(self.store, self.batch, S, S, self.dtype, bucket_cut=cut)
+        self._buckets = self.store.bucket_ranges(cut) if cut is not None else None
+        self._reduce_works, self._reduced = [], False
         lv = [self.plan.levels[i] for i in sorted(self.plan.levels)]
         self.loss_op = SegLossOp(lv, [tuple(self.plan.G(v) for v in l) for l in lv], self.plan.proto_view, self.plan.G(self.plan.proto_view), self.nc, S, S,
                                  self.dtype, self.device)
@@ -360,9 +397,27 @@ class Trainer:
         out["gt"] = torch.from_numpy(gt).to(self.device, non_blocking=True)
         return out
 
-    def forward_backward(self, batch) -> torch.Tensor:
-        """HIP forward → HIP loss op (value + gradient of the head outputs) → HIP backward.  Gradients ACCUMULATE into store.g."""
+    def _reduce_bucket(self, k: int) -> None:
+        """All-reduce (SUM) of gradient bucket k's flat ranges, issued now: RCCL runs it on its own stream behind what this stream holds so far, so bucket 0
+        (head + neck) overlaps the backbone's backward program.  gloo (the single-box rehearsal): staged through host memory, synchronously."""
+        dist = torch.distributed
+        for lo, hi in self._buckets[k]:
+            if hi <= lo:
+                continue
+            view = self.store.g[lo:hi]
+            if dist.get_backend() == "gloo":
+                host = view.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                view.copy_(host)
+            else:
+                self._reduce_works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def forward_backward(self, batch, reduce_now: bool = False) -> torch.Tensor:
+        """HIP forward → HIP loss op (value + gradient of the head outputs) → HIP backward.  Gradients ACCUMULATE into store.g.
+        `reduce_now` (data parallel): this is the last micro-batch before an optimizer step — the gradient buckets are all-reduced as they complete
+        (the first one between the two backward programs); optimizer_step() then only waits for them."""
         plan = self.plan
+        bucketed = reduce_now and self.world > 1 and self._buckets is not None and not self.torch_loss
         if not torch.is_tensor(batch["img"]):
             batch = self.to_device(batch)
         plan.in_view.t.copy_(batch["img"].reshape(-1), non_blocking=True)
@@ -370,7 +425,12 @@ class Trainer:
         plan.forward()
         if not self.torch_loss:
             items = self.loss_op(batch["gt"], batch["masks"])[:4].clone()  # writes d(loss)/d(head outputs) into the plan's gradient views
-            plan.backward()
+            if bucketed:
+                plan.backward(on_cut=lambda: self._reduce_bucket(0))
+                self._reduce_bucket(1)
+                self._reduced = True
+            else:
+                plan.backward()
             return items
         outs = plan.head_outputs()
         leaves = [[t.detach().requires_grad_() for t in lv] for lv in outs["levels"]]
@@ -400,7 +460,12 @@ class Trainer:
     def optimizer_step(self, lr: float) -> None:
         st = self.store
         if self.world > 1:
-            allreduce_gradients(st.g)  # the one collective of the data path (SUM over ranks)
+            if self._reduced:  # the buckets were issued inside forward_backward(reduce_now=True): this stream waits for them
+                for w in self._reduce_works:
+                    w.wait()
+                self._reduce_works, self._reduced = [], False
+            else:
+                allreduce_gradients(st.g)  # the one collective of the data path (SUM over ranks)
         norm = torch.linalg.vector_norm(st.g)
         self.gscale.copy_(torch.clamp(self.hyp["clip"] / (norm + 1e-6), max=1.0))
         self.opt_steps += 1
@@ -513,14 +578,25 @@ class Trainer:
         def finish(to_rank0: bool = False):
             """Host half (may run in the writer thread): per-image rows, the merge over ranks, AP.  `to_rank0`: gather on the validation group to
             rank 0 only — the other ranks return (None, None) — instead of an all-gather on the default group."""
-            done.synchronize()
-            stats = MT.SegStats()
-            for b0, tensors in host:
-                stats.add_matched(tuple(t.numpy() for t in tensors), first_id=b0)
-            mine_items = items_h[:n_mine].numpy().astype(np.float64)
-            parts = gather_objects({"batches": mine, "items": mine_items, "stats": stats.export()}, self.world, group=self._val_group if to_rank0 else None, to_rank0=to_rank0)
+            # A rank whose host half fails still enters the gather — with the error as its payload — so that no peer waits for it forever; the
+            # failure is raised on the ranks that receive it and (by this rank's wait()) in its own main thread.
+            try:
+                done.synchronize()
+                stats = MT.SegStats()
+                for b0, tensors in host:
+                    stats.add_matched(tuple(t.numpy() for t in tensors), first_id=b0)
+                mine_items = items_h[:n_mine].numpy().astype(np.float64)
+                payload, failure = {"batches": mine, "items": mine_items, "stats": stats.export()}, None
+            except Exception as e:  # noqa: BLE001 — reported, then re-raised below
+                payload, failure = {"error": f"rank {self.rank}: {e!r}"}, e
+            parts = gather_objects(payload, self.world, group=self._val_group if to_rank0 else None, to_rank0=to_rank0)
+            if failure is not None:
+                raise failure
             if parts is None:
                 return None, None
+            errors = [part["error"] for part in parts if "error" in part]
+            if errors:
+                raise RuntimeError("validation failed on " + "; ".join(errors))
             per_batch = np.zeros((n_bounds, 4))
             for part in parts:
                 for bi, it in zip(part["batches"], part["items"]):
@@ -551,7 +627,9 @@ class Trainer:
         mcols = [float(mets[c]) for c in RESULT_COLUMNS[6:14]] if mets else [0.0] * 8
         row = [epoch + 1, time.time() - self.t0] + [float(x) for x in tl] + mcols + [float(x) for x in vl] + [lr] * 3
         with open(self.save_dir / "results.csv", "a", newline="") as f:
-            f.write(",".join([str(row[0])] + [f"{v:.6g}" for v in row[1:]]) + "\n")  # six significant digits, as the reference's files carry
+            # as the reference's files: losses and metrics rounded to five decimals (2.41102, 0.36806, 1.2162), then every column with six significant digits
+            row = row[:2] + [round(v, 5) for v in row[2:18]] + row[18:]
+            f.write(",".join([str(row[0])] + [f"{v:.6g}" for v in row[1:]]) + "\n")
         is_best = self.best_fitness is None or fitness >= self.best_fitness
         if is_best:
             self.best_fitness = fitness
@@ -580,7 +658,8 @@ class Trainer:
     def fit(self):
         self.t0 = time.time()
         if self.world > 1 and self._val_group is None:
-            self._val_group = torch.distributed.new_group(backend="gloo")  # collective: every rank enters fit()
+            # collective: every rank enters fit().  A bounded wait: a peer that died turns the writer threads' gather into an error instead of a hang
+            self._val_group = torch.distributed.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("MSLESSEG_VAL_GROUP_TIMEOUT_S", "600"))))
         if self.rank == 0:
             self._write_args()
             with open(self.save_dir / "results.csv", "w", newline="") as f:
@@ -594,7 +673,7 @@ class Trainer:
             lr = self.sched.lr(ni, epoch)
             for batch in self._batches(epoch):
                 lr = self.sched.lr(ni, epoch)
-                items = self.forward_backward(batch)
+                items = self.forward_backward(batch, reduce_now=ni - last_opt >= self.sched.accumulate(ni))
                 if ni - last_opt >= self.sched.accumulate(ni):
                     self.optimizer_step(lr)
                     last_opt = ni

@@ -81,6 +81,21 @@ class ParamStore:
         self.v = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.b = torch.zeros(self.nb, dtype=torch.float32, device=dev)  # BN running stats
 
+    def bucket_ranges(self, first_layer: int):
+        """Flat-buffer ranges [(lo, hi)] of two gradient buckets: (parameters of layers model.<first_layer>.. , parameters of the layers before).  The flat order
+        is [weights in layer order | BatchNorm gammas / betas / biases in layer order], so each bucket is one range of either region."""
+        def first(keys):
+            for k in keys:
+                if int(k.split(".")[1]) >= first_layer:
+                    return self.entries[k][0]
+            return None
+        wk = [k for k in self.entries if k.endswith(".w")]
+        bk = [k for k in self.entries if not k.endswith(".w")]
+        w0, b0 = first(wk), first(bk)
+        w0 = self.n_decay if w0 is None else w0
+        b0 = self.n if b0 is None else b0
+        return [(w0, self.n_decay), (b0, self.n)], [(0, w0), (self.n_decay, b0)]
+
     # -- addressing
     def off(self, key: str) -> int:
         return self.entries[key][0]
@@ -240,6 +255,144 @@ class _Init:
         return m is not None and bool(m[v.co : v.co + v.C].all())
 
 
+class _SV:
+    """Handle of the reader scan: a channel range of a numbered buffer."""
+
+    __slots__ = ("b", "H", "W", "C", "cs", "co")
+
+    def __init__(self, b, H, W, C, cs, co):
+        self.b, self.H, self.W, self.C, self.cs, self.co = b, H, W, C, cs, co
+
+
+class OnLoadScan(graph.Visitor):
+    """Dry walk that decides which train-mode BatchNorms stay PENDING ("BatchNorm on load", csrc/msl_common.h): the layer keeps its raw conv output z
+    where the activated tensor used to go, MSL_OP_BN_FINALIZE writes (scale, shift) into the buffer's table, and every reader applies
+    act(z * scale + shift) to what it stages — the BN_ACT pass (one read + one write of the tensor) disappears.  A layer qualifies when it has no
+    residual of its own and EVERY reader of its output is a kernel that takes the table: 1x1 / LDS-tiled 3x3 forward convs together with their
+    transposed-read weight gradients (asked from the library: msl_input_table_supported) and the residual operand of another layer's BN_ACT; and when
+    the readers together pass over it at most `max_reads` times (each pass pays the activation's two transcendentals per element on the vector ALU).
+    [the arithmetic: ultralytics' Conv = Conv2d + BatchNorm2d(batch statistics) + SiLU under model.train(), REF scripts/train.py:358-366]"""
+
+    def __init__(self, N: int, H: int, W: int, dtype: int, max_reads: float = 2.0):
+        self.N, self.H, self.W, self.dtype, self.max_reads = N, H, W, dtype, max_reads
+        self.nb = 0
+        self.prod: List[dict] = []
+        self.reads: List[dict] = []
+
+    def _new(self, H, W, C):
+        self.nb += 1
+        return _SV(self.nb, H, W, C, C, 0)
+
+    def _probe(self, kind, x, cout, k, s, z_cs, lds):
+        pad = k // 2
+        Ho, Wo = (x.H + 2 * pad - k) // s + 1, (x.W + 2 * pad - k) // s + 1
+        K = k * k * x.C
+        kpad = K if lds else (K + 31) // 32 * 32
+        i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: z_cs, 13: 0, 16: K, 17: kpad,
+             21: cout if lds else (cout + 15) // 16 * 16, 25: 1 if lds else 0}
+        op = hiplib.make_op(kind, self.dtype, p=(4096, 4096, 4096, 0, 4096), i=i)
+        import ctypes
+        return bool(hiplib.lib().msl_input_table_supported(ctypes.byref(op)))
+
+    def _conv_reader_ok(self, x, cout, k, s) -> bool:
+        if self.dtype != MSL_BF16:
+            return False
+        lds = _lds_ok(x.C, cout, k, self.dtype)
+        if k == 3 and not lds:
+            return False
+        if k == 3 and s == 1 and cout % 64 == 0 and x.C % 32 == 0 and x.C <= 64 and self.N * ((x.H + 7) // 8) * ((x.W + 31) // 32) >= 1024:
+            return False  # the persistent weights-resident 3x3 form (conv3x3_lds.hip) has no room for a table: such a reader keeps its activated input
+        cpad = cout if cout % 8 == 0 else (cout + 7) // 8 * 8
+        return self._probe(hiplib.OP_CONV, x, cout, k, s, cpad, lds) and self._probe(hiplib.OP_CONV_WGRAD, x, cout, k, s, cpad, False)
+
+    def _read(self, v, kind, ok, name=None):
+        if v is not None:
+            self.reads.append(dict(v=v, kind=kind, ok=ok, name=name))
+
+    # -- Visitor
+    def input(self):
+        return self._new(self.H, self.W, 3)
+
+    def stem(self, name, x, cout):
+        y = self._new((x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, cout)
+        self.prod.append(dict(name=name, v=y, bn=True, res=False))
+        return y
+
+    def conv(self, name, x, cout, k=1, s=1, act=True, bn=True, out=None, res=None, f32_out=False):
+        pad = k // 2
+        Ho, Wo = (x.H + 2 * pad - k) // s + 1, (x.W + 2 * pad - k) // s + 1
+        y = out if out is not None else self._new(Ho, Wo, cout)
+        self._read(x, "conv", self._conv_reader_ok(x, cout, k, s), name)
+        self._read(res, "res", bool(bn), name)
+        self.prod.append(dict(name=name, v=y, bn=bn, res=res is not None))
+        return y
+
+    def dwconv(self, name, x, act=True, res=None, gmap=None, out=None):
+        C = x.C if gmap is None else x.C // gmap[1] * gmap[0]
+        inplace = res is not None and out is not None and res.b == out.b and res.co == out.co
+        y = out if (out is not None and not inplace) else self._new(x.H, x.W, C)
+        self._read(x, "dw", False, name)
+        self._read(res, "res", gmap is None, name)
+        self.prod.append(dict(name=name, v=y, bn=True, res=res is not None))
+        return y
+
+    def convT2x2(self, name, x, cout):
+        self._read(x, "convT", False, name)
+        y = self._new(2 * x.H, 2 * x.W, cout)
+        self.prod.append(dict(name=name, v=y, bn=False, res=False))
+        return y
+
+    def cat_buffer(self, like, C, scale=1.0):
+        return self._new(like.H, like.W, C)
+
+    def view(self, buf, c0, c):
+        return _SV(buf.b, buf.H, buf.W, c, buf.cs, buf.co + c0)
+
+    def upsample2x(self, x, out):
+        self._read(x, "up", False)
+        return out
+
+    def copy(self, src, dst):
+        self._read(src, "copy", False)
+        return dst
+
+    def sppf_pool(self, buf, c):
+        self._read(self.view(buf, 0, c), "pool", False)
+
+    def attention(self, qkv, heads, kd, hd):
+        self._read(qkv, "attn", False)
+        return self._new(qkv.H, qkv.W, heads * hd)
+
+    def head_level(self, i, box, cls, coef):
+        for v in (box, cls, coef):
+            self._read(v, "loss", False)
+
+    def proto(self, p):
+        self._read(p, "loss", False)
+
+    # -- decision
+    def pending(self) -> "set[str]":
+        out = set()
+        for pr in self.prod:
+            v = pr["v"]
+            if not pr["bn"] or pr["res"]:
+                continue
+            passes, ok, n = 0.0, True, 0
+            for rd in self.reads:
+                r = rd["v"]
+                if r.b != v.b:
+                    continue
+                lo, hi = max(r.co, v.co), min(r.co + r.C, v.co + v.C)
+                if hi <= lo:
+                    continue
+                n += 1
+                ok = ok and rd["ok"]
+                passes += (hi - lo) / v.C
+            if ok and n > 0 and passes <= self.max_reads + 1e-9 and v.C % 8 == 0 and v.co % 8 == 0 and v.cs % 8 == 0:
+                out.add(pr["name"])
+        return out
+
+
 class TrainPlan(graph.Visitor):
     """Forward + backward programs of YOLO11-seg in training mode for a fixed batch shape.
 
@@ -247,8 +400,13 @@ class TrainPlan(graph.Visitor):
     `forward/backward` are lists of segments (hiplib.Program; the segment machinery still accepts a Python callable, none is emitted any more:
     every op of both engines, the PSA attention core included, is a kernel of this library)."""
 
-    def __init__(self, store: ParamStore, N: int, H: int, W: int, dtype: int = MSL_BF16):
+    def __init__(self, store: ParamStore, N: int, H: int, W: int, dtype: int = MSL_BF16, bucket_cut: Optional[int] = None):
+        """`bucket_cut` (data-parallel training): layer index L such that the backward program is cut into two programs — the layers model.L.. (head + neck,
+        whose backward runs first) and model.0..L-1 (backbone).  Every program ends with all its lanes joined, so after the first one the flat-gradient
+        ranges `store.bucket_ranges(L)[0]` are complete and their all-reduce can run beside the second (train.Trainer)."""
         assert H % 32 == 0 and W % 32 == 0
+        self.bucket_cut, self.cut_segment = bucket_cut, None
+        self._last_name = "model.0"
         self.store, self.N, self.H, self.W, self.dtype = store, N, H, W, dtype
         self.device = store.device
         self.zeros = torch.zeros(4096, dtype=torch.float32, device=self.device)
@@ -275,6 +433,21 @@ class TrainPlan(graph.Visitor):
         self.taps: Dict[str, View] = {}
         self._init = _Init()
         self._bw_builders: List[Callable[[], None]] = []
+        # BatchNorm on load (bf16): the layers whose activated tensor is never written (OnLoadScan); MSL_BN_ONLOAD=0 switches the form off, MSL_BN_ONLOAD_MAX_READS bounds
+        # the reader passes a pending tensor may have
+        self.pending: "set[str]" = set()
+        self._tabs: Dict[int, torch.Tensor] = {}   # id(buffer tensor) -> input BatchNorm table (f32 [cs][2] | u8 [cs / 8] flags)
+        self._tab_flags: Dict[int, torch.Tensor] = {}  # host copy of the flags
+        # Measured (round 4; scripts/dev_bn_on_load_ab.py → profiles/r04c_onload_ab.txt): with the activation's two quarter-rate transcendentals
+        # on every reader the form is SLOWER than the BN_ACT pass it removes on all but the channel-slice layers, and no faster over the step — it is built,
+        # tested (tests/test_gpu_bn_onload.py, tests/test_gpu_train.py with MSL_BN_ONLOAD=1) and off by default.
+        if dtype == MSL_BF16 and os.environ.get("MSL_BN_ONLOAD", "0") == "1":
+            scan = OnLoadScan(N, H, W, dtype, float(os.environ.get("MSL_BN_ONLOAD_MAX_READS", "2.0")))
+            graph.walk(scan, store.scale, store.nc)
+            self.pending = scan.pending()
+            only = os.environ.get("MSL_BN_ONLOAD_ONLY")  # measurement switch: a regular expression the pending layers' names must match
+            if only:
+                self.pending = {n for n in self.pending if re.search(only, n)}
         graph.walk(self, store.scale, store.nc)
         self._finish()
 
@@ -296,6 +469,29 @@ class TrainPlan(graph.Visitor):
         op._lane = self._lane
         self._fwd[-1].append(op)
 
+    # -- input BatchNorm tables (csrc/msl_common.h): one per activation buffer, created when a layer writing into it is left pending
+    def _mark_pending(self, y: View, act: bool) -> int:
+        """Flag y's 8-channel groups as 'raw conv output of a pending BatchNorm' in its buffer's table; returns the address of y's first table row."""
+        key = id(y.t)
+        if key not in self._tabs:
+            nfl = (y.cs // 8 + 15) // 16 * 16
+            self._tabs[key] = torch.zeros(y.cs * 8 + nfl, dtype=torch.uint8, device=self.device)
+            self._tab_flags[key] = torch.zeros(y.cs // 8, dtype=torch.uint8)
+            self._keep.append(self._tabs[key])
+        fl = self._tab_flags[key]
+        fl[y.co // 8 : (y.co + y.C) // 8] = 1 | (2 if act else 0)
+        self._tabs[key][y.cs * 8 : y.cs * 8 + fl.numel()] = fl.to(self.device)
+        return self._tabs[key].data_ptr() + 8 * y.co
+
+    def _xtab(self, x: Optional[View]) -> int:
+        """Table address for a reader of view x: non-zero iff some channel group of x is pending."""
+        if x is None:
+            return 0
+        fl = self._tab_flags.get(id(x.t))
+        if fl is None or not bool(fl[x.co // 8 : (x.co + x.C + 7) // 8].any()):
+            return 0
+        return self._tabs[id(x.t)].data_ptr()
+
     def _set_lane(self, name: Optional[str]) -> int:
         """Lane (side stream) of the layer being visited: the detection-head chains of pyramid level i run on lane 1+i, concurrently with
         the other levels (their kernels at 40x40 / 20x20 are launch-latency bound); the prototype branch shares lane 1 with level 0
@@ -308,6 +504,8 @@ class TrainPlan(graph.Visitor):
             elif re.match(r"model\.\d+\.proto\.", name):
                 lane = 4 if self._proto_own_lane else 1
         self._lane = lane
+        if name:
+            self._last_name = name
         return lane
 
     WGRAD_LANE = 5  # first deferred lane (capi.hip): weight gradients of the trunk run beside the input-gradient / BatchNorm chain
@@ -335,7 +533,7 @@ class TrainPlan(graph.Visitor):
         return self._wg_scratch[lane].data_ptr()
 
     def _add_bw(self, build):
-        self._bw_builders.append((build, self._lane))
+        self._bw_builders.append((build, self._lane, self._last_name))
 
     def _acc(self, C) -> torch.Tensor:
         """Forward BatchNorm accumulator f64[slots][2C]: a slice of ONE buffer.  BN_FINALIZE resets its own slice after reading it; the layers
@@ -396,10 +594,13 @@ class TrainPlan(graph.Visitor):
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
         if stats_acc is not None:  # BatchNorm sums in the conv epilogue (1x1 streaming kernel only)
             i[23] = ACC_SLOTS
-        return hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bias_ptr, rp, y.t.data_ptr(), 0 if stats_acc is None else stats_acc.data_ptr()), i=i)
+        xt = 0 if dgrad or store_mode else self._xtab(x)  # forward convs only: a gradient view never holds a pending BatchNorm
+        return hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bias_ptr, rp, y.t.data_ptr(), 0 if stats_acc is None else stats_acc.data_ptr(), 0, 0, xt), i=i)
 
-    def _bn_forward(self, name, z: View, y: View, C, act, res, acc=None):
-        """`acc` given: the producing conv already accumulated (sum z, sum z^2) into it — no BN_STATS pass."""
+    def _bn_forward(self, name, z: View, y: View, C, act, res, acc=None, pending=False):
+        """`acc` given: the producing conv already accumulated (sum z, sum z^2) into it — no BN_STATS pass.
+        `pending` (z IS y: the raw conv output sits where the activation used to go): no BN_ACT pass — BN_FINALIZE writes the layer's (scale, shift) rows of the
+        buffer's input BatchNorm table and the readers apply the activation on load."""
         st = self.store
         fused = acc is not None
         acc = self._acc(C) if acc is None else acc
@@ -408,6 +609,12 @@ class TrainPlan(graph.Visitor):
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C}
         if not fused:
             self._f(hiplib.make_op(hiplib.OP_BN_STATS, self.dtype, p=(z.t.data_ptr(), acc.data_ptr()), i={**dims, 10: z.cs, 11: z.co, 21: ACC_SLOTS}))
+        if pending:
+            assert res is None and z.t is y.t and z.co == y.co
+            rows = self._mark_pending(y, bool(act))
+            self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var"), rows,
+                                                                         st.ptr(name + ".gamma"), st.ptr(name + ".beta")), i={**dims, 21: ACC_SLOTS}, f=(BN_EPS, BN_MOM)))
+            return stats
         # the finalize rides in BN_ACT: a separate 5 us launch per layer on the forward chain costs more than recomputing (mean, invstd) per workgroup
         # (measured at batch 128, ms per step: never fused 26.92, layers <= 2e7 elements 26.75, <= 6e7 26.70, all layers 26.60)
         fuse = self._fuse_finalize and self.N * z.H * z.W * C <= int(os.environ.get("MSL_BN_FUSE_MAX", "1000000000000")) and C <= 1024
@@ -418,18 +625,20 @@ class TrainPlan(graph.Visitor):
         rp = 0
         if res is not None:
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
-        p = (z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), rp, y.t.data_ptr(), st.ptr(name + ".beta"))
+        p = (z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), rp, y.t.data_ptr(), st.ptr(name + ".beta"), 0, 0)
         f = ()
         if fuse:
             i[16], i[21] = (st.bptr(name + ".var") - st.bptr(name + ".mean")) // 4, ACC_SLOTS
-            p, f = p + (acc.data_ptr(), st.bptr(name + ".mean")), (BN_EPS, BN_MOM)
-        self._f(hiplib.make_op(hiplib.OP_BN_ACT, self.dtype, p=p, i=i, f=f))
+            p, f = p[:6] + (acc.data_ptr(), st.bptr(name + ".mean")), (BN_EPS, BN_MOM)
+        self._f(hiplib.make_op(hiplib.OP_BN_ACT, self.dtype, p=p + (self._xtab(res),), i=i, f=f))  # p 8: the residual may itself be a pending BatchNorm's raw output
         return stats
 
-    def _bn_backward(self, ops, name, z: View, y: View, C, act, stats, res: Optional[View], res_inplace=False, lane: Optional[int] = None):
-        """dy = G(y) → dz written in place over z; dgamma/dbeta into the flat gradient; residual fan-out."""
+    def _bn_backward(self, ops, name, z: View, y: View, C, act, stats, res: Optional[View], res_inplace=False, lane: Optional[int] = None, dz: Optional[View] = None):
+        """dy = G(y) → dz written in place over z (or into `dz`: pending layers keep z, their readers' weight gradients still need it); dgamma/dbeta into the
+        flat gradient; residual fan-out."""
         st = self.store
         gy = self.G(y)
+        dz = z if dz is None else dz
         acc = self._acc_bwd(C, ACC_SLOTS)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS}
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
@@ -437,8 +646,8 @@ class TrainPlan(graph.Visitor):
         # (MSL_OP_BN_ACT_BWD_FUSED; at most one such kernel may be in flight, hence lane 0 only; no residual fan-out in that form)
         fuse_max = int(os.environ.get("MSL_BN_BWD_FUSE_MAX", "0"))
         if fuse_max > 0 and lane == 0 and (res is None or res_inplace) and self.N * z.H * z.W * C <= fuse_max:
-            ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_FUSED, self.dtype, p=pcommon + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
-                                      i={**dims, 14: z.cs, 15: z.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
+            ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_FUSED, self.dtype, p=pcommon + (dz.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
+                                      i={**dims, 14: dz.cs, 15: dz.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
             return
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
         papply, extra = pcommon, {}
@@ -449,8 +658,8 @@ class TrainPlan(graph.Visitor):
             first = self._init.first_write(gr)
             papply = pcommon[:4] + (gr.t.data_ptr(),) + pcommon[5:]
             extra = {16: 1, 19: 1 if first else 0, 22: st.off(name + ".beta") - st.off(name + ".gamma"), 24: gr.cs, 25: gr.co}
-        ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=papply + (z.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
-                                  i={**dims, 14: z.cs, 15: z.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma"), **extra}))  # 17: dgamma / dbeta ADD
+        ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_APPLY, self.dtype, p=papply + (dz.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
+                                  i={**dims, 14: dz.cs, 15: dz.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma"), **extra}))  # 17: dgamma / dbeta ADD
         # to the flat gradient like every weight gradient does (round 3: they used to overwrite it, so under gradient accumulation — batch < nbs = 64 —
         # only the last micro-batch's BatchNorm gradients reached the optimizer; found by tests/test_gpu_ddp_rehearsal.py's union-batch equivalence)
 
@@ -464,19 +673,22 @@ class TrainPlan(graph.Visitor):
         lane = self._set_lane(name)
         st = self.store
         Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
-        z, y = self._new(Ho, Wo, cout), self._new(Ho, Wo, cout)
+        pend = name in self.pending
+        y = self._new(Ho, Wo, cout)
+        dzv = self._new(Ho, Wo, cout)  # pending: z lives in y and stays intact, dz gets this buffer; else z, overwritten in place by dz
+        z = y if pend else dzv
         # bf16: the matrix-core stem kernel accumulates the BatchNorm sums of the values it stores (p 5 / i 23 as the conv ops): no BN_STATS pass
         acc = self._acc(cout) if self.dtype == MSL_BF16 and os.environ.get("MSL_STEM_STATS", "1") == "1" else None
         self._f(hiplib.make_op(hiplib.OP_STEM, self.dtype, p=(x.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), 0, z.t.data_ptr(), 0 if acc is None else acc.data_ptr()),
                                i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 18: 0, 23: 0 if acc is None else ACC_SLOTS}))
-        stats = self._bn_forward(name, z, y, cout, True, None, acc=acc)
+        stats = self._bn_forward(name, z, y, cout, True, None, acc=acc, pending=pend)
         self.taps[name] = y
 
         def bw():
             ops = []
-            self._bn_backward(ops, name, z, y, cout, True, stats, None, lane=lane)
-            ops.append(self._defer(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
-                                                  i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS}), lane))
+            self._bn_backward(ops, name, z, y, cout, True, stats, None, lane=lane, dz=dzv)
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_STEM_WGRAD, self.dtype, p=(x.t.data_ptr(), dzv.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+                                                  i={0: self.N, 1: x.H, 2: x.W, 4: Ho, 5: Wo, 6: cout, 12: dzv.cs, 13: dzv.co, 21: WG_SCRATCH_FLOATS}), lane))
             return ops
 
         self._add_bw(bw)
@@ -544,12 +756,14 @@ class TrainPlan(graph.Visitor):
             d_mode = 1
         wd = self._packed(didx) if d_mode != 2 else None
         self.taps[name] = y
+        pend = bn and name in self.pending
         if bn:
-            z = self._new(Ho, Wo, cout)
+            dzv = self._new(Ho, Wo, cout)  # pending: z lives in y (left intact by the backward pass), dz gets this buffer; else z, overwritten in place by dz
+            z = y if pend else dzv
             # BatchNorm sums in the producing kernel's epilogue where it has one: the 1x1 streaming kernel and the LDS-tiled 3x3 kernel
             acc = self._acc(cout) if (self._conv1x1_stats_ok(x, z, cout, k, s, pad, wm) or wm.get("lds", 0) == 1) else None
             self._f(self._conv_op(x, z, wt, self.zeros.data_ptr(), wm, k, s, pad, stats_acc=acc))
-            stats = self._bn_forward(name, z, y, cout, act, res, acc=acc)
+            stats = self._bn_forward(name, z, y, cout, act, res, acc=acc, pending=pend)
         else:
             z, stats = None, None
             self._f(self._conv_op(x, y, wt, st.ptr(name + ".bias"), wm, k, s, pad, act=1 if act else 0, res=res, out_f32=f32_out))
@@ -558,8 +772,8 @@ class TrainPlan(graph.Visitor):
         def bw():
             ops = []
             if bn:
-                self._bn_backward(ops, name, z, y, cout, act, stats, res, lane=lane)
-                dz, dz_f32 = z, 0
+                self._bn_backward(ops, name, z, y, cout, act, stats, res, lane=lane, dz=dzv)
+                dz, dz_f32 = dzv, 0
             else:  # plain conv + bias: dz = dy (the loss writes it, zeros in the padding channels)
                 gy = self.G(y)
                 gyw = View(gy.t, gy.N, gy.H, gy.W, cpad, gy.cs, gy.co, gy.f32)
@@ -576,7 +790,7 @@ class TrainPlan(graph.Visitor):
                 ops.append(hiplib.make_op(hiplib.OP_ADD_VIEW, self.dtype, p=(dzc.t.data_ptr(), dz.t.data_ptr()),
                                           i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
                 dz, dz_f32 = dzc, 0
-            ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane)), 0, 0, self._xtab(x)),
                                                   i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}), lane))
             gx = self.G(x)
             if self._proto_own_lane and name.endswith(".proto.cv1"):
@@ -656,32 +870,35 @@ class TrainPlan(graph.Visitor):
             # the qkv gradient and everything upstream of C2PSA (found with tests/tools/dev_grad_diag.py at 400 tokens) — a buffer of its own instead.
             out = None
         y = out if out is not None else self._new(x.H, x.W, C)
-        z = self._new(x.H, x.W, C)
+        pend = name in self.pending
+        dzv = self._new(x.H, x.W, C)
+        z = y if pend else dzv
+        assert self._xtab(x) == 0, "the depthwise conv reads activated tensors only (OnLoadScan)"
         gm = {22: gmap[0], 23: gmap[1], 24: gmap[2]} if gmap is not None else {}
         self._f(hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(x.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), 0, z.t.data_ptr()),
                                i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 18: 0, **gm}))
         inplace = res is not None and out is not None and res.t is out.t and res.co == out.co
-        stats = self._bn_forward(name, z, y, C, act, res)
+        stats = self._bn_forward(name, z, y, C, act, res, pending=pend)
         self.taps[name] = y
 
         def bw():
             ops = []
-            self._bn_backward(ops, name, z, y, C, act, stats, res, res_inplace=inplace)
-            ops.append(self._defer(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), z.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
-                                                  i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: z.cs, 13: z.co, 21: WG_SCRATCH_FLOATS, **gm}), lane))
+            self._bn_backward(ops, name, z, y, C, act, stats, res, res_inplace=inplace, dz=dzv)
+            ops.append(self._defer(hiplib.make_op(hiplib.OP_DW_WGRAD, self.dtype, p=(x.t.data_ptr(), dzv.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane))),
+                                                  i={0: self.N, 1: x.H, 2: x.W, 3: C, 10: x.cs, 11: x.co, 12: dzv.cs, 13: dzv.co, 21: WG_SCRATCH_FLOATS, **gm}), lane))
             gx = self.G(x)
             if gmap is None:
                 first = self._init.first_write(gx)
-                i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: z.cs, 11: z.co, 12: gx.cs, 13: gx.co, 18: 0, 20: 1}
+                i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: dzv.cs, 11: dzv.co, 12: gx.cs, 13: gx.co, 18: 0, 20: 1}
                 rp = 0
                 if not first:
                     i[14], i[15], rp = gx.cs, gx.co, gx.t.data_ptr()
             else:  # gradient lands in the mapped (v) channels of the qkv gradient: first writer of those channels
                 chans = torch.tensor([x.co + (c // gmap[0]) * gmap[1] + gmap[2] + c % gmap[0] for c in range(C)])
                 self._init.mark(gx, chans)
-                i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: z.cs, 11: z.co, 12: gx.cs, 13: gx.co, 18: 0, 20: 1, 21: 1, **gm}
+                i = {0: self.N, 1: x.H, 2: x.W, 3: C, 10: dzv.cs, 11: dzv.co, 12: gx.cs, 13: gx.co, 18: 0, 20: 1, 21: 1, **gm}
                 rp = 0
-            ops.append(hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(z.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), rp, gx.t.data_ptr()), i=i))
+            ops.append(hiplib.make_op(hiplib.OP_DWCONV, self.dtype, p=(dzv.t.data_ptr(), st.ptr(name + ".w"), self.zeros.data_ptr(), rp, gx.t.data_ptr()), i=i))
             return ops
 
         self._add_bw(bw)
@@ -777,7 +994,13 @@ class TrainPlan(graph.Visitor):
         self._init.mark(self.G(self.proto_view))
         bwd_segments: List = [[]]
         seen_side = False
-        for build, lane in reversed(self._bw_builders):
+        cut_done = self.bucket_cut is None
+        for build, lane, lname in reversed(self._bw_builders):
+            if not cut_done and int(lname.split(".")[1]) < self.bucket_cut and lane == 0:
+                # first backbone layer in backward order: everything before it (head + neck) becomes a program of its own
+                cut_done = True
+                bwd_segments.append("CUT")
+                bwd_segments.append([])
             built = build()
             if lane != 0:
                 seen_side = True
@@ -800,7 +1023,12 @@ class TrainPlan(graph.Visitor):
 
         self._graphs = os.environ.get("MSL_TRAIN_GRAPH", "0") == "1"
         self.forward_segments = [prog(s) if isinstance(s, list) and s else s for s in self._fwd if not (isinstance(s, list) and not s)]
-        self.backward_segments = [prog(s) if isinstance(s, list) and s else s for s in bwd_segments if not (isinstance(s, list) and not s)]
+        self.backward_segments = []
+        for sgm in bwd_segments:
+            if isinstance(sgm, str):  # "CUT": index of the first segment of the backbone part
+                self.cut_segment = len(self.backward_segments)
+            elif not (isinstance(sgm, list) and not sgm):
+                self.backward_segments.append(prog(sgm) if isinstance(sgm, list) else sgm)
         for dt, ar in self._arena.items():
             idx_d = torch.cat(ar["idx"]).to(self.device)
             self._keep += [idx_d, ar["buf"]]
@@ -830,11 +1058,17 @@ class TrainPlan(graph.Visitor):
         self._fwd_acc[: self._fwd_acc_n].zero_()  # one memset: the accumulators of the layers whose finalize is fused into BN_ACT are not reset by a kernel
         self._run(self.forward_segments)
 
-    def backward(self):
+    def backward(self, on_cut: Optional[Callable[[], None]] = None):
         """Head/proto gradient buffers must have been filled (see `head_grads`); weight gradients ACCUMULATE into store.g,
-        so the caller zeroes store.g once per optimizer step."""
+        so the caller zeroes store.g once per optimizer step.  `on_cut` (plans built with `bucket_cut`): called between the head + neck program and the
+        backbone program, when the first gradient bucket is complete."""
         self._bwd_acc[: self._bwd_acc_n].zero_()  # one memset for every backward reduction accumulator
-        self._run(self.backward_segments)
+        if self.cut_segment is None or on_cut is None:
+            self._run(self.backward_segments)
+            return
+        self._run(self.backward_segments[: self.cut_segment])
+        on_cut()
+        self._run(self.backward_segments[self.cut_segment :])
 
     def time_segments(self, segments, reps: int = 3):
         """HIP-event time of every op of the given segments (callables are timed as one item): [(label, kind, mean ms, op)]."""
