@@ -26,6 +26,12 @@
  *       base + ((n*H + y)*W + x)*cs + co + c        (cs = channel stride of the underlying buffer,
  *                                                    co = channel offset of this view inside it)
  *     so a Concat is just several producers writing different `co` of one buffer.
+ *   - Planar views (training program, bf16; slots named per op below): a concat whose members are narrower than a 128-byte line (C3k2 at the 160² / 80² levels:
+ *     16 or 32 bf16 channels) is stored as cs / pl dense planes of pl channels instead of interleaved pixels: channel c of pixel p of the buffer lives at
+ *       base + ((c / pl) * N*H*W + p) * pl + c % pl
+ *     so that the readers of ONE member see a dense tensor (full lines); only the ops that touch several members take the plane width in an i slot:
+ *     MSL_OP_CONV 1x1 (i 26 = planes of x, i 27 = planes of y and of a residual that is y itself), MSL_OP_CONV_WGRAD 1x1 (i 26 = planes of x),
+ *     MSL_OP_BN_ACT (i 27 = planes of y), MSL_OP_BN_ACT_BWD_REDUCE / _APPLY (i 26 = planes of dy).  0 = the interleaved layout above.
  *   - dtype: MSL_BF16 (bf16 storage, fp32 accumulate on v_mfma_f32_16x16x32_bf16),
  *            MSL_F32  (fp32 storage, exact fp32 on v_mfma_f32_16x16x4_f32 — the parity mode) or
  *            MSL_F32S (fp32 storage, split-precision conv products on the f16 matrix cores — predict only).

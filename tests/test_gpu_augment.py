@@ -61,13 +61,13 @@ def test_device_batch_against_the_independent_oracle(mosaic):
         worst, n_diff, n_tot = max(worst, int(d.max())), n_diff + int((d > 0).sum()), n_tot + d.size
         mine = boxes[bidx == b] * size  # xywh, pixels
         inside = [(c, xy, box) for c, xy, box, keep, crossing in recs if keep and not crossing]
-        crossing_kept = sum(1 for c, xy, box, keep, crossing in recs if keep and crossing)
-        assert len(inside) <= len(mine) <= len(inside) + crossing_kept + 1, (b, len(mine), len(inside), crossing_kept)
+        n_cross = sum(1 for c, xy, box, keep, crossing in recs if crossing)  # cut by the image border: the product's vertex clipping vs upstream's resampling decide `keep`
+        assert len(inside) <= len(mine) <= len(inside) + n_cross, (b, len(mine), len(inside), n_cross)  # differently for slivers (tests/test_oracle_augment.py measures those)
         for c, xy, (x1, y1, x2, y2) in inside:  # every instance the oracle keeps inside the image is in the device batch with the same box
             bo = np.array([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1])
             assert len(mine) and np.abs(mine - bo).max(1).min() <= 3e-3, (b, bo, mine)
             n_boxes += 1
-        if crossing_kept == 0 and inside:  # the overlap-encoded mask under the device batch's own ranking of near-equal areas
+        if len(mine) == len(inside) and inside:  # no border-crossing instance in the batch row: the overlap-encoded mask under the device batch's own ranking of near-equal areas
             order = [int(np.argmin([np.abs(mine[j] - [(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1]).max() for (_, _, (x1, y1, x2, y2)) in inside])) for j in range(len(mine))]
             if sorted(order) == list(range(len(inside))):
                 om, _, _ = OA.overlap_masks(inside, size, order=order)

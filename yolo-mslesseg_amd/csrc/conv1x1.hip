@@ -35,6 +35,9 @@ struct C1Args {
   const float* bn_tab;  // input BatchNorm table of the x BUFFER (msl_common.h: f32 [x_cs][2] (scale, shift), then u8 [x_cs / 8] group flags) or NULL: the wave applies
                         // x <- act(x * scale + shift) to the flagged 8-channel groups of the slice it staged, in LDS, before multiplying — the producer's BN_ACT pass
                         // (z -> a) folded into this consumer
+  int x_pl, y_pl;  // PLANAR concat views (round 4; include/mslesseg_hip.h "planar views"): channels per plane of the x / y (and residual) buffer, 0 = interleaved.
+                   // Channel ca of pixel p of a planar buffer lives at element (ca / pl) * M * pl + p * pl + ca % pl — every member of a C3k2 concat is a
+                   // dense plane of its own (its other readers see full lines) and this kernel picks K-chunks / stores channel groups plane by plane
   int shuffle, H, W;  // shuffle = 1: pixel-shuffle store of a ConvTranspose2d k2 s2 run as a 1x1 GEMM — channel q*C + c (C = Cout/4, q = dy*2 + dx) of
                       // pixel (y, x) goes to channel c of pixel (2y + dy, 2x + dx) of the 2H x 2W output (same contract as conv_igemm's store mode 1)
 };
@@ -96,6 +99,10 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
   for (int k = 0; k < MAXP; ++k) {
     const int cidx = k * 64 + lane, px = cidx / cps, ch = cidx - px * cps;
     xo[k] = (cidx < slice_chunks && ch < xchunks) ? (unsigned)((px * a.x_cs + ch * EPC) * ES) : OOB;
+    if (a.x_pl && xo[k] != OOB) {  // planar: (plane of the chunk's first channel) * M * pl + px * pl + channel inside the plane; the slice origin p0 * pl goes into the descriptor base
+      const int ca = a.x_co + ch * EPC, pln = ca / a.x_pl;
+      xo[k] = (unsigned)((((long)pln * a.M + px) * a.x_pl + (ca - pln * a.x_pl)) * ES);
+    }
   }
   const unsigned lds_ring = msl_lds_addr(s_x);
 
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
     unsigned char* dst = s_x + buf * slice_bytes;
     const long p0 = tile * SP;
     if (npieces <= MAXP && p0 + SP <= a.M) {  // wave-uniform: a full slice (all but the tensor's last one)
-      const c1_i32x4 rx = c1_rsrc(a.x + (p0 * a.x_cs + a.x_co) * ES);
+      const c1_i32x4 rx = c1_rsrc(a.x_pl ? a.x + p0 * a.x_pl * ES : a.x + (p0 * a.x_cs + a.x_co) * ES);
       const unsigned l0 = lds_ring + buf * slice_bytes;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
@@ -116,6 +123,10 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
       const int cidx = c0 + lane, px = cidx / cps, ch = cidx - px * cps;
       const bool ok = cidx < slice_chunks && ch < xchunks && p0 + px < a.M;
       const char* src = ok ? a.x + ((p0 + px) * a.x_cs + a.x_co + ch * EPC) * ES : (const char*)c1_zero_page;
+      if (ok && a.x_pl) {
+        const int ca = a.x_co + ch * EPC, pln = ca / a.x_pl;
+        src = a.x + (((long)pln * a.M + p0 + px) * a.x_pl + (ca - pln * a.x_pl)) * ES;
+      }
       msl_glds16(src, msl_lds_addr(dst + c0 * 16));  // asm form: the builtin makes hipcc wait vmcnt(0) before LDS reads it cannot prove disjoint (msl_common.h)
     }
   };
@@ -175,8 +186,10 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
                                       // condition is branched around and waited for with vmcnt(0) one by one
 #pragma unroll
           for (int c = 0; c < NCP; ++c) {
-            const int c0 = c * 32 + 8 * g;
-            rpre[pt][c] = *(const uint4*)((const unsigned short*)a.res + p * a.res_cs + a.res_co + (c0 < a.Cout ? c0 : 0));
+            const int c0 = c * 32 + 8 * g, cr = c0 < a.Cout ? c0 : 0;
+            long ri = p * a.res_cs + a.res_co + cr;
+            if (a.y_pl) { const int ca = a.res_co + cr, pln = ca / a.y_pl; ri = ((long)pln * a.M + p) * a.y_pl + (ca - pln * a.y_pl); }  // the residual is the output view's own content (an accumulating input gradient)
+            rpre[pt][c] = *(const uint4*)((const unsigned short*)a.res + ri);
           }
         }
       }
@@ -294,6 +307,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
           for (int r = 0; r < 8; ++r) v[r] += rv[r];
         }
         long oi = p * a.y_cs + a.y_co + c0;
+        if (a.y_pl) { const int ca = a.y_co + c0, pln = ca / a.y_pl; oi = ((long)pln * a.M + p) * a.y_pl + (ca - pln * a.y_pl); }
         if (a.shuffle) {  // an 8-channel run never straddles a quadrant (Cout/4 is a multiple of 8)
           const int C4 = a.Cout >> 2, q = c0 / C4;
           const long n = p / ((long)a.H * a.W);
@@ -746,6 +760,13 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
   a.oscale = op.dtype == MSL_F32S ? op.f[0] : 1.0f;
   MSL_REQUIRE(!op.p[8] || (op.dtype == MSL_BF16 && a.x_co % 8 == 0 && a.Cin % 8 == 0 && a.x_cs % 8 == 0), "conv1x1: the input BatchNorm table (p[8]) is a bf16 form over whole 8-channel groups");
   a.bn_tab = (const float*)op.p[8];  // p 8 (bf16, optional): input BatchNorm table of the x buffer (msl_common.h)
+  a.x_pl = op.i[26]; a.y_pl = op.i[27];
+  if (a.x_pl || a.y_pl) {
+    MSL_REQUIRE(op.dtype == MSL_BF16 && !a.shuffle && !a.bn_tab && !a.out_f32, "conv1x1: planar views are a form of the plain bf16 1x1 conv");
+    MSL_REQUIRE(!a.x_pl || (a.x_pl % 8 == 0 && a.x_cs % a.x_pl == 0 && (long)(a.x_cs / a.x_pl) * a.M * a.x_pl * 2 < (1L << 31)), "conv1x1: bad planar input view (planes of %d channels)", a.x_pl);
+    MSL_REQUIRE(!a.y_pl || (a.y_pl % 8 == 0 && a.y_cs % a.y_pl == 0 && (!a.res || (a.res == (const char*)a.y && a.res_cs == a.y_cs && a.res_co == a.y_co))),
+                "conv1x1: bad planar output view (planes of %d channels; a residual must be the output view itself)", a.y_pl);
+  }
   if (op.dtype == MSL_F32S) {
     MSL_REQUIRE(op.f[0] > 0.f && !a.acc, "conv1x1 (MSL_F32S): f[0] must hold the output scale of the pre-split weights; no statistics epilogue");
 #define C1S(N) case N: return c1_launch_f32<N, true>(a, s)

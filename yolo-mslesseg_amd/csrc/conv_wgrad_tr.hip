@@ -31,6 +31,7 @@ struct WgTrArgs {
   int tiles_x, tiles_y, tiles_per_block;
   long total_tiles, M;
   float* scratch;  // [gridDim.x][Cout][K] per-workgroup partial sums (NULL: flush with atomics)
+  int x_pl;             // planar x view (1x1 only): channels per plane, 0 = interleaved — channel ca of pixel p at element (ca / pl) * M * pl + p * pl + ca % pl
   const float* bn_tab;  // input BatchNorm table of the x buffer (msl_common.h) or NULL: x holds the producer's raw conv output z and the activated tensor this
                         // weight gradient contracts with is act(z * scale + shift) — every wave rewrites the x pieces it staged once they have landed, before the
                         // barrier that publishes the tile (units staged as zeros — padding, image edges, missing channels — stay zero)
@@ -151,6 +152,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
       if constexpr (S == 2) c = c < C::HALF ? 2 * c : 2 * (c - C::HALF) + 1;  // parity-split image → halo column
     }
     xoff[k] = ok ? (unsigned)(((r * a.W + c) * a.x_cs + ch * 8) * 2) : OOB;
+    if (TAPS == 1 && a.x_pl && ok) {  // planar: the tile's first pixel goes into the descriptor base (x pl), the plane and the channel inside it are lane constants
+      const int ca = a.x_co + cib * 64 + ch * 8, pn = ca / a.x_pl;
+      xoff[k] = (unsigned)((((long)pn * a.M + slot) * a.x_pl + (ca - pn * a.x_pl)) * 2);
+    }
     xrc[k] = ((unsigned)r << 16) | (unsigned)c;
   }
   constexpr int XCOLS = S == 1 ? ROWP : 2 * C::HALF;  // halo columns staged
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tr_kernel(WgTrArgs a) {
     const int zr_lim = gm.zr_lim, zc_lim = gm.zc_lim;
     const bool z_in = gm.z_in;
     const wg_i32x4 rz = wg_rsrc(a.dz + (zpix * a.z_cs + a.z_co + cob * 64) * 2);
-    const wg_i32x4 rx = wg_rsrc(a.x + (xpix * a.x_cs + a.x_co + cib * 64) * 2);
+    const wg_i32x4 rx = wg_rsrc((TAPS == 1 && a.x_pl) ? a.x + xpix * a.x_pl * 2 : a.x + (xpix * a.x_cs + a.x_co + cib * 64) * 2);
     const unsigned lz = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)s_z, lx = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)s_x;
 #pragma unroll
     for (int k = 0; k < ZK; ++k) {
@@ -557,6 +562,9 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
   const long gx = (a.total_tiles + tpb - 1) / tpb;
   a.scratch = (float*)op.p[5];
   a.bn_tab = (const float*)op.p[8];  // p 8 (optional): input BatchNorm table of the x buffer (msl_common.h)
+  a.x_pl = op.i[26];                  // i 26 (optional, 1x1): planar x view, channels per plane
+  MSL_REQUIRE(!a.x_pl || (k == 1 && !a.bn_tab && a.x_pl % 8 == 0 && a.x_cs % a.x_pl == 0 && (long)(a.x_cs / a.x_pl) * a.M * a.x_pl * 2 < (1L << 31)),
+              "conv_wgrad_tr: a planar x view (i 26) is a form of the 1x1 weight gradient");
 #ifdef WG_STAMPS
   a.dbg = wg_dbg_ptr;
 #endif

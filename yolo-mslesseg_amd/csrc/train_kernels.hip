@@ -47,11 +47,13 @@ static inline bool aligned16(const void* a, const void* b, const void* c) { retu
 template <bool F32, int MODE, int V>  // MODE 0: (sum z, sum z^2)   MODE 1: BN+act backward sums (sum g, sum g*zhat)   MODE 2: column sum
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ acc,
-                                                          long M, int C, int a_cs, int a_co, int b_cs, int b_co, int act, int a_f32, int slots) {
+                                                          long M, int C, int a_cs, int a_co, int b_cs, int b_co, int act, int a_f32, int slots, int a_pl) {
   __shared__ float red[2][256][V];
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
   const int c = cq * V;
+  // a planar `a` view (a_pl channels per plane: a C3k2 concat's gradient): pixel stride = the plane width, the thread's channel group sits in plane (a_co + c) / a_pl
+  if (a_pl) { const int ca = a_co + c, pn = ca / a_pl; a_co = (int)0; a_cs = a_pl; a = (const char*)a + ((long)pn * M * a_pl + (ca - pn * a_pl) - c) * (F32 ? 4 : 2); }
   float s1[V], s2[V], mu[V], is[V], ga[V], be[V];
 #pragma unroll
   for (int r = 0; r < V; ++r) { s1[r] = 0.f; s2[r] = 0.f; mu[r] = 0.f; is[r] = 1.f; ga[r] = 1.f; be[r] = 0.f; }
@@ -174,7 +176,7 @@ int msl_launch_bn_stats(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "bn_stats: too many accumulator slots");
   const bool v8 = vec8(C, cs, co);
   dim3 grid(reduce_grid(M, C, slots, v8 ? 8 : 4));
-#define BS(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 0, V>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots)
+#define BS(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 0, V>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[1], M, C, cs, co, 0, 0, 0, 0, slots, 0)
   if (op.dtype == MSL_F32) { if (v8) BS(true, 8); else BS(true, 4); } else { if (v8) BS(false, 8); else BS(false, 4); }
 #undef BS
   MSL_CHECK_LAUNCH("bn_stats");
@@ -233,7 +235,8 @@ template <bool F32, int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const void* __restrict__ res, void* __restrict__ y, long M, int C,
                                                      int z_cs, int z_co, int y_cs, int y_co, int r_cs, int r_co, int act, int PPT, BnFin fin, bool cvec,
-                                                     const float* __restrict__ rtab) {  // rtab: input BatchNorm table of the RESIDUAL's buffer (msl_common.h) or NULL
+                                                     const float* __restrict__ rtab,  // rtab: input BatchNorm table of the RESIDUAL's buffer (msl_common.h) or NULL
+                                                     int y_pl) {                      // planar output view: channels per plane (0 = interleaved)
   __shared__ __attribute__((aligned(16))) float ks[2048];
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ z,
     __syncthreads();
   }
   if (pl >= PL) return;
+  if (y_pl) { const int ca = y_co + c, pn = ca / y_pl; y = (char*)y + ((long)pn * M * y_pl + (ca - pn * y_pl) - c) * (F32 ? 4 : 2); y_cs = y_pl; y_co = 0; }  // (as chan_reduce_kernel's planar `a`)
   float mu[V], is[V], ga[V], be[V];
   if (fin.acc) ld_bn_consts<V>(ks, gamma, beta, c, cvec, mu, is, ga, be);  // ks (LDS) is 16-byte aligned
   else ld_bn_consts<V>(stats, gamma, beta, c, cvec, mu, is, ga, be);
@@ -343,7 +347,8 @@ int msl_launch_bn_act(const msl_op& op, hipStream_t s) {
     fin.acc = (const double*)op.p[6]; fin.stats_out = (float*)op.p[1]; fin.rmean = (float*)op.p[7]; fin.rvar = op.p[7] ? (float*)op.p[7] + op.i[16] : nullptr;
     fin.M = (double)M; fin.eps = op.f[0]; fin.mom = op.f[1]; fin.slots = slots_of(op, 21);
   }
-#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin, cvec, (const float*)op.p[8])
+#define BA(F, V) hipLaunchKernelGGL((bn_act_kernel<F, V>), grid, dim3(256), 0, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[5], op.p[3], op.p[4], M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], PPT, fin, cvec, (const float*)op.p[8], op.i[27])
+  MSL_REQUIRE(!op.i[27] || (op.i[27] % 8 == 0 && op.i[12] % op.i[27] == 0 && op.i[13] % 8 == 0 && C % 8 == 0), "bn_act: bad planar output view (i 27 = channels per plane)");
   MSL_REQUIRE(!op.p[8] || (op.p[3] && op.i[14] % 8 == 0 && op.i[15] % 4 == 0), "bn_act: the residual's input BatchNorm table (p 8) needs a residual view inside whole 8-channel groups");
   if (op.dtype == MSL_F32) { if (v8) BA(true, 8); else BA(true, 4); } else { if (v8) BA(false, 8); else BA(false, 4); }
 #undef BA
@@ -360,7 +365,8 @@ int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "bn_act_bwd_reduce: too many accumulator slots");
   const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13]);
   dim3 grid(reduce_grid(M, C, slots, v8 ? 8 : 4));
-#define BR(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 1, V>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0, slots)
+#define BR(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 1, V>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], M, C, op.i[12], op.i[13], op.i[10], op.i[11], op.i[18], 0, slots, op.i[26])
+  MSL_REQUIRE(!op.i[26] || (op.i[26] % 8 == 0 && op.i[12] % op.i[26] == 0 && op.i[13] % 8 == 0 && C % 8 == 0), "bn_act_bwd_reduce: bad planar dy view (i 26 = channels per plane)");
   if (op.dtype == MSL_F32) { if (v8) BR(true, 8); else BR(true, 4); } else { if (v8) BR(false, 8); else BR(false, 4); }
 #undef BR
   MSL_CHECK_LAUNCH("bn_act_bwd_reduce");
@@ -375,11 +381,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ acc, void* __restrict__ dz, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long M, int C, int z_cs, int z_co, int dy_cs, int dy_co,
-                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first, int pacc, bool cvec) {
+                                                               int dz_cs, int dz_co, int act, int slots, int PPT, void* gres, int gr_cs, int gr_co, int gr_first, int pacc, bool cvec,
+                                                               int dy_pl) {  // planar dy view: channels per plane (0 = interleaved)
   __shared__ float ks[2048];  // (s1, s2) per channel, summed over the accumulator slots
   const int CV = C / V;
   const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
   const int c = cq * V;
+  if (dy_pl) { const int ca = dy_co + c, pn = ca / dy_pl; dy = (const char*)dy + ((long)pn * M * dy_pl + (ca - pn * dy_pl) - c) * (F32 ? 4 : 2); dy_cs = dy_pl; dy_co = 0; }
   for (int v = threadIdx.x; v < 2 * C; v += 256) {
     double a = 0.0;
     for (int j = 0; j < slots; ++j) a += acc[(long)j * 2 * C + v];
@@ -488,7 +496,8 @@ int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   float* dgamma = (float*)op.p[7];
   float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
   const bool cvec = aligned16(op.p[2], op.p[3], beta);
-#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17], cvec); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17], cvec); } while (0)
+#define BB(F, V) do { if (gres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, true>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17], cvec, op.i[26]); else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<F, V, false>), grid, dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], beta, (const double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, PPT, gres, op.i[24], op.i[25], op.i[19], op.i[17], cvec, op.i[26]); } while (0)
+  MSL_REQUIRE(!op.i[26] || (op.i[26] % 8 == 0 && op.i[12] % op.i[26] == 0 && op.i[13] % 8 == 0 && C % 8 == 0), "bn_act_bwd_apply: bad planar dy view (i 26 = channels per plane)");
   if (op.dtype == MSL_F32) { if (v8) BB(true, 8); else BB(true, 4); } else { if (v8) BB(false, 8); else BB(false, 4); }
 #undef BB
   MSL_CHECK_LAUNCH("bn_act_bwd_apply");
@@ -673,7 +682,7 @@ int msl_launch_colsum(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(slots <= MSL_MAX_SLOTS, "colsum: too many accumulator slots");
   const bool v8 = !op.i[19] && vec8(C, op.i[10], op.i[11]);  // compute-dtype input, 8-aligned view: 16-byte loads
   dim3 grid(reduce_grid(M, C, slots, v8 ? 8 : 4, 1024));
-#define CS(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 2, V>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots)
+#define CS(F, V) hipLaunchKernelGGL((chan_reduce_kernel<F, 2, V>), grid, dim3(256), 0, s, op.p[0], nullptr, nullptr, nullptr, nullptr, (double*)op.p[4], M, C, op.i[10], op.i[11], 0, 0, 0, op.i[19], slots, 0)
   if (op.dtype == MSL_F32) { if (v8) CS(true, 8); else CS(true, 4); } else { if (v8) CS(false, 8); else CS(false, 4); }
 #undef CS
   MSL_CHECK_LAUNCH("colsum");
@@ -864,6 +873,77 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const void* __restri
   __syncthreads();
   for (int p = threadIdx.x; p < HW; p += 256) *(float4*)(scratch + ((long)n * HW + p) * C + c) = gsum[p];
 }
+
+// The same routing with 16 channels (four quads) of a slice per workgroup (round 4).  The form above gives a workgroup 4 channels: every thread's 8-byte
+// access sits in its own pixel (pixel stride = the concat buffer's 4 * C channels), so each 64-byte sector is fetched for 8 bytes by 8 workgroups — 0.165 ms
+// for the 52 MB of the batch-128 SPPF, on the backward pass's main chain.  Here a work item is (pixel, quad): four neighbouring threads cover 32 contiguous
+// bytes of a pixel; the three windows run one after the other through ONE row-maximum plane (the LDS then holds 16 channels: 224 bytes per pixel).  Same
+// arg-max rule (leftmost maximum of the row window, then the topmost row), same sums up to the order of the fp32 LDS atomics.
+template <bool F32>
+__global__ __launch_bounds__(256) void sppf_pool_bwd16_kernel(const void* __restrict__ ybuf, const void* __restrict__ gbuf, float* __restrict__ scratch,
+                                                              int N, int H, int W, int C, int cs, int co, int g_cs, int g_co) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_[];
+  const int HW = H * W, items = HW * 4;
+  float4* val = (float4*)sm_;                          // [HW][4 quads]
+  float4* rmax = val + items;                          // [HW][4]: row-pass maxima of the current window
+  float4* gsum = rmax + items;                         // [HW][4]: routed gradient
+  unsigned short* rarg = (unsigned short*)(gsum + items);  // [HW][4][4]: row-pass arg x of the current window
+  const int n = blockIdx.x / (C >> 4), c0 = (blockIdx.x % (C >> 4)) * 16;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int p = it >> 2, q = it & 3;
+    float v[4];
+    ld4<F32>(ybuf, ((long)n * HW + p) * cs + co + c0 + 4 * q, v);
+    val[it] = make_float4(v[0], v[1], v[2], v[3]);
+    gsum[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    const int rad = 2 * (k + 1);
+    for (int it = threadIdx.x; it < items; it += 256) {  // row pass
+      const int p = it >> 2, q = it & 3, y = p / W, x = p - y * W;
+      float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+      int arg[4] = {x, x, x, x};
+      for (int dx = -rad; dx <= rad; ++dx) {
+        const int xx = x + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const float4 f = val[(y * W + xx) * 4 + q];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (v[r] > best[r]) { best[r] = v[r]; arg[r] = xx; }
+      }
+      rmax[it] = make_float4(best[0], best[1], best[2], best[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rarg[it * 4 + r] = (unsigned short)arg[r];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < items; it += 256) {  // column pass + routing
+      const int p = it >> 2, q = it & 3, y = p / W, x = p - y * W;
+      float g[4];
+      ld4<F32>(gbuf, ((long)n * HW + p) * g_cs + g_co + (k + 1) * C + c0 + 4 * q, g);
+      float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+      int ay[4] = {y, y, y, y};
+      for (int dy = -rad; dy <= rad; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        const float4 f = rmax[(yy * W + x) * 4 + q];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (v[r] > best[r]) { best[r] = v[r]; ay[r] = yy; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (g[r] != 0.f) {
+          const int ax = rarg[((ay[r] * W + x) * 4 + q) * 4 + r];
+          atomicAdd((float*)(gsum + (ay[r] * W + ax) * 4 + q) + r, g[r]);
+        }
+      }
+    }
+    __syncthreads();  // the next window overwrites rmax / rarg
+  }
+  for (int it = threadIdx.x; it < items; it += 256) *(float4*)(scratch + ((long)n * HW + (it >> 2)) * C + c0 + 4 * (it & 3)) = gsum[it];
+}
 // p 0 y buffer (forward concat buffer), 1 grad buffer, 4 scratch f32 [N,H,W,C] (fully written) ; i 0 N,1 H,2 W,3 C,10 cs,11 co,12 g_cs,13 g_co
 int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s) {
   const int N = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
@@ -876,6 +956,22 @@ int msl_launch_sppf_pool_bwd(const msl_op& op, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
+  }
+  // 16 channels per workgroup: i 23 = -2 asks for it (tests, A/B).  Measured at batch 128 (20² x 128, profiles/r04h_op_table_train.txt): 0.260 ms against 0.165 ms for
+  // the 4-channel form — a quarter of the sector waste, but one 90-KiB workgroup per CU walking three windows between barriers: NOT the default.
+  const size_t lds16 = (size_t)H * W * 4 * (16 * 3 + 8);
+  if (C % 16 == 0 && lds16 <= 150 * 1024 && op.i[23] == -2) {
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute((const void*)sppf_pool_bwd16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute((const void*)sppf_pool_bwd16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr16 = true;
+    }
+    dim3 grid16((unsigned)(N * (C / 16)));
+    if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_bwd16_kernel<true>, grid16, dim3(256), lds16, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+    else hipLaunchKernelGGL(sppf_pool_bwd16_kernel<false>, grid16, dim3(256), lds16, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
+    MSL_CHECK_LAUNCH("sppf_pool_bwd16");
+    return MSL_OK;
   }
   dim3 grid((unsigned)(N * (C / 4)));
   if (op.dtype == MSL_F32) hipLaunchKernelGGL(sppf_pool_bwd_kernel<true>, grid, dim3(256), lds, s, op.p[0], op.p[1], (float*)op.p[4], N, H, W, C, op.i[10], op.i[11], op.i[12], op.i[13]);
@@ -975,6 +1071,7 @@ int msl_launch_conv_wgrad(const msl_op& op, hipStream_t s) {
                     op.i[13] + (op.i[6] + 7) / 8 * 8 <= op.i[12];  // a narrow dz view is read in whole 8-channel chunks: they must lie inside the pixel stride
     if (op.dtype == MSL_BF16 && !op.i[19] && geom && al && op.i[20] == 0) return msl_launch_conv_wgrad_tr(op, s);
   }
+  MSL_REQUIRE(!op.i[26] && !op.p[8], "conv_wgrad: planar views (i 26) and input BatchNorm tables (p 8) exist in the bf16 transposed-read kernel only");
   WgradArgs a;
   a.x = (const char*)op.p[0]; a.dz = (const char*)op.p[1]; a.dw = (float*)op.p[4];
   a.N = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6]; a.k = op.i[7]; a.stride = op.i[8]; a.pad = op.i[9];

@@ -57,13 +57,18 @@ def split_f16_units(w: torch.Tensor):
 class View:
     """A channel slice of an NHWC activation buffer."""
 
-    __slots__ = ("t", "N", "H", "W", "C", "cs", "co", "f32")
+    __slots__ = ("t", "N", "H", "W", "C", "cs", "co", "f32", "pl")
 
-    def __init__(self, t, N, H, W, C, cs, co, f32=False):
-        self.t, self.N, self.H, self.W, self.C, self.cs, self.co, self.f32 = t, N, H, W, C, cs, co, f32
+    def __init__(self, t, N, H, W, C, cs, co, f32=False, pl=0):
+        """`pl` > 0: a PLANAR buffer (training program, C3k2 concats of narrow members): the cs channels are stored as cs / pl dense planes of pl channels —
+        channel c of pixel p at element (c // pl) * N*H*W * pl + p * pl + c % pl (include/mslesseg_hip.h "planar views")."""
+        self.t, self.N, self.H, self.W, self.C, self.cs, self.co, self.f32, self.pl = t, N, H, W, C, cs, co, f32, pl
 
     def torch(self) -> torch.Tensor:
-        """[N,H,W,C] strided torch view (for tests)."""
+        """[N,H,W,C] strided torch view (for tests); a planar view is gathered into a new tensor."""
+        if self.pl:
+            full = self.t.view(self.cs // self.pl, self.N, self.H, self.W, self.pl).permute(1, 2, 3, 0, 4).reshape(self.N, self.H, self.W, self.cs)
+            return full[..., self.co : self.co + self.C]
         return self.t.view(self.N, self.H, self.W, self.cs)[..., self.co : self.co + self.C]
 
 
@@ -296,7 +301,7 @@ class ProgramBuilder(graph.Visitor):
         self.taps[name] = y
         return y
 
-    def cat_buffer(self, like, C, scale=1.0):
+    def cat_buffer(self, like, C, scale=1.0, member=0):
         return self._new(like.H, like.W, C)
 
     def view(self, buf, c0, c):

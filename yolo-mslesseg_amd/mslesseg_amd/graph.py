@@ -46,7 +46,7 @@ class Visitor:
     def conv(self, name, x, cout, k=1, s=1, act=True, bn=True, out=None, res=None, f32_out=False): ...
     def dwconv(self, name, x, act=True, res=None, gmap=None, out=None): ...
     def convT2x2(self, name, x, cout): ...
-    def cat_buffer(self, like, C, scale=1.0): ...
+    def cat_buffer(self, like, C, scale=1.0, member=0): ...  # member: width of the equal-width members (C3k2), a hint for planar layouts
     def view(self, buf, c0, c): ...
     def upsample2x(self, x, out): ...
     def copy(self, src, dst): ...
@@ -74,7 +74,7 @@ def _c3k(v, name, x, c2, n=2, out=None):
 
 def _c3k2(v, name, x, c2, n, c3k, e=0.5, out=None):
     c = int(c2 * e)
-    cat = v.cat_buffer(x, (2 + n) * c)
+    cat = v.cat_buffer(x, (2 + n) * c, member=c)  # [cv1 lower half | cv1 upper half | m.0 | ...]: members of equal width c
     v.conv(f"{name}.cv1", x, 2 * c, 1, 1, out=v.view(cat, 0, 2 * c))
     for j in range(n):
         src = v.view(cat, (1 + j) * c, c)

@@ -52,7 +52,7 @@ class SpecVisitor(graph.Visitor):
         self.specs[name] = dict(kind="convT", cin=x.C, cout=cout, k=2, s=2)
         return _H(cout)
 
-    def cat_buffer(self, like, C, scale=1.0):
+    def cat_buffer(self, like, C, scale=1.0, member=0):
         return _H(C)
 
     def view(self, buf, c0, c):

@@ -232,11 +232,17 @@ class _Init:
 
     def __init__(self):
         self.done: Dict[int, torch.Tensor] = {}
+        self.alias: Dict[int, Tuple[int, int, int]] = {}  # id(plane tensor of a planar gradient buffer) -> (id(whole buffer), first channel, channels of the buffer)
+
+    def _mask(self, v: View):
+        """(channel mask of v's buffer, v's first channel in it): a dense plane of a planar buffer is booked in the buffer's own mask."""
+        key, c0, cs = self.alias.get(id(v.t), (id(v.t), 0, v.cs))
+        return self.done.setdefault(key, torch.zeros(cs, dtype=torch.bool)), c0 + v.co
 
     def first_write(self, v: View) -> bool:
         """True ⇒ this write must OVERWRITE (nothing there yet); marks the range initialised."""
-        m = self.done.setdefault(id(v.t), torch.zeros(v.cs, dtype=torch.bool))
-        seg = m[v.co : v.co + v.C]
+        m, co = self._mask(v)
+        seg = m[co : co + v.C]
         if seg.all():
             return False
         assert not seg.any(), "partially initialised gradient range: backward order broken"
@@ -244,15 +250,16 @@ class _Init:
         return True
 
     def mark(self, v: View, chans=None):
-        m = self.done.setdefault(id(v.t), torch.zeros(v.cs, dtype=torch.bool))
+        m, co = self._mask(v)
         if chans is None:
-            m[v.co : v.co + v.C] = True
+            m[co : co + v.C] = True
         else:
+            assert id(v.t) not in self.alias
             m[chans] = True
 
     def is_done(self, v: View) -> bool:
-        m = self.done.get(id(v.t))
-        return m is not None and bool(m[v.co : v.co + v.C].all())
+        m, co = self._mask(v)
+        return bool(m[co : co + v.C].all())
 
 
 class _SV:
@@ -342,7 +349,7 @@ class OnLoadScan(graph.Visitor):
         self.prod.append(dict(name=name, v=y, bn=False, res=False))
         return y
 
-    def cat_buffer(self, like, C, scale=1.0):
+    def cat_buffer(self, like, C, scale=1.0, member=0):
         return self._new(like.H, like.W, C)
 
     def view(self, buf, c0, c):
@@ -436,6 +443,8 @@ class TrainPlan(graph.Visitor):
         # BatchNorm on load (bf16): the layers whose activated tensor is never written (OnLoadScan); MSL_BN_ONLOAD=0 switches the form off, MSL_BN_ONLOAD_MAX_READS bounds
         # the reader passes a pending tensor may have
         self.pending: "set[str]" = set()
+        self._planes: Dict[int, list] = {}  # id(planar buffer tensor) -> its dense plane sub-tensors (one object each: buffers are identified by tensor id)
+        self.pending_on = dtype == MSL_BF16 and os.environ.get("MSL_BN_ONLOAD", "0") == "1"  # (BatchNorm tables are per interleaved buffer: no planar concats beside them)
         self._tabs: Dict[int, torch.Tensor] = {}   # id(buffer tensor) -> input BatchNorm table (f32 [cs][2] | u8 [cs / 8] flags)
         self._tab_flags: Dict[int, torch.Tensor] = {}  # host copy of the flags
         # Measured (round 4; scripts/dev_bn_on_load_ab.py → profiles/r04c_onload_ab.txt): with the activation's two quarter-rate transcendentals
@@ -463,7 +472,7 @@ class TrainPlan(graph.Visitor):
         if g is None:
             g = torch.empty_like(v.t)
             self.grads[id(v.t)] = g
-        return View(g, v.N, v.H, v.W, v.C, v.cs, v.co, v.f32)
+        return View(g, v.N, v.H, v.W, v.C, v.cs, v.co, v.f32, v.pl)
 
     def _f(self, op):
         op._lane = self._lane
@@ -588,10 +597,11 @@ class TrainPlan(graph.Visitor):
         cout = y.C if cout is None else cout
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: (y.H // 2 if store_mode else y.H), 5: (y.W // 2 if store_mode else y.W), 6: cout, 7: k, 8: s, 9: pad,
              10: x.cs, 11: x.co, 12: y.cs, 13: y.co, 16: m["K"], 17: m["Kpad"], 18: act, 19: 1 if out_f32 else 0, 20: store_mode, 21: m["Cout_pad"],
-             22: dgrad, 24: m.get("cot", 0), 25: m.get("lds", 0)}
+             22: dgrad, 24: m.get("cot", 0), 25: m.get("lds", 0), 26: x.pl, 27: y.pl}
         rp = 0
         if res is not None:
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
+            assert res.pl == y.pl and (not y.pl or res.t is y.t)
         if stats_acc is not None:  # BatchNorm sums in the conv epilogue (1x1 streaming kernel only)
             i[23] = ACC_SLOTS
         xt = 0 if dgrad or store_mode else self._xtab(x)  # forward convs only: a gradient view never holds a pending BatchNorm
@@ -621,7 +631,8 @@ class TrainPlan(graph.Visitor):
         if not fuse:
             self._f(hiplib.make_op(hiplib.OP_BN_FINALIZE, self.dtype, p=(acc.data_ptr(), stats.data_ptr(), st.bptr(name + ".mean"), st.bptr(name + ".var")),
                                    i={**dims, 21: ACC_SLOTS}, f=(BN_EPS, BN_MOM)))
-        i = {**dims, 10: z.cs, 11: z.co, 12: y.cs, 13: y.co, 18: 1 if act else 0}
+        i = {**dims, 10: z.cs, 11: z.co, 12: y.cs, 13: y.co, 18: 1 if act else 0, 27: y.pl}
+        assert not z.pl and (res is None or not res.pl)
         rp = 0
         if res is not None:
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
@@ -639,8 +650,10 @@ class TrainPlan(graph.Visitor):
         st = self.store
         gy = self.G(y)
         dz = z if dz is None else dz
+        fuse_max_off = int(os.environ.get("MSL_BN_BWD_FUSE_MAX", "0")) <= 0
         acc = self._acc_bwd(C, ACC_SLOTS)
-        dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS}
+        dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS, 26: gy.pl}
+        assert not z.pl and not dz.pl and (not gy.pl or fuse_max_off)
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
         # MSL_BN_BWD_FUSE_MAX=<elements> (measurement switch, default off): reduction + apply of small main-lane layers as ONE launch with a grid barrier
         # (MSL_OP_BN_ACT_BWD_FUSED; at most one such kernel may be in flight, hence lane 0 only; no residual fan-out in that form)
@@ -791,7 +804,7 @@ class TrainPlan(graph.Visitor):
                                           i={0: self.N, 1: Ho, 2: Wo, 3: dz.C, 10: dzc.cs, 11: dzc.co, 12: dz.cs, 13: dz.co, 19: 1, 20: 1}))
                 dz, dz_f32 = dzc, 0
             ops.append(self._defer(hiplib.make_op(hiplib.OP_CONV_WGRAD, self.dtype, p=(x.t.data_ptr(), dz.t.data_ptr(), 0, 0, st.ptr(name + ".w", st.g), self._scratch(self._wgrad_lane(lane)), 0, 0, self._xtab(x)),
-                                                  i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS}), lane))
+                                                  i={0: self.N, 1: x.H, 2: x.W, 3: cin, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: dz.cs, 13: dz.co, 19: dz_f32, 21: WG_SCRATCH_FLOATS, 26: x.pl}), lane))
             gx = self.G(x)
             if self._proto_own_lane and name.endswith(".proto.cv1"):
                 priv = torch.empty_like(x.t)
@@ -904,10 +917,34 @@ class TrainPlan(graph.Visitor):
         self._add_bw(bw)
         return y
 
-    def cat_buffer(self, like, C, scale=1.0):
+    def cat_buffer(self, like, C, scale=1.0, member=0):
+        """`member`: the concat's members all have this width (C3k2: [cv1 lower | cv1 upper | bottleneck outputs]).  Members narrower than a 128-byte line make every
+        reader of ONE member fetch whole lines for a fraction of them (160² x 16 channels of 64: BN passes at 1.8-2.5 TB/s, the 3x3 input gradient 1.8 x its
+        algorithmic traffic — round-3 verdict, item 3): such a concat is stored PLANAR — every member a dense plane (View.pl) — and only the 1x1 conv that reads
+        the whole concat, its weight gradient and its input gradient address it plane by plane (conv1x1.hip, conv_wgrad_tr.hip; the BatchNorm passes of cv1)."""
+        es = 4 if self.dtype == MSL_F32 else 2
+        if member and self.dtype == MSL_BF16 and member % 8 == 0 and C % member == 0 and member * es < 128 and os.environ.get("MSL_PLANAR_CAT", "1") != "0" and not self.pending_on:
+            t = torch.empty(self.N * like.H * like.W * C, dtype=_dt(self.dtype), device=self.device)
+            g = torch.empty_like(t)
+            self._keep += [t, g]
+            self.grads[id(t)] = g
+            M = self.N * like.H * like.W
+            planes = [t[k * M * member : (k + 1) * M * member] for k in range(C // member)]
+            gplanes = [g[k * M * member : (k + 1) * M * member] for k in range(C // member)]
+            self._planes[id(t)] = planes
+            self._keep += planes + gplanes
+            for k, (pt, gp) in enumerate(zip(planes, gplanes)):
+                self.grads[id(pt)] = gp
+                self._init.alias[id(gp)] = (id(g), k * member, C)
+            return View(t, self.N, like.H, like.W, C, C, 0, False, member)
         return self._new(like.H, like.W, C)
 
     def view(self, buf, c0, c):
+        if buf.pl:
+            assert c0 % buf.pl == 0 and c % buf.pl == 0, "views of a planar buffer cover whole planes"
+            if c == buf.pl:  # one member: an ordinary dense tensor
+                return View(self._planes[id(buf.t)][(buf.co + c0) // buf.pl], buf.N, buf.H, buf.W, c, c, 0, buf.f32)
+            return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32, buf.pl)
         return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32)
 
     def upsample2x(self, x, out):
