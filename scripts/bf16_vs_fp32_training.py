@@ -36,7 +36,9 @@ def main():
     ds = D.VolumeSliceDataset(flair, mask, keep=lambda plano, i: i % 5 != 0)
     val = D.VolumeSliceDataset(flair, mask, keep=lambda plano, i: i % 5 == 0)
     runs = []
-    work = Path(args.out).parent / "bf16_vs_fp32_runs"
+    import tempfile
+
+    work = Path(tempfile.mkdtemp(prefix="bf16_vs_fp32_runs_"))  # checkpoints of six runs: not into gpurun_out (64 MiB come back from the GPU box)
     for prec in ("fp32", "bf16"):
         for seed in args.seeds:
             t0 = time.time()

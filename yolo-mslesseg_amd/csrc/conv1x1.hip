@@ -47,8 +47,10 @@ struct C1Args {
 // k-permutation conv_igemm uses, an exact fp32 fma chain).  The generic kernel these layers used before has no LDS staging: 2-4 TB/s.
 // SPLIT (fp32 tensors): split-precision products (msl_common.h) — the weight rows arrive pre-split from the host, and the wave rewrites the slice it staged
 // itself as (hi x 4 | lo x 4) units once it has landed (wave-private ring: no barrier), so the K loop reads ready-made f16 operands.
-template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight)
+template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false, bool PLANAR = false>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight);
+// PLANAR: planar x / y views (its own instantiation: the plane arithmetic costs 20-50 registers, i.e. a wave per SIMD on the plain forms — measured: the ConvT 64 -> 256 launch 0.144 -> 0.313 ms)
 __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
+  static_assert(!PLANAR || (!F32 && !SPLIT), "planar views: bf16");
   static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");  // 4 or 8 waves: 8 when the weight matrix is large, so that fewer LDS copies of it buy more pixels in flight per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
   for (int k = 0; k < MAXP; ++k) {
     const int cidx = k * 64 + lane, px = cidx / cps, ch = cidx - px * cps;
     xo[k] = (cidx < slice_chunks && ch < xchunks) ? (unsigned)((px * a.x_cs + ch * EPC) * ES) : OOB;
-    if (a.x_pl && xo[k] != OOB) {  // planar: (plane of the chunk's first channel) * M * pl + px * pl + channel inside the plane; the slice origin p0 * pl goes into the descriptor base
+    if (PLANAR && a.x_pl && xo[k] != OOB) {  // planar: (plane of the chunk's first channel) * M * pl + px * pl + channel inside the plane; the slice origin p0 * pl goes into the descriptor base
       const int ca = a.x_co + ch * EPC, pln = ca / a.x_pl;
       xo[k] = (unsigned)((((long)pln * a.M + px) * a.x_pl + (ca - pln * a.x_pl)) * ES);
     }
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
     unsigned char* dst = s_x + buf * slice_bytes;
     const long p0 = tile * SP;
     if (npieces <= MAXP && p0 + SP <= a.M) {  // wave-uniform: a full slice (all but the tensor's last one)
-      const c1_i32x4 rx = c1_rsrc(a.x_pl ? a.x + p0 * a.x_pl * ES : a.x + (p0 * a.x_cs + a.x_co) * ES);
+      const c1_i32x4 rx = c1_rsrc((PLANAR && a.x_pl) ? a.x + p0 * a.x_pl * ES : a.x + (p0 * a.x_cs + a.x_co) * ES);
       const unsigned l0 = lds_ring + buf * slice_bytes;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
       const int cidx = c0 + lane, px = cidx / cps, ch = cidx - px * cps;
       const bool ok = cidx < slice_chunks && ch < xchunks && p0 + px < a.M;
       const char* src = ok ? a.x + ((p0 + px) * a.x_cs + a.x_co + ch * EPC) * ES : (const char*)c1_zero_page;
-      if (ok && a.x_pl) {
+      if (PLANAR && ok && a.x_pl) {
         const int ca = a.x_co + ch * EPC, pln = ca / a.x_pl;
         src = a.x + (((long)pln * a.M + p0 + px) * a.x_pl + (ca - pln * a.x_pl)) * ES;
       }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
           for (int c = 0; c < NCP; ++c) {
             const int c0 = c * 32 + 8 * g, cr = c0 < a.Cout ? c0 : 0;
             long ri = p * a.res_cs + a.res_co + cr;
-            if (a.y_pl) { const int ca = a.res_co + cr, pln = ca / a.y_pl; ri = ((long)pln * a.M + p) * a.y_pl + (ca - pln * a.y_pl); }  // the residual is the output view's own content (an accumulating input gradient)
+            if (PLANAR && a.y_pl) { const int ca = a.res_co + cr, pln = ca / a.y_pl; ri = ((long)pln * a.M + p) * a.y_pl + (ca - pln * a.y_pl); }  // the residual is the output view's own content (an accumulating input gradient)
             rpre[pt][c] = *(const uint4*)((const unsigned short*)a.res + ri);
           }
         }
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
           for (int r = 0; r < 8; ++r) v[r] += rv[r];
         }
         long oi = p * a.y_cs + a.y_co + c0;
-        if (a.y_pl) { const int ca = a.y_co + c0, pln = ca / a.y_pl; oi = ((long)pln * a.M + p) * a.y_pl + (ca - pln * a.y_pl); }
+        if (PLANAR && a.y_pl) { const int ca = a.y_co + c0, pln = ca / a.y_pl; oi = ((long)pln * a.M + p) * a.y_pl + (ca - pln * a.y_pl); }
         if (a.shuffle) {  // an 8-channel run never straddles a quadrant (Cout/4 is a multiple of 8)
           const int C4 = a.Cout >> 2, q = c0 / C4;
           const long n = p / ((long)a.H * a.W);
@@ -709,7 +711,7 @@ bool msl_conv1x1_eligible(const msl_op& op) {
   return c1_lds((Cout + 31) / 32, Kpad, 1, 4, f32 ? 4 : 2) <= C1_LDS_MAX;
 }
 
-template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false>
+template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false, bool PLANAR = false>
 static int c1_launch(const C1Args& a, hipStream_t s) {
   constexpr int ES = F32 ? 4 : 2;
   // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
@@ -717,7 +719,7 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES) + (a.bn_tab ? (size_t)a.Kpad * 8 + (size_t)((a.Kpad / 8 + 15) & ~15) : 0);  // + the input BatchNorm table and group flags behind the bias
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT, PLANAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const long tiles = (a.M + PT * 16 - 1) / (PT * 16);
@@ -726,7 +728,7 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   if (per_cu < 1) per_cu = 1;
   long blocks = (tiles + nw - 1) / nw;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32, SPLIT>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
+  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32, SPLIT, PLANAR>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
   MSL_CHECK_LAUNCH("conv1x1");
   return MSL_OK;
 }
@@ -735,11 +737,11 @@ static int c1_launch_f32(const C1Args& a, hipStream_t s) {
   if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true, SPLIT>(a, s);
   return c1_launch<NCP, false, 1, true, SPLIT>(a, s);
 }
-template <int NCP, bool STATS>
+template <int NCP, bool STATS, bool PLANAR = false>
 static int c1_launch_pt(const C1Args& a, hipStream_t s) {
   // 32-pixel slices (each weight fragment feeds two MFMAs) when at least two workgroups still fit a CU, else 16-pixel slices
-  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2) * 2 <= 160 * 1024) return c1_launch<NCP, STATS, 2>(a, s);  // wide outputs: keep the accumulators at one pixel tile
-  return c1_launch<NCP, STATS, 1>(a, s);
+  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2) * 2 <= 160 * 1024) return c1_launch<NCP, STATS, 2, false, false, PLANAR>(a, s);  // wide outputs: keep the accumulators at one pixel tile
+  return c1_launch<NCP, STATS, 1, false, false, PLANAR>(a, s);
 }
 
 // MSL_OP_CONV slots (see msl_launch_conv) + p 5 = BatchNorm accumulator f64[slots][2*Cout] (optional), i 23 = slots
@@ -783,6 +785,13 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
       C1F(5); C1F(6); C1F(7); C1F(8);
     }
 #undef C1F
+  }
+  if (a.x_pl || a.y_pl) {  // planar views: the C3k2 concats of the 160² / 80² levels (<= 128 output channels)
+#define C1P(N) case N: return a.acc ? c1_launch_pt<N, true, true>(a, s) : c1_launch_pt<N, false, true>(a, s)
+    switch (ncp) { C1P(1); C1P(2); C1P(3); C1P(4); }
+#undef C1P
+    msl_set_error("conv1x1: planar views need Cout <= 128 (got %d)", a.Cout);
+    return MSL_EINVAL;
   }
 #define C1(N) case N: return a.acc ? c1_launch_pt<N, true>(a, s) : c1_launch_pt<N, false>(a, s)
 #define C1N(N) case N: return c1_launch_pt<N, false>(a, s)

@@ -260,7 +260,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 
 int msl_launch_conv(const msl_op& op, hipStream_t s) {
   if (op.i[26] || op.i[27])  // planar views (i 26 / 27): the 1x1 streaming kernel only — a multi-plane view never reaches a 3x3 conv (its members are dense planes)
-    MSL_REQUIRE(op.i[25] != 1 && msl_conv1x1_eligible(op) && op.i[6] <= 256, "conv: planar views exist in the bf16 1x1 streaming kernel only");
+    MSL_REQUIRE(op.i[25] != 1 && msl_conv1x1_eligible(op) && op.i[6] <= 128, "conv: planar views exist in the bf16 1x1 streaming kernel only (<= 128 output channels)");
   if (op.i[25] == 1) return msl_launch_conv3x3_lds(op, s);  // weights packed as the LDS image: tiled 3x3 kernel
   if (msl_conv1x1_eligible(op)) return msl_launch_conv1x1(op, s);  // bf16 1x1: streaming kernel with LDS-resident weights (conv1x1.hip)
   if (op.dtype == MSL_BF16 && op.i[7] == 1 && op.i[8] == 1 && op.i[9] == 0 && op.i[20] == 0 && op.i[6] > 256 && op.i[6] % 32 == 0 && !op.p[5] && op.p[1]) {

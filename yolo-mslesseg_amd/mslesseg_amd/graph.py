@@ -64,7 +64,7 @@ def _bottleneck(v, name, x, c2, shortcut=True, e=0.5, out=None):
 
 def _c3k(v, name, x, c2, n=2, out=None):
     c_ = int(c2 * 0.5)
-    cat = v.cat_buffer(x, 2 * c_)
+    cat = v.cat_buffer(x, 2 * c_, member=c_)  # [bottleneck chain output | cv2]: two members of equal width
     h = v.conv(f"{name}.cv1", x, c_, 1, 1)
     for j in range(n):
         h = _bottleneck(v, f"{name}.m.{j}", h, c_, True, 1.0, out=v.view(cat, 0, c_) if j == n - 1 else None)
