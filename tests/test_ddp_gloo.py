@@ -75,3 +75,47 @@ def test_gradient_buckets_partition_the_flat_buffer():
     for key, (o, shp) in st.entries.items():
         mine = head if int(key.split(".")[1]) >= 11 else back
         assert any(lo <= o and o + math.prod(shp) <= hi for lo, hi in mine), key
+
+
+def _shard_worker(rank, world, port, root, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from mslesseg_amd import data as D
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = D.SegDataset(root, 64, shard=(rank, world))
+    decoded = sum(r is not None for r in ds.raw)
+    ds.exchange()
+    torch.save({"decoded": decoded, "imgs": [torch.from_numpy(ds.raw[i][0].copy()) for i in range(len(ds.raw))],
+                "labels": [[torch.from_numpy(p) for _, p in ds.raw[i][1]] for i in range(len(ds.raw))]}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_dataset_load_equals_the_full_load(tmp_path):
+    """Data-parallel start-up: every rank decodes 1 / world of the fold's PNG files and one all-gather completes the list (data.SegDataset(shard=...).exchange())
+    — the same slices and labels, in the same order, as one process loading everything."""
+    from mslesseg_amd import data as D
+    from mslesseg_amd import pngio
+
+    rng = np.random.default_rng(0)
+    root = tmp_path / "ds"
+    (root / "images").mkdir(parents=True)
+    (root / "labels").mkdir()
+    for k in range(7):
+        h, w = [(40, 33), (33, 40), (40, 40)][k % 3]
+        pngio.write_png(root / "images" / f"s{k:02d}.png", rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        (root / "labels" / f"s{k:02d}.txt").write_text("".join(f"0 {0.1 + 0.05 * j:.3f} 0.2 0.6 0.25 0.5 {0.7 + 0.02 * j:.3f}\n" for j in range(k % 3 + 1)))
+    full = D.SegDataset(root, 64)
+    world, port = 2, _free_port()
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_shard_worker, args=(world, port, str(root), str(out)), nprocs=world, join=True)
+    r = [torch.load(out / f"s{k}.pt", weights_only=True) for k in range(world)]
+    assert r[0]["decoded"] == 4 and r[1]["decoded"] == 3
+    for rk in r:
+        assert len(rk["imgs"]) == len(full.raw) == 7
+        for i, (img, inst) in enumerate(full.raw):
+            assert np.array_equal(rk["imgs"][i].numpy(), img)
+            assert len(rk["labels"][i]) == len(inst) and all(np.array_equal(a.numpy(), p) for a, (_, p) in zip(rk["labels"][i], inst))

@@ -250,8 +250,12 @@ class Trainer:
             self.names = dict(enumerate(nm)) if isinstance(nm, (list, tuple)) else {int(k): v for k, v in nm.items()}
             root = Path(cfg.get("path", "."))
             tr, va = Path(cfg["train"]), Path(cfg["val"])
-            dataset = D.SegDataset(tr if tr.is_absolute() else root / tr, self.hyp["imgsz"])
-            val_dataset = D.SegDataset(va if va.is_absolute() else root / va, self.hyp["imgsz"])
+            # data parallel: the ranks of the node split the PNG decoding of the fold and exchange the decoded slices (data.SegDataset.exchange)
+            shard = (self.rank, self.world) if self.world > 1 else None
+            dataset = D.SegDataset(tr if tr.is_absolute() else root / tr, self.hyp["imgsz"], shard=shard)
+            val_dataset = D.SegDataset(va if va.is_absolute() else root / va, self.hyp["imgsz"], shard=shard)
+            dataset.exchange()
+            val_dataset.exchange()
         self.ds, self.val_ds = dataset, val_dataset
         # the slice cache of `cache=True` lives in HBM and batches are augmented there (augment.py); device_augment=False keeps the NumPy path of data.py
         self.aug = self.val_aug = None
@@ -287,7 +291,7 @@ class Trainer:
         S = self.hyp["imgsz"]
         # data parallel: the backward program is cut behind the head + neck layers (model.11..) so that their gradient bucket is reduced beside the backbone's
         # backward (forward_backward(reduce_now=True)); MSLESSEG_GRAD_BUCKETS=1 keeps one program and one all-reduce behind it
-        cut = 11 if (self.world > 1 and os.environ.get("MSLESSEG_GRAD_BUCKETS", "2") != "1") else None
+        cut = 11 if ((self.world > 1 and os.environ.get("MSLESSEG_GRAD_BUCKETS", "2") != "1") or os.environ.get("MSLESSEG_FORCE_CUT") == "1") else None  # FORCE_CUT: measure the cut's own cost on one GPU
         self.plan = TrainPlan(self.store, self.batch, S, S, self.dtype, bucket_cut=cut)
         self._buckets = self.store.bucket_ranges(cut) if cut is not None else None
         self._reduce_works, self._reduced = [], False
@@ -429,6 +433,8 @@ class Trainer:
                 plan.backward(on_cut=lambda: self._reduce_bucket(0))
                 self._reduce_bucket(1)
                 self._reduced = True
+            elif self.world == 1 and plan.cut_segment is not None:  # MSLESSEG_FORCE_CUT=1: the two-program backward without a collective (its own cost, one GPU)
+                plan.backward(on_cut=lambda: None)
             else:
                 plan.backward()
             return items
