@@ -553,6 +553,11 @@ int msl_launch_conv_wgrad_tr(const msl_op& op, hipStream_t s) {
     static double small_t = -1.0;
     if (small_t < 0) { const char* e = getenv("MSL_WGRAD_SMALL_T"); small_t = e ? atof(e) : 1.0; }
     if (small_env > 0 && operands < small_t * partials256) wgs_total = small_env;
+    // stride-2 layers stage with a ring of 2 (their 56-KB tiles do not leave room for a third): one tile in flight per CU, the loop waits for the LDS-DMA round trip
+    // every tile (80²→40² 128→128: 4 800 cycles per tile by counters against ~1 200 of MFMAs) — MSL_WGRAD_S2_WGS=<n> gives them their own workgroup count (measurements)
+    static int s2_env = -1;
+    if (s2_env < 0) { const char* e = getenv("MSL_WGRAD_S2_WGS"); s2_env = e ? atoi(e) : 0; }
+    if (s2_env > 0 && stride == 2 && k == 3) wgs_total = s2_env;
   }
   long want = wgs_total / ny;  // one 8-wave workgroup per CU (its ring of staged tiles takes the LDS): never more workgroups than CUs, a second round doubles the time
   if (want < 1) want = 1;
