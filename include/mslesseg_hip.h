@@ -52,7 +52,10 @@ enum { MSL_BF16 = 0, MSL_F32 = 1,
                        each, fp32 accumulate) on v_mfma_f32_16x16x16_f16 — 1e-6-grade instead of exact fp32, several times the fp32 matrix rate.  Conv
                        weights must be packed pre-split: every 16-byte unit of four fp32 values rewritten as (hi f16 x 4 | lo f16 x 4), hi = f16(w),
                        lo = f16(w - hi), after scaling the tensor by a power of two that brings its largest magnitude to [2^13, 2^14); the inverse power of two
-                       goes into msl_op.f[0] and is applied to the accumulators (mslesseg_amd.engine.split_f16_units).  Every other op kind treats it as MSL_F32. */ };
+                       goes into msl_op.f[0] and is applied to the accumulators (mslesseg_amd.engine.split_f16_units).  Every other op kind treats it as MSL_F32.
+                       ACTIVATION RANGE: activations are split as they are (no scale): hi + lo carries 21-22 bits for 6.1e-5 <= |x| <= 6.5e4 (the "1e-6-grade" figure holds
+                       there — every tensor of the network behind LetterBox's [0, 1] input lies inside); smaller magnitudes fall into f16 subnormals (absolute error
+                       <= 3e-8 instead of a relative one), larger ones saturate at 131 008 (finite: no inf / NaN reaches the accumulators). */ };
 
 enum {
   MSL_OK = 0,

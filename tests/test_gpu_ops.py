@@ -893,6 +893,45 @@ def test_split_precision_products_are_fp32_grade(kind):
     assert errs[MSL_F32] <= 2e-6 and errs[MSL_F32S] <= 4e-6, errs
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_split_precision_activation_range(k):
+    """MSL_F32S splits activations hi + lo without a scale (include/mslesseg_hip.h, "ACTIVATION RANGE"; round-3 ADVICE): inside 6.1e-5 <= |x| <= 6.5e4 the
+    products are fp32-grade; tiny activations lose to f16 subnormals by an ABSOLUTE 3e-8 at most; huge ones saturate at 131 008 — finite, never inf / NaN."""
+    g = torch.Generator().manual_seed(11 + k)
+    N, H, W, Cin, Cout = 2, 24, 24, 64, 32
+    pad = k // 2
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.zeros(Cout)
+
+    def run(x):
+        if k == 3:
+            wt, bt, m = E.pack_conv3x3_lds(w, b, MSL_F32S, DEV)
+            extra = {23: -8, 24: m["cot"], 25: 1}
+        else:
+            wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), b, MSL_F32S, DEV)
+            extra = {}
+        xd = x.to(DEV)
+        yd = torch.zeros(N, H, W, Cout, device=DEV)
+        hiplib.launch(hiplib.make_op(hiplib.OP_CONV, MSL_F32S, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr()),
+                                     i={0: N, 1: H, 2: W, 3: Cin, 4: H, 5: W, 6: Cout, 7: k, 8: 1, 9: pad, 10: Cin, 11: 0, 12: Cout, 13: 0, 14: Cout, 15: 0,
+                                        16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 0, 21: m["Cout_pad"], **extra}, f=(m.get("oscale", 1.0),)), _stream())
+        torch.cuda.synchronize()
+        return yd.cpu().double()
+
+    def ref(x):
+        return F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), stride=1, padding=pad).permute(0, 2, 3, 1)
+
+    big = (torch.rand(N, H, W, Cin, generator=g) * 2 - 1) * 6.0e4  # inside the range, up to its top (beyond 65 504 the hi half saturates and lo keeps 11 bits: ~1e-4)
+    d = (run(big) - ref(big)).abs().max() / ref(big).abs().max()
+    assert d <= 4e-6, f"large in-range activations: {float(d):.2e}"
+    tiny = torch.randn(N, H, W, Cin, generator=g) * 1e-6        # f16-subnormal territory: absolute, not relative, accuracy
+    err = (run(tiny) - ref(tiny)).abs().max()
+    assert err <= 3e-8 * Cin * k * k, f"tiny activations: abs err {float(err):.2e}"
+    huge = torch.randn(N, H, W, Cin, generator=g) * 1e7         # far outside: saturates, stays finite
+    out = run(huge)
+    assert torch.isfinite(out).all(), "out-of-range activations produced inf / NaN"
+
+
 def test_conv3x3_with_fused_1x1_tail():
     """MSL_OP_CONV p[6]/p[7]: y = SiLU(W2 · SiLU(conv3x3(x) + b) + b2) in one launch of the persistent 3x3 kernel (Proto.cv2 + Proto.cv3 at
     predict time; bf16, 64 -> 64 -> 32) against the two-step fp32 reference with the intermediate rounded to bf16 as the unfused layers store it."""

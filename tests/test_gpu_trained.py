@@ -217,7 +217,7 @@ def test_predict_variants_mixed_work_list_equals_single_variant_runs(trained_sta
 def test_a_bad_item_is_logged_and_skipped_like_the_reference_skips_a_patient(trained_state, demo_volumes, tmp_path, caplog):
     """The reference wraps every patient in try / except → logger.warning("… se omite") → continue [REF scripts/generar_predicciones.py:289-301,
     reconstruir_volumen.py:297-306]; the batched paths keep that: one wrong-shaped volume, one variant without a model and one out-of-range
-    slice index in the list leave their entries None, the good items are still predicted and equal the undisturbed run."""
+    slice index in the list leave their entries SKIPPED (falsy, distinct from the None of another rank's item), the good items are still predicted and equal the undisturbed run."""
     import logging
 
     from ultralytics import YOLO
@@ -234,7 +234,7 @@ def test_a_bad_item_is_logged_and_skipped_like_the_reference_skips_a_patient(tra
     want = V.predict_volume(models["GC"], fl, "axial", idx, mejora="GC").cpu()
     with caplog.at_level(logging.WARNING, logger="ultralytics"):
         outs = V.predict_variants(models, items, rank=0, world=1)
-    assert outs[1] is None and outs[2] is None and outs[3] is None
+    assert outs[1] is V.SKIPPED and outs[2] is V.SKIPPED and outs[3] is V.SKIPPED and not outs[1]  # a marker of its own: None means "another rank's item"
     assert torch.equal(outs[0].cpu(), want) and torch.equal(outs[4].cpu(), want)
     assert sum("se omite" in r.getMessage() for r in caplog.records) == 3
     # the per-patient loop around the three-plane consensus
@@ -243,7 +243,7 @@ def test_a_bad_item_is_logged_and_skipped_like_the_reference_skips_a_patient(tra
     caplog.clear()
     with caplog.at_level(logging.WARNING, logger="ultralytics"):
         res = V.predict_patients(plane_models, [("P39", fl), ("Pbad", np.zeros((4, 4))), ("P39b", fl)], indices={"P39": sel, "P39b": sel})
-    assert res["Pbad"] is None and sum("Pbad" in r.getMessage() for r in caplog.records) == 1
+    assert res["Pbad"] is V.SKIPPED and sum("Pbad" in r.getMessage() for r in caplog.records) == 1
     assert torch.equal(res["P39"][0], res["P39b"][0]) and res["P39"][0].dtype == torch.uint8
     with pytest.raises(ValueError):
         V.predict_patients(plane_models, [("Pbad", np.zeros((4, 4)))], strict=True)

@@ -432,7 +432,7 @@ int msl_adamw(float* params, const float* grads, float* m, float* v, int64_t n, 
   op.kind = MSL_OP_ADAMW; op.dtype = MSL_F32;
   op.p[0] = params; op.p[1] = (void*)grads; op.p[2] = m; op.p[3] = v; op.p[5] = (void*)clip_scale;
   op.i[0] = (int32_t)(n & 0x7FFFFFFF); op.i[1] = (int32_t)(n >> 31);
-  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));  // in double, as the Python trainer computes them (powf: 6e-5 off at step 1)
   memcpy(&op.i[2], &weight_decay, 4); memcpy(&op.i[3], &bc1, 4); memcpy(&op.i[4], &bc2, 4);
   op.f[0] = lr; op.f[1] = beta1; op.f[2] = beta2; op.f[3] = eps;
   return dispatch(op, (hipStream_t)stream);

@@ -222,8 +222,10 @@ typedef __fp16 msl_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 msl_split_unit(uint4 raw) {
   const f32x4 v = __builtin_bit_cast(f32x4, raw);
   const msl_h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-  const _Float16 l0 = (_Float16)(v[0] - (float)h01[0]), l1 = (_Float16)(v[1] - (float)h01[1]);
-  const _Float16 l2 = (_Float16)(v[2] - (float)h23[0]), l3 = (_Float16)(v[3] - (float)h23[1]);
+  // the residual is clamped to the f16 range: beyond |x| ~ 1.3e5 (hi saturated at 65504) it would round to inf and poison the accumulator with NaN — the value
+  // then saturates at hi + lo = 131008 instead (activation range contract: include/mslesseg_hip.h, MSL_F32S)
+  const _Float16 l0 = (_Float16)__builtin_amdgcn_fmed3f(v[0] - (float)h01[0], -65504.f, 65504.f), l1 = (_Float16)__builtin_amdgcn_fmed3f(v[1] - (float)h01[1], -65504.f, 65504.f);
+  const _Float16 l2 = (_Float16)__builtin_amdgcn_fmed3f(v[2] - (float)h23[0], -65504.f, 65504.f), l3 = (_Float16)__builtin_amdgcn_fmed3f(v[3] - (float)h23[1], -65504.f, 65504.f);
   uint4 o;
   o.x = __builtin_bit_cast(unsigned, h01);
   o.y = __builtin_bit_cast(unsigned, h23);

@@ -26,6 +26,20 @@ from .hiplib import MSL_F32
 LOGGER = logging.getLogger("ultralytics")  # the logger the reference silences / reads [REF scripts/train.py:78]
 
 PLANE_AXIS = {"axial": 2, "coronal": 1, "sagital": 0}
+
+
+class _Skipped:
+    """Result slot of an item that was skipped because of a bad input (logged with the reference's wording); falsy, and distinct from None — which in
+    `predict_variants` means "this item belongs to another rank"."""
+
+    def __bool__(self):
+        return False
+
+    def __repr__(self):
+        return "SKIPPED"
+
+
+SKIPPED = _Skipped()
 _GRAY_LUT = (np.linspace(0, 1, 256) * 255).astype(np.uint8)  # matplotlib cm.gray(bytes=True): truncation, 24 entries one below
 _NIFTI_DT = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16, 768: np.uint32}
 _NIFTI_CODE = {np.dtype(np.uint8): (2, 8), np.dtype(np.int16): (4, 16), np.dtype(np.float32): (16, 32), np.dtype(np.float64): (64, 64)}
@@ -264,11 +278,13 @@ def predict_patients(models: Dict[str, object], patients: Sequence[Tuple[str, np
             if a.ndim != 3:
                 raise ValueError(f"se esperaba un volumen 3D, se recibió {a.shape}")
             out[pid] = predict_consensus(models, a, umbral, None if indices is None else indices.get(pid))
-        except Exception as e:  # noqa: BLE001 — the reference's own `except Exception` around a patient
+        except hiplib.MslError:
+            raise  # a library / device error is not a property of this patient: every later item would fail the same way — never swallowed
+        except (ValueError, KeyError, IndexError, TypeError) as e:  # the reference's `except Exception` around a patient, narrowed to what a bad INPUT raises
             if strict:
                 raise
             LOGGER.warning(f"⚠️ Error generando predicciones de {pid}, se omite: {e}.")
-            out[pid] = None
+            out[pid] = SKIPPED
     return out
 
 
@@ -304,8 +320,11 @@ def predict_variants(models: Dict[Optional[str], object], items: Sequence[Tuple]
             if np.ndim(flair) != 3:
                 raise ValueError(f"se esperaba un volumen 3D, se recibió {np.shape(flair)}")
             out[k] = predict_volume(model, flair, plano, idx, batch=batch, mejora=mejora)
-        except Exception as e:  # noqa: BLE001
+        except hiplib.MslError:
+            raise  # (as predict_patients: device errors are not swallowed)
+        except (ValueError, KeyError, IndexError, TypeError) as e:
             if strict:
                 raise
             LOGGER.warning(f"⚠️ Error generando predicciones del elemento {k} ({mejora}, {plano}), se omite: {e}.")
+            out[k] = SKIPPED  # distinct from None = "this item belongs to another rank"
     return out
