@@ -131,3 +131,35 @@ def test_planar_views_equal_interleaved_views(case):
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-9) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-6, atol=1e-6), "BatchNorm backward sums: planar dy"
     same = (outs[0][1] == outs[1][1]).float().mean().item()
     assert same > 0.999, f"BatchNorm backward apply: planar dy differs on {1 - same:.4%} of dz"  # the sums differ in the last bits of their fp64 -> fp32 rounding at most
+
+
+@pytest.mark.parametrize("case", [(2, 24, 20, 32, 64, 0, 64, 1), (3, 17, 9, 64, 96, 32, 32, 1), (1, 40, 40, 128, 32, 0, 32, 0)])
+def test_backward_sums_in_the_input_gradient_epilogue(case):
+    """The 1x1 input gradient with p 9..11 (conv1x1.hip, BWS form; a measured form of round 4 — slower than the two launches on the large maps, not emitted by the
+    training program): the same dy as the plain launch, bit for bit, and the (sum g, sum g * zhat) that MSL_OP_BN_ACT_BWD_REDUCE computes from that dy and z,
+    for a layer that owns a channel sub-range of the output."""
+    from mslesseg_amd import engine as E
+
+    N, H, W, Cdz, Cout, c0, CL, act = case
+    g = torch.Generator().manual_seed(sum(case))
+    BF, slots = MSL_BF16, 8
+    dz = torch.randn(N, H, W, Cdz, generator=g).bfloat16().to(DEV)
+    z = torch.randn(N, H, W, CL, generator=g).bfloat16().to(DEV)
+    w = ((torch.rand((Cout, Cdz, 1, 1), generator=g) * 2 - 1) / Cdz**0.5).to(torch.bfloat16).float()
+    wt, bt, m = E.pack_gemm(E.pack_conv_weight(w), torch.zeros(Cout), BF, DEV)
+    stats = torch.stack([torch.rand(CL, generator=g) * 0.2, torch.rand(CL, generator=g) + 0.5], 1).reshape(-1).to(DEV)
+    gb = torch.cat([torch.rand(CL, generator=g) + 0.5, torch.rand(CL, generator=g) - 0.5]).to(DEV)
+    ci = {0: N, 1: H, 2: W, 3: Cdz, 4: H, 5: W, 6: Cout, 7: 1, 8: 1, 9: 0, 10: Cdz, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 21: m["Cout_pad"], 22: 1}
+    dy0 = torch.zeros(N, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    dy1 = torch.zeros_like(dy0)
+    acc0 = torch.zeros(slots * 2 * CL, dtype=torch.float64, device=DEV)
+    acc1 = torch.zeros_like(acc0)
+    hiplib.launch(hiplib.make_op(hiplib.OP_CONV, BF, p=(dz.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, dy0.data_ptr()), i=ci), _stream())
+    hiplib.launch(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, BF, p=(dy0.data_ptr(), z.data_ptr(), stats.data_ptr(), gb.data_ptr(), gb.data_ptr() + 4 * CL, acc0.data_ptr()),
+                                 i={0: N, 1: H, 2: W, 3: CL, 10: CL, 11: 0, 12: Cout, 13: c0, 18: act, 21: slots}), _stream())
+    hiplib.launch(hiplib.make_op(hiplib.OP_CONV, BF, p=(dz.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, dy1.data_ptr(), acc1.data_ptr(), 0, 0, 0, z.data_ptr(), stats.data_ptr(), gb.data_ptr()),
+                                 i={**ci, 23: slots, 28: CL, 29: CL, 30: 0, 31: c0 | (CL << 16)}, f=(0.0, 0.0, float(act))), _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dy0, dy1)
+    s0, s1 = acc0.cpu().view(slots, CL, 2).sum(0), acc1.cpu().view(slots, CL, 2).sum(0)
+    assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-5 * float(s0.abs().max())), float((s0 - s1).abs().max())

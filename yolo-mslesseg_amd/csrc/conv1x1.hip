@@ -35,6 +35,14 @@ struct C1Args {
   const float* bn_tab;  // input BatchNorm table of the x BUFFER (msl_common.h: f32 [x_cs][2] (scale, shift), then u8 [x_cs / 8] group flags) or NULL: the wave applies
                         // x <- act(x * scale + shift) to the flagged 8-channel groups of the slice it staged, in LDS, before multiplying — the producer's BN_ACT pass
                         // (z -> a) folded into this consumer
+  // BatchNorm BACKWARD sums in the epilogue (BWS form, round 4): this launch is the input gradient that writes dy of a Conv + BatchNorm + SiLU layer L (its only
+  // gradient producer); while a lane holds 8 values of dy it also reads the layer's raw conv output z at the same place and adds (sum g, sum g * zhat),
+  // g = dy * act'(gamma * zhat + beta), to L's slot accumulators `acc` — the MSL_OP_BN_ACT_BWD_REDUCE pass over (dy, z) disappears.
+  const char* bz;        // z of layer L, dense view (bz_cs, bz_co), same pixels as y; channels [bws_c0, bws_c0 + bws_C) of y belong to L
+  const float* bstats;   // (mean, invstd) f32 [bws_C][2]
+  const float* bgamma;   // f32 [bws_C]
+  const float* bbeta;
+  int bz_cs, bz_co, bws_c0, bws_C, bact;
   int x_pl, y_pl;  // PLANAR concat views (round 4; include/mslesseg_hip.h "planar views"): channels per plane of the x / y (and residual) buffer, 0 = interleaved.
                    // Channel ca of pixel p of a planar buffer lives at element (ca / pl) * M * pl + p * pl + ca % pl — every member of a C3k2 concat is a
                    // dense plane of its own (its other readers see full lines) and this kernel picks K-chunks / stores channel groups plane by plane
@@ -47,10 +55,11 @@ struct C1Args {
 // k-permutation conv_igemm uses, an exact fp32 fma chain).  The generic kernel these layers used before has no LDS staging: 2-4 TB/s.
 // SPLIT (fp32 tensors): split-precision products (msl_common.h) — the weight rows arrive pre-split from the host, and the wave rewrites the slice it staged
 // itself as (hi x 4 | lo x 4) units once it has landed (wave-private ring: no barrier), so the K loop reads ready-made f16 operands.
-template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false, bool PLANAR = false>  // NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight);
+template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false, bool PLANAR = false, bool BWS = false>  // BWS: BatchNorm backward sums in the epilogue (with STATS: shares its fold); NCP: 32-channel output groups (two MFMA tiles each); PT: 16-pixel tiles per slice (2, or 1 when LDS is tight);
 // PLANAR: planar x / y views (its own instantiation: the plane arithmetic costs 20-50 registers, i.e. a wave per SIMD on the plain forms — measured: the ConvT 64 -> 256 launch 0.144 -> 0.313 ms)
 __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
   static_assert(!PLANAR || (!F32 && !SPLIT), "planar views: bf16");
+  static_assert(!BWS || (STATS && !F32), "backward sums: a form of the bf16 statistics epilogue");
   static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");  // 4 or 8 waves: 8 when the weight matrix is large, so that fewer LDS copies of it buy more pixels in flight per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -69,6 +78,17 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
   for (int i = threadIdx.x; i < NCP * 32; i += blockDim.x) s_bias[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;
   float* s_bn = s_bias + NCP * 32;  // [2 * Kpad] (scale, shift) per input channel of the view, then [Kpad / 8] group flags (as floats' bytes: 1 byte each)
   unsigned char* s_fl = (unsigned char*)(s_bn + 2 * a.Kpad);
+  float* s_cst = (float*)(((unsigned long)(s_fl + ((a.Kpad / 8 + 15) & ~15)) + 15) & ~15ul);  // BWS: [4][NCP * 32] = mean | invstd | gamma | beta per OUTPUT channel (0 outside layer L's range)
+  if constexpr (BWS) {
+    for (int i = threadIdx.x; i < NCP * 32; i += blockDim.x) {
+      const int cl = i - a.bws_c0;
+      const bool in = cl >= 0 && cl < a.bws_C;
+      s_cst[i] = in ? a.bstats[2 * cl] : 0.f;
+      s_cst[NCP * 32 + i] = in ? a.bstats[2 * cl + 1] : 0.f;
+      s_cst[2 * NCP * 32 + i] = in ? a.bgamma[cl] : 0.f;
+      s_cst[3 * NCP * 32 + i] = in ? a.bbeta[cl] : 0.f;
+    }
+  }
   if (a.bn_tab) {
     const MslBnTab bt = msl_bn_tab(a.bn_tab, a.x_cs);
     for (int i = threadIdx.x; i < 2 * a.Kpad; i += blockDim.x) s_bn[i] = i < 2 * a.Cin ? bt.tab[2 * a.x_co + i] : 0.f;
@@ -196,6 +216,20 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
         }
       }
     }
+    uint4 zpre[BWS ? PT : 1][BWS ? NCP : 1];  // BWS: z of layer L at this lane's store groups, requested before the MFMAs (as the residual prefetch)
+    if constexpr (BWS) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        long p = tile * SP + pt * 16 + li;
+        p = p < a.M ? p : a.M - 1;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+          int cl = c * 32 + 8 * g - a.bws_c0;
+          cl = (cl >= 0 && cl < a.bws_C) ? cl : 0;
+          zpre[pt][c] = *(const uint4*)((const unsigned short*)a.bz + p * a.bz_cs + a.bz_co + cl);
+        }
+      }
+    }
     f32x4 acc[PT][NCP][2];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
@@ -278,7 +312,33 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
         float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[pt][c][0][r]; v[4 + r] = acc[pt][c][1][r]; }
-        if constexpr (STATS) {
+        if constexpr (BWS) {
+          const int cl = c0 - a.bws_c0;
+          if (cl >= 0 && cl < a.bws_C) {  // (wave-uniform per lane group: a layer's range covers whole 8-channel groups)
+            const uint4 zt = zpre[pt][c];
+            const unsigned zw[4] = {zt.x, zt.y, zt.z, zt.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float2 mu2 = *(const float2*)(s_cst + c0 + 2 * j), is2 = *(const float2*)(s_cst + NCP * 32 + c0 + 2 * j);
+              const float2 ga2 = *(const float2*)(s_cst + 2 * NCP * 32 + c0 + 2 * j), be2 = *(const float2*)(s_cst + 3 * NCP * 32 + c0 + 2 * j);
+              const msl_f2 z2 = {__uint_as_float(zw[j] << 16), __uint_as_float(zw[j] & 0xffff0000u)};
+              const msl_f2 d2 = {bf16_bits_to_f32(f32_to_bf16_bits(v[2 * j])), bf16_bits_to_f32(f32_to_bf16_bits(v[2 * j + 1]))};  // the dy values actually stored
+              const msl_f2 zh = (z2 - (msl_f2){mu2.x, mu2.y}) * (msl_f2){is2.x, is2.y};
+              msl_f2 gg = d2;
+              if (a.bact) {  // the same expressions as chan_reduce_kernel<MODE 1> (train_kernels.hip)
+                const msl_f2 u = (msl_f2){ga2.x, ga2.y} * zh + (msl_f2){be2.x, be2.y};
+                const msl_f2 t = u * -1.44269504088896f;
+                const msl_f2 den = (msl_f2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+                const msl_f2 sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                gg = d2 * (sg * (u * (1.0f - sg) + 1.0f));
+              }
+              const msl_f2 q = gg * zh;
+              const int r = 2 * j;
+              s1[c][r >> 2][r & 3] += gg.x; s1[c][(r + 1) >> 2][(r + 1) & 3] += gg.y;
+              s2[c][r >> 2][r & 3] += q.x; s2[c][(r + 1) >> 2][(r + 1) & 3] += q.y;
+            }
+          }
+        } else if constexpr (STATS) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             const float vr = bf16_bits_to_f32(f32_to_bf16_bits(v[r]));  // statistics of the values actually stored
@@ -342,12 +402,14 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(C1Args a) {
           }
         }
     __syncthreads();
-    double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * a.Cout;
-    for (int ch = threadIdx.x; ch < a.Cout; ch += blockDim.x) {
+    const int fc0 = BWS ? a.bws_c0 : 0, fC = BWS ? a.bws_C : a.Cout;  // BWS: the accumulator is layer L's, [slots][2 * bws_C], for the output channels [bws_c0, bws_c0 + bws_C)
+    double* dst = a.acc + (long)(blockIdx.x % a.slots) * 2 * fC;
+    for (int cl = threadIdx.x; cl < fC; cl += blockDim.x) {
+      const int ch = fc0 + cl;
       float t1 = 0.f, t2 = 0.f;
       for (int w = 0; w < NW; ++w) { t1 += red[(w * 2 + 0) * NCP * 32 + ch]; t2 += red[(w * 2 + 1) * NCP * 32 + ch]; }
-      atomicAdd(dst + 2 * ch, (double)t1);
-      atomicAdd(dst + 2 * ch + 1, (double)t2);
+      atomicAdd(dst + 2 * cl, (double)t1);
+      atomicAdd(dst + 2 * cl + 1, (double)t2);
     }
   }
 }
@@ -711,15 +773,16 @@ bool msl_conv1x1_eligible(const msl_op& op) {
   return c1_lds((Cout + 31) / 32, Kpad, 1, 4, f32 ? 4 : 2) <= C1_LDS_MAX;
 }
 
-template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false, bool PLANAR = false>
+template <int NCP, bool STATS, int PT, bool F32 = false, bool SPLIT = false, bool PLANAR = false, bool BWS = false>
 static int c1_launch(const C1Args& a, hipStream_t s) {
   constexpr int ES = F32 ? 4 : 2;
   // 8 waves per workgroup when fewer than 3 four-wave workgroups would fit a CU (large weight matrix) and the 8-wave form still fits
   const int nw = (c1_lds(NCP, a.Kpad, PT, 4, ES) * 3 > 160 * 1024 && c1_lds(NCP, a.Kpad, PT, 8, ES) <= C1_LDS_MAX) ? 8 : 4;
-  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES) + (a.bn_tab ? (size_t)a.Kpad * 8 + (size_t)((a.Kpad / 8 + 15) & ~15) : 0);  // + the input BatchNorm table and group flags behind the bias
+  const size_t lds = c1_lds(NCP, a.Kpad, PT, nw, ES) + (a.bn_tab || BWS ? (size_t)a.Kpad * 8 + (size_t)((a.Kpad / 8 + 15) & ~15) + 16 : 0)  // + the input BatchNorm table and group flags behind the bias
+                     + (BWS ? (size_t)NCP * 32 * 16 : 0);                                                                              // + the backward-sums constants
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT, PLANAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCP, STATS, PT, F32, SPLIT, PLANAR, BWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const long tiles = (a.M + PT * 16 - 1) / (PT * 16);
@@ -728,7 +791,7 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
   if (per_cu < 1) per_cu = 1;
   long blocks = (tiles + nw - 1) / nw;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32, SPLIT, PLANAR>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
+  hipLaunchKernelGGL((conv1x1_kernel<NCP, STATS, PT, F32, SPLIT, PLANAR, BWS>), dim3((unsigned)blocks), dim3(64 * nw), lds, s, a);
   MSL_CHECK_LAUNCH("conv1x1");
   return MSL_OK;
 }
@@ -737,11 +800,11 @@ static int c1_launch_f32(const C1Args& a, hipStream_t s) {
   if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true, SPLIT>(a, s);
   return c1_launch<NCP, false, 1, true, SPLIT>(a, s);
 }
-template <int NCP, bool STATS, bool PLANAR = false>
+template <int NCP, bool STATS, bool PLANAR = false, bool BWS = false>
 static int c1_launch_pt(const C1Args& a, hipStream_t s) {
   // 32-pixel slices (each weight fragment feeds two MFMAs) when at least two workgroups still fit a CU, else 16-pixel slices
-  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2) * 2 <= 160 * 1024) return c1_launch<NCP, STATS, 2, false, false, PLANAR>(a, s);  // wide outputs: keep the accumulators at one pixel tile
-  return c1_launch<NCP, STATS, 1, false, false, PLANAR>(a, s);
+  if (NCP <= (BWS ? 3 : 4) && c1_lds(NCP, a.Kpad, 2) * 2 <= 160 * 1024) return c1_launch<NCP, STATS, 2, false, false, PLANAR, BWS>(a, s);  // wide outputs: keep the accumulators at one pixel tile (backward sums: 128 outputs spill at two)
+  return c1_launch<NCP, STATS, 1, false, false, PLANAR, BWS>(a, s);
 }
 
 // MSL_OP_CONV slots (see msl_launch_conv) + p 5 = BatchNorm accumulator f64[slots][2*Cout] (optional), i 23 = slots
@@ -785,6 +848,20 @@ int msl_launch_conv1x1(const msl_op& op, hipStream_t s) {
       C1F(5); C1F(6); C1F(7); C1F(8);
     }
 #undef C1F
+  }
+  // p 9 (bf16, optional; with p 5 = the slot accumulator of LAYER L, i 23 = slots): BatchNorm backward sums of layer L in this input gradient's epilogue — p 9 = z of L
+  // (dense view: i 29 = its channel stride, i 30 = offset), p 10 = (mean, invstd) f32 [C_L][2], p 11 = gamma f32 [C_L] with beta at gamma + i 28 elements,
+  // i 31 = first output channel of L | C_L << 16, f 2 != 0: SiLU.  No residual (this launch is dy's only producer), bf16 output, <= 128 output channels.
+  if (op.p[9]) {
+    a.bz = (const char*)op.p[9]; a.bstats = (const float*)op.p[10]; a.bgamma = (const float*)op.p[11]; a.bbeta = a.bgamma ? a.bgamma + op.i[28] : nullptr;
+    a.bz_cs = op.i[29]; a.bz_co = op.i[30]; a.bws_c0 = op.i[31] & 0xffff; a.bws_C = (op.i[31] >> 16) & 0xffff; a.bact = op.f[2] != 0.f;
+    MSL_REQUIRE(a.acc && a.bstats && a.bgamma && !a.res && !a.out_f32 && !a.shuffle && !a.bn_tab && ncp <= 4 && a.bws_C > 0 && a.bws_C % 8 == 0 && a.bws_c0 % 8 == 0 &&
+                    a.bws_c0 + a.bws_C <= a.Cout && a.bz_cs % 8 == 0 && a.bz_co % 8 == 0 && a.bz_co + a.bws_C <= a.bz_cs,
+                "conv1x1: bad backward-sums arguments (p 9..11, i 28..31)");
+    const bool pl = a.x_pl || a.y_pl;
+#define C1B(N) case N: return pl ? c1_launch_pt<N, true, true, true>(a, s) : c1_launch_pt<N, true, false, true>(a, s)
+    switch (ncp) { C1B(1); C1B(2); C1B(3); C1B(4); }
+#undef C1B
   }
   if (a.x_pl || a.y_pl) {  // planar views: the C3k2 concats of the 160² / 80² levels (<= 128 output channels)
 #define C1P(N) case N: return a.acc ? c1_launch_pt<N, true, true>(a, s) : c1_launch_pt<N, false, true>(a, s)
