@@ -211,6 +211,7 @@ class ProgramBuilder(graph.Visitor):
         self.proto_view: Optional[View] = None
         self.in_view: Optional[View] = None
         self._keep = []
+        self._planes: Dict[int, list] = {}  # id(planar buffer tensor) -> its plane sub-tensors
 
     # -- helpers
     def _new(self, H, W, C, f32=False) -> View:
@@ -248,10 +249,10 @@ class ProgramBuilder(graph.Visitor):
             return y
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
              16: m["K"], 17: m["Kpad"], 18: 1 if act else 0, 19: 1 if f32_out else 0, 20: 0, 21: m["Cout_pad"],
-             24: m.get("cot", 0), 25: m.get("lds", 0)}
+             24: m.get("cot", 0), 25: m.get("lds", 0), 26: x.pl, 27: y.pl}
         rp = 0
         if res is not None:
-            assert (res.H, res.W, res.C) == (Ho, Wo, cout), name
+            assert (res.H, res.W, res.C) == (Ho, Wo, cout) and not res.pl, name
             i[14], i[15], rp = res.cs, res.co, res.t.data_ptr()
         self._emit(name, hiplib.make_op(hiplib.OP_CONV, self.dtype, p=(x.t.data_ptr(), wt.data_ptr(), bt.data_ptr(), rp, y.t.data_ptr()), i=i, f=(m.get("oscale", 1.0),)))
         self.taps[name] = y
@@ -302,9 +303,23 @@ class ProgramBuilder(graph.Visitor):
         return y
 
     def cat_buffer(self, like, C, scale=1.0, member=0):
+        """bf16: a concat of equal-width members narrower than a 128-byte line (C3k2 at the 160² / 80² levels) is stored PLANAR — one dense plane per member
+        (View.pl; trainprog.TrainPlan.cat_buffer has the rationale): the bottleneck convs and residuals read full lines instead of a fraction of every line."""
+        if member and self.dtype == MSL_BF16 and member % 8 == 0 and C % member == 0 and member * 2 < 128 and os.environ.get("MSL_PLANAR_CAT", "1") != "0":
+            t = torch.empty(self.N * like.H * like.W * C, dtype=_dt(self.dtype), device=self.device)
+            M = self.N * like.H * like.W
+            planes = [t[k * M * member : (k + 1) * M * member] for k in range(C // member)]
+            self._keep += [t] + planes
+            self._planes[id(t)] = planes
+            return View(t, self.N, like.H, like.W, C, C, 0, False, member)
         return self._new(like.H, like.W, C)
 
     def view(self, buf, c0, c):
+        if buf.pl:
+            assert c0 % buf.pl == 0 and c % buf.pl == 0, "views of a planar buffer cover whole planes"
+            if c == buf.pl:  # one member: an ordinary dense tensor
+                return View(self._planes[id(buf.t)][(buf.co + c0) // buf.pl], buf.N, buf.H, buf.W, c, c, 0, buf.f32)
+            return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32, buf.pl)
         return View(buf.t, buf.N, buf.H, buf.W, c, buf.cs, buf.co + c0, buf.f32)
 
     def upsample2x(self, x, out):
