@@ -163,3 +163,38 @@ def test_backward_sums_in_the_input_gradient_epilogue(case):
     assert torch.equal(dy0, dy1)
     s0, s1 = acc0.cpu().view(slots, CL, 2).sum(0), acc1.cpu().view(slots, CL, 2).sum(0)
     assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-5 * float(s0.abs().max())), float((s0 - s1).abs().max())
+
+
+@pytest.mark.parametrize("case", [(32, 128, 64, 64, 64, 4), (32, 128, 64, 128, 128, 2), (40, 96, 72, 32, 64, 4), (40, 100, 60, 96, 32, 2), (33, 128, 64, 128, 256, 2)])
+def test_stride2_persistent_conv_equals_the_tile_kernel(case):
+    """conv3x3_s2pers_kernel (round 4: stride 2, the block's weights for all input chunks resident in LDS, halo units double-buffered; i 23 = -10 — measured slower
+    than the tile kernel and not dispatched by default) against PyTorch and, bit for bit, against the tile-per-workgroup kernel on the same packed weights (i 23 = -8),
+    with the BatchNorm-statistics epilogue; ragged tiles included."""
+    import torch.nn.functional as F
+
+    from mslesseg_amd import engine as E
+
+    N, H, W, Cin, Cout, cot = case
+    g = torch.Generator().manual_seed(sum(case))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = (torch.rand((N, H, W, Cin), generator=g) * 2 - 1).to(torch.bfloat16)
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) / (Cin * 9) ** 0.5).to(torch.bfloat16).float()
+    wt, bt, m = E.pack_conv3x3_lds(w, torch.zeros(Cout), MSL_BF16, DEV, cot)
+    assert m["cot"] == cot
+    xd = x.to(DEV)
+    slots = 8
+    outs = []
+    for sel in (-10, -8):
+        yd = torch.zeros((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=DEV)
+        acc = torch.zeros(slots * 2 * Cout, dtype=torch.float64, device=DEV)
+        hiplib.launch(hiplib.make_op(hiplib.OP_CONV, MSL_BF16, p=(xd.data_ptr(), wt.data_ptr(), bt.data_ptr(), 0, yd.data_ptr(), acc.data_ptr()),
+                                     i={0: N, 1: H, 2: W, 3: Cin, 4: Ho, 5: Wo, 6: Cout, 7: 3, 8: 2, 9: 1, 10: Cin, 11: 0, 12: Cout, 13: 0, 16: m["K"], 17: m["Kpad"], 18: 0, 19: 0, 20: 0,
+                                        21: m["Cout_pad"], 23: sel, 24: m["cot"], 25: 1}), _stream())
+        torch.cuda.synchronize()
+        outs.append((yd.cpu(), acc.cpu().view(slots, Cout, 2).sum(0)))  # (a selector in i 23 means one accumulator slot: the other seven stay zero)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=2, padding=1).permute(0, 2, 3, 1)
+    err = (outs[0][0].float() - ref).abs().max() / ref.abs().max()
+    assert err < 1e-2, float(err)
+    assert torch.equal(outs[0][0], outs[1][0]), "persistent and tile kernel differ"
+    z = outs[0][0].float().reshape(-1, Cout).double()
+    assert torch.allclose(outs[0][1][:, 0], z.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(outs[0][1][:, 1], (z * z).sum(0), rtol=1e-5, atol=1e-3)

@@ -812,6 +812,190 @@ static int launch3p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent, weights-resident form of the STRIDE-2 forward conv (bf16; round 4).  In the tile kernel above a stride-2 workgroup lives four chunks long and every
+// chunk is stage (39 KiB of parity-split halo + 36 KiB of weights) -> wait for the LDS-DMA round trip -> 72 MFMAs per wave, nothing double-buffered: by counters the
+// 80² -> 40² 128 -> 128 layer spends 10 000 cycles per chunk for ~1 200 of MFMAs (mfma_util 0.22, 1.3 TB/s) and half of what it stages is the weight slab, fetched
+// again by each of the 2 560 tiles.  Here one 4-wave workgroup per CU keeps the weights of its output-channel block for ALL input chunks in LDS (<= 72 KiB: 64 -> 64
+// with 64-channel blocks, 128 -> N with 32-channel blocks) and walks a contiguous run of tiles; the unit of work is (tile, chunk): the halo of unit u + 1 is in flight
+// (asm LDS-DMA into the other half of a 2 x 39 KiB ring) while unit u is multiplied, one bare barrier per unit, BatchNorm statistics in registers over all tiles.
+template <int COT, int NCH>
+__global__ __launch_bounds__(256) void conv3x3_s2pers_kernel(Conv3Args a, int total_tiles, int tiles_per_wg) {
+  using T = Tile3<2, 1>;  // 4 x 32 outputs; halo 9 rows x (2 parities x 34 slots)
+  constexpr int ES = 2, CHUNK = 32, COB = COT * 16, PT = 2;
+  constexpr int IN_BYTES = T::PIECES * 1024;
+  constexpr int W_BYTES = 9 * 4 * COB * 16;
+  constexpr int IN_PER_WAVE = (T::PIECES + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_w = smem;                     // [chunk][tap][g][COB][16 B]
+  unsigned char* s_ring = smem + NCH * W_BYTES;  // [2][IN_BYTES]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lp = lane & 15, g = lane >> 4;
+  const int cob = blockIdx.y;
+  const int t0 = blockIdx.x * tiles_per_wg;
+  const int nt = min(tiles_per_wg, total_tiles - t0);
+  const int my_units = nt > 0 ? nt * NCH : 0;
+  {  // weights of this output-channel block, all chunks: staged once
+    const char* wsrc = a.w + (long)cob * NCH * W_BYTES + lane * 16;
+    for (int pc = wave; pc < NCH * W_BYTES / 1024; pc += 4) msl_glds16(wsrc + pc * 1024, msl_lds_addr(s_w + pc * 1024));
+  }
+  // tile-independent part of the staging gather: halo (row, col) of this lane's 16 bytes for each of its pieces (parity-split columns)
+  int rc[IN_PER_WAVE];
+  const int gq16 = ((((lane & 15) & 3) - (lane >> 4)) & 3) * 16;
+  {
+    const int row4 = lane >> 4, pos = lane & 15;
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      const int sl = pc * 16 + row4 * 4 + (pos >> 2);
+      const int rr = sl / T::ROWP, ps = sl - rr * T::ROWP;  // rr = row * 2 + parity
+      const bool ok = pc < T::PIECES && sl < T::SLOTS && (gq16 >> 4) * (CHUNK / 4) < a.Cin;
+      rc[j] = ok ? ((rr >> 1) << 8 | (ps * 2 + (rr & 1))) : -1;
+    }
+  }
+  // fragment addresses: output row `wave` of the tile, taps (ty, tx): halo row 2 * wave + ty, parity tx & 1, column col + (tx >> 1)
+  int baddr[3][3];
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) baddr[ty][tx] = halo_byte(((2 * wave + ty) * 2 + (tx & 1)) * T::ROWP + (tx >> 1) + lp, g);
+  const int aoff = (g * COB + lp) * 16;
+  f32x4 acc[COT][PT];
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s1[COT][4], s2[COT][4];
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
+  float bias_r[COT * 4];
+  load_bias<COT>(a, cob * COB + g * (4 * COT), bias_r);
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const char* st_img = a.x;
+  int st_off[IN_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < IN_PER_WAVE; ++j) st_off[j] = -1;
+
+  auto stage = [&](int un, unsigned char* dst) __attribute__((always_inline)) {
+    const int cc = un % NCH;
+    if (cc == 0) {  // first chunk of a new tile: gather offsets
+      int t = t0 + un / NCH;
+      const int n = t / tiles_per_img;
+      t -= n * tiles_per_img;
+      const int tyi = t / a.tiles_x, txi = t - tyi * a.tiles_x;
+      const int iy0 = tyi * T::TH * 2 - 1, ix0 = txi * T::TW * 2 - 1;
+      st_img = a.x + ((long)n * a.H * a.W * a.x_cs + a.x_co) * ES;
+#pragma unroll
+      for (int j = 0; j < IN_PER_WAVE; ++j) {
+        const int iy = iy0 + (rc[j] >> 8), ix = ix0 + (rc[j] & 255);
+        const bool ok = rc[j] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        st_off[j] = ok ? ((iy * a.W + ix) * a.x_cs) * ES + gq16 : -1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int pc = wave + 4 * j;
+      if (pc < T::PIECES) {
+        const char* src = st_off[j] >= 0 ? st_img + st_off[j] + cc * (CHUNK * ES) : (const char*)msl_zero_page;
+        msl_glds16(src, msl_lds_addr(dst + pc * 1024));
+      }
+    }
+  };
+  auto compute = [&](int cc, const unsigned char* buf) __attribute__((always_inline)) {
+    const unsigned char* wa = s_w + cc * W_BYTES + aoff;
+    uint4 av[2][COT], bv[2][PT];
+    auto fetch = [&](int t, uint4 (&A)[COT], uint4 (&B)[PT]) {
+#pragma unroll
+      for (int c = 0; c < COT; ++c) A[c] = *(const uint4*)(wa + (t * 4 * COB + c * 16) * 16);
+#pragma unroll
+      for (int p = 0; p < PT; ++p) B[p] = *(const uint4*)(buf + baddr[t / 3][t % 3] + p * 1024);  // the second 16-column half: 16 slots = 4 image rows of 256 B
+    };
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) fetch(t + 1, av[(t + 1) & 1], bv[(t + 1) & 1]);
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+          acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[t & 1][c]), __builtin_bit_cast(bf16x8, bv[t & 1][p]), acc[c][p], 0, 0, 0);
+    }
+  };
+  auto epilogue = [&](int k) __attribute__((always_inline)) {
+    int t = t0 + k;
+    const int n = t / tiles_per_img;
+    t -= n * tiles_per_img;
+    const int tyi = t / a.tiles_x, txi = t - tyi * a.tiles_x;
+    const int oy = tyi * T::TH + wave;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int ox = txi * T::TW + p * 16 + lp;
+      if (oy < a.Ho && ox < a.Wo) {
+        f32x4 accp[COT];
+#pragma unroll
+        for (int c = 0; c < COT; ++c) accp[c] = acc[c][p];
+        store_pixel_b<false, COT>(a, ((long)n * a.Ho + oy) * a.Wo + ox, cob * COB + g * (4 * COT), accp, s1, s2, bias_r, nullptr);
+      }
+#pragma unroll
+      for (int c = 0; c < COT; ++c) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (my_units > 0) stage(0, s_ring);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights + unit 0 (this wave's pieces)
+  for (int u = 0; u < my_units; ++u) {  // block-uniform
+    // every wave's pieces of unit u have landed (each waited for its own), and everyone is done reading the buffer refilled next
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (u + 1 < my_units) stage(u + 1, s_ring + ((u + 1) & 1) * IN_BYTES);
+    compute(u % NCH, s_ring + (u & 1) * IN_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unit u + 1 (it had the MFMAs to land); waited for before the epilogue so that its stores stay in flight
+    if (u % NCH == NCH - 1) epilogue(u / NCH);
+  }
+  if (a.acc) {  // fold the statistics: 16 pixel lanes (DPP), the 4 waves (LDS), then one fp64 atomic per channel and statistic
+    __syncthreads();
+    float* red = (float*)s_ring;  // [4 waves][2][COB]
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = row16_sum(s1[c][r]), t2 = row16_sum(s2[c][r]);
+        if (lp == 0) {
+          red[(wave * 2 + 0) * COB + g * (4 * COT) + c * 4 + r] = t1;
+          red[(wave * 2 + 1) * COB + g * (4 * COT) + c * 4 + r] = t2;
+        }
+      }
+    __syncthreads();
+    double* dst = a.acc + (long)((blockIdx.x + blockIdx.y) % a.slots) * 2 * a.Cout;
+    for (int i = threadIdx.x; i < 2 * COB; i += 256) {
+      const int st = i / COB, ch = i - st * COB;
+      const int co = cob * COB + ch;
+      if (co < a.Cout) atomicAdd(dst + 2 * co + st, (double)(red[(0 * 2 + st) * COB + ch] + red[(1 * 2 + st) * COB + ch] + red[(2 * 2 + st) * COB + ch] + red[(3 * 2 + st) * COB + ch]));
+    }
+  }
+}
+
+template <int COT, int NCH>
+static int launch3s2p(const Conv3Args& a, int cout_blocks, hipStream_t s) {
+  using T = Tile3<2, 1>;
+  constexpr int LDS = NCH * 9 * 4 * COT * 16 * 16 + 2 * T::PIECES * 1024;
+  static_assert(LDS <= 160 * 1024, "conv3x3_s2pers: LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_s2pers_kernel<COT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const long tiles = (long)a.N * a.tiles_y * a.tiles_x;
+  long wgs = 256 / cout_blocks;  // one workgroup per CU over all output-channel blocks
+  if (wgs < 1) wgs = 1;
+  if (wgs > tiles) wgs = tiles;
+  const long tpw = (tiles + wgs - 1) / wgs;
+  wgs = (tiles + tpw - 1) / tpw;
+  hipLaunchKernelGGL((conv3x3_s2pers_kernel<COT, NCH>), dim3((unsigned)wgs, (unsigned)cout_blocks), dim3(256), LDS, s, a, (int)tiles, (int)tpw);
+  MSL_CHECK_LAUNCH("conv3x3_s2pers");
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Input gradient of a 3x3 / stride 2 / pad 1 convolution, all four parity classes in ONE pass (bf16).  dx[2Y+a][2X+b] only receives the
 // taps ky = 1 (a = 0) or ky in {2, 0} (a = 1; sources dz[Y], dz[Y+1]), and likewise kx for b — a 1x1, 1x2, 2x1 and 2x2 kernel over dz.
 // Run as four separate passes (store mode 2 above) the gradient tile is staged four times and every 128-byte line of dx is written
@@ -1093,6 +1277,27 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (cot == 2) return launch3<F, S_, RW_, 2>(a, cout_blocks, s);      \
     return launch3<F, S_, RW_, 1>(a, cout_blocks, s);                    \
   } while (0)
+  // stride 2, bf16, whole chunks: the persistent weights-resident form (block's weights for all chunks beside a 2 x 39 KiB halo ring) — i 23 = -10 asks for it (tests,
+  // A/B).  MEASURED SLOWER and not dispatched (batch 128, ms, tile kernel -> this form): 80² -> 40² 128 -> 128 0.197 -> 0.279, 40² -> 20² 128 -> 256 0.082 -> 0.127,
+  // 128 -> 128 0.050 -> 0.069, 160² -> 80² 64 -> 64 0.181 -> 0.171, 80² -> 40² 64 -> 64 0.064 -> 0.063; step 22.25 -> 22.4-22.6 ms.  One 4-wave workgroup per CU has ONE
+  // 39-KiB halo unit in flight while it multiplies the other: at an LDS-DMA round trip of ~5 000 cycles under load that is 8 bytes per clock and CU, and a unit's
+  // 36-72 MFMAs per wave (600-1 200 cycles) hide a fifth of it; the tile kernel's two resident workgroups keep 150 KiB in flight.  What bounds these layers is the
+  // bytes a CU can have in flight (LDS) over the DMA latency, not the weight slab's re-staging.
+  if (!f32 && stride == 2 && rw == 1 && a.Cin % chunk == 0 && !a.bn_tab && !a.res && !a.w2 && op.i[23] == -10) {
+    const int nch = a.Cin / chunk;
+    const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
+    const bool fits = nch <= 4 && nch * 9 * 4 * cot * 256 + 2 * Tile3<2, 1>::PIECES * 1024 <= 160 * 1024;
+    if (fits && tiles >= 512) {
+#define L3S2(NCH_)                                                      \
+  do {                                                                  \
+    if (cot == 4) { if constexpr (NCH_ <= 2) return launch3s2p<4, NCH_>(a, cout_blocks, s); } \
+    else if (cot == 2) return launch3s2p<2, NCH_>(a, cout_blocks, s);   \
+    else return launch3s2p<1, NCH_>(a, cout_blocks, s);                 \
+  } while (0)
+      if (nch == 1) L3S2(1); else if (nch == 2) L3S2(2); else if (nch == 3) L3S2(3); else L3S2(4);
+#undef L3S2
+    }
+  }
   if (split) {  // the tile-per-workgroup kernel only
 #define L3S(S_, RW_)                                                                     \
   do {                                                                                   \
