@@ -710,7 +710,12 @@ bool msl_gemm1x1_eligible(const msl_op& op) {
   if ((op.i[10] | op.i[11] | op.i[12] | op.i[13]) & al) return false;
   if (op.p[3] && ((op.i[14] | op.i[15]) & al)) return false;
   const long M = (long)op.i[0] * op.i[1] * op.i[2];
-  return M >= 128 * 64 && (long)128 * op.i[10] * es < (1L << 31) && (long)128 * Kpad * es < (1L << 31);
+  // enough pixels to fill the chip with 128-pixel tiles — or, for the fp32 forms, the few-tile launches of the one-slice-per-call plans (64-channel tiles there:
+  // msl_launch_gemm1x1): the generic kernel these ran on before re-fetches both operands from L2 on every K-step (20² 512 -> 256 at batch 1: 62 us)
+  static int small_ok = -1;
+  if (small_ok < 0) { const char* e = getenv("MSL_GEMM1X1_SMALL"); small_ok = e ? atoi(e) : 1; }
+  const long min_m = (f32 && small_ok) ? 256 : 128 * 64;
+  return M >= min_m && (long)128 * op.i[10] * es < (1L << 31) && (long)128 * Kpad * es < (1L << 31);
 }
 
 int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
@@ -727,8 +732,12 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   MSL_REQUIRE(!a.bn_tab || (op.dtype == MSL_BF16 && a.Kpad <= 2048 && a.x_co % 8 == 0 && a.x_cs % 8 == 0), "gemm1x1: the input BatchNorm table (p[8]) is a bf16 form (K <= 2048)");
   MSL_REQUIRE(a.x && a.w && a.y && msl_gemm1x1_eligible(op), "gemm1x1: bad args");
   MSL_REQUIRE(op.i[4] == op.i[1] && op.i[5] == op.i[2] && a.x_co + a.Cin <= a.x_cs && a.y_co + a.Cout <= a.y_cs && (!a.res || a.res_co + a.Cout <= a.res_cs), "gemm1x1: bad dims / views");
-  const bool f32 = op.dtype != MSL_BF16, narrow = f32 && a.Cout <= 64;
-  a.ntn = narrow ? 1 : (a.Cout + 127) / 128;
+  // fp32 forms: 64-channel tiles (four waves x 32 pixels) for layers of at most 64 output channels — and for launches with FEW tiles (the one-slice-per-call plans:
+  // 20² 512 -> 256 at batch 1 is 4 pixel tiles x 2 channel tiles = 8 workgroups walking 16 chunks): twice the workgroups, half the matrix work per chunk
+  // (i 23 = -3 keeps 128-channel tiles: A/B measurements)
+  const bool f32 = op.dtype != MSL_BF16;
+  const bool narrow = f32 && (a.Cout <= 64 || ((a.M + 127) / 128 * ((a.Cout + 127) / 128) < 128 && op.i[23] != -3));
+  a.ntn = narrow ? (a.Cout + 63) / 64 : (a.Cout + 127) / 128;
   const long tiles = (a.M + 127) / 128 * a.ntn;
   MSL_REQUIRE(tiles < (1L << 31), "gemm1x1: too many tiles");
   constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4 + 2048 * 8 + 256;  // (the 64-channel forms use 2 x 27 KiB of it) + the input BatchNorm table (K <= 2048) and its group flags

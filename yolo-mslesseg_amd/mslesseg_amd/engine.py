@@ -148,6 +148,10 @@ class PackedWeights:
         self.scale, self.nc, self.dtype, self.device = scale, nc, dtype, device
         self.specs = params.param_specs(scale, nc)
         self.t: Dict[str, Tuple[torch.Tensor, torch.Tensor, dict]] = {}
+        # the 3x3 layers once more in 16-channel output blocks (COT = 1): plans with FEW tiles — the reference's one-slice-per-call loop, batch 1 — give a layer
+        # 1-5 workgroups with 64-channel blocks (20² 256 -> 64 at batch 1: three CUs busy for 148 us); 16-channel blocks are four times as many workgroups doing
+        # a quarter of the matrix work each.  Same arithmetic per output (chunk and tap order unchanged): bit-identical results
+        self.t1: Dict[str, Tuple[torch.Tensor, torch.Tensor, dict]] = {}
         kstep = 32 if dtype == MSL_BF16 else 16
         for name, s in self.specs.items():
             w, b = params.folded(state, name, s)
@@ -171,6 +175,8 @@ class PackedWeights:
                     # fragment read feeds half as many matrix instructions.  Off.
                     cot = 2 if dtype != MSL_BF16 and s["s"] == 1 and cin == 64 and cout % 32 == 0 and os.environ.get("MSL_F32_COT2", "0") == "1" else None
                     self.t[name] = pack_conv3x3_lds(w, b, dtype, device, cot)
+                    if self.t[name][2]["cot"] > 1 and os.environ.get("MSL_SMALL_PLAN_COT1", "1") != "0":
+                        self.t1[name] = pack_conv3x3_lds(w, b, dtype, device, 1)
                 else:
                     self._pack_gemm(name, pack_conv_weight(w), b, kstep)
 
@@ -245,6 +251,11 @@ class ProgramBuilder(graph.Visitor):
         y = out if out is not None else self._new(Ho, Wo, cout, f32=f32_out)
         assert (y.H, y.W, y.C) == (Ho, Wo, cout), (name, (y.H, y.W, y.C), (Ho, Wo, cout))
         wt, bt, m = self.w.t[name]
+        if name in self.w.t1:  # few tiles (batch 1): 16-channel output blocks when the layer would not give every CU a workgroup otherwise
+            th = 8 if s == 1 else 4
+            wgs = self.N * ((Wo + 31) // 32) * ((Ho + th - 1) // th) * max(1, cout // (16 * m["cot"]))
+            if wgs < 256:
+                wt, bt, m = self.w.t1[name]
         if self._fuse_into_previous_3x3(name, x, y, cout, k, s, act, res, f32_out, wt, bt, m):
             return y
         i = {0: self.N, 1: x.H, 2: x.W, 3: x.C, 4: Ho, 5: Wo, 6: cout, 7: k, 8: s, 9: pad, 10: x.cs, 11: x.co, 12: y.cs, 13: y.co,
@@ -540,6 +551,10 @@ class InferEngine:
         for name, (wt, bt, m) in self.weights.t.items():
             nw, nb_, nm = new.t[name]
             assert wt.shape == nw.shape and bt.shape == nb_.shape and m == nm, name
+            wt.copy_(nw)
+            bt.copy_(nb_)
+        for name, (wt, bt, m) in self.weights.t1.items():
+            nw, nb_, nm = new.t1[name]
             wt.copy_(nw)
             bt.copy_(nb_)
 
