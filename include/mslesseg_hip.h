@@ -92,10 +92,16 @@ enum {
    *    p 6,7 (LDS 3x3 only, optional) fused 1x1 tail: 6 = W2 [i22 = 32][Cout = 64] row-major in the op dtype (bf16), 7 = bias2 f32[32]; the op
    *       then writes y = act(W2 * act(conv(x) + bias) + bias2) (32 channels) and the 64-channel intermediate never reaches memory
    *       (Proto.cv2 + Proto.cv3 at predict time); refused unless the persistent weights-resident kernel can take it
-   *    p 6 (1x1 / stride 1 / pad 0, bf16, optional) input transform on load: f32 [Cin][2] = (scale, shift) per INPUT channel; the kernel multiplies
-   *       W by x' = (f 1 != 0 ? SiLU : id)(x * scale + shift), rounded to bf16 — the producer's BatchNorm + activation (scale = gamma * invstd,
-   *       shift = beta - mean * scale) folded into this consumer so that the activated tensor is never written.  Only the streaming kernel
-   *       (weights resident in LDS) has it: refused otherwise.  A measured form (BatchNorm fusion), not emitted by the training program */
+   *    p 8 (bf16, optional; round 4) input BatchNorm table of the x BUFFER: f32 [x_cs][2] = (scale, shift) per buffer channel, then u8 [x_cs / 8] flags per 8-channel
+   *       group (bit 0: the group holds the raw conv output of a pending BatchNorm — the kernel multiplies W by x' = act(x * scale + shift) rounded to bf16, applied to the
+   *       16-byte units it stages; bit 1: act = SiLU; flag 0: ordinary activations, left alone).  Honoured by the 1x1 streaming kernel, the tiled 1x1 GEMM and the LDS-tiled
+   *       3x3 tile kernel (units staged from the zero page — padding — stay zero); refused elsewhere (msl_input_table_supported tells).  scale = gamma * invstd,
+   *       shift = beta - mean * scale are written by MSL_OP_BN_FINALIZE (p 4..6).  Measured slower than the BN_ACT pass it removes: tested,
+   *       not emitted by the training program unless MSL_BN_ONLOAD=1.
+   *    i 26 / 27 (bf16 1x1 streaming kernel): planar x / planar y (+ residual = y) — channels per plane, see "Planar views" above.
+   *    p 9..11, i 28..31, f 2 (bf16 1x1 streaming kernel, with p 5 / i 23): BatchNorm BACKWARD sums of the layer whose dy this input gradient writes, in the epilogue
+   *       (slot list beside msl_launch_conv1x1; a measured form, not emitted).
+   *    i 23 further selectors: -10 = the persistent weights-resident stride-2 kernel (measured slower, tests); LDS 3x3 launches with few tiles may be packed with COT = 1. */
   MSL_OP_CONV = 1,
   /* Stem: 3x3 stride-2 conv straight from the letterboxed uint8 image (RGB order, /255 folded in).
    * p: 0 x u8 [N,H,W,3], 1 w f32 [27][Cout] ((ky,kx,ci) major), 2 bias f32[Cout], 4 y
