@@ -174,3 +174,31 @@ def test_folded_conv_bn_matches_oracle_fuse(golden_dir):
         for part in name.split("."):
             mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
         assert torch.allclose(w, mod.conv.weight, rtol=1e-5, atol=1e-7) and torch.allclose(b, mod.conv.bias, rtol=1e-5, atol=1e-6)
+
+
+def test_on_load_scan_decides_from_the_library(built_lib):
+    """trainprog.OnLoadScan (BatchNorm on load, round 4) asks the library which readers honour an input BatchNorm table (msl_input_table_supported: host code, no
+    GPU needed) and leaves a layer pending only when every reader does: no layer with a residual of its own, no layer read by a pool / upsample / attention /
+    depthwise conv / the loss, none read through the generic kernel (the one-channel class head); and the reader-pass bound is respected."""
+    from mslesseg_amd import graph, trainprog
+    from mslesseg_amd.hiplib import MSL_BF16, MSL_F32
+
+    sc = trainprog.OnLoadScan(128, 640, 640, MSL_BF16, 2.0)
+    graph.walk(sc, "n", 1)
+    pend = sc.pending()
+    bn_layers = [p for p in sc.prod if p["bn"]]
+    assert len(bn_layers) == 90 and len(pend) == 56
+    for p in sc.prod:
+        if p["res"] or not p["bn"]:
+            assert p["name"] not in pend
+    for must_not in ("model.9.cv1", "model.10.m.0.attn.qkv", "model.10.cv2", "model.13.cv2", "model.16.cv2", "model.22.cv2", "model.23.proto.cv3", "model.23.cv3.0.1.1",
+                     "model.23.cv2.0.0"):  # pool, attention, upsample, multi-reader pyramid features, the loss, the generic class head, the persistent 3x3 reader
+        assert must_not not in pend, must_not
+    for must in ("model.0", "model.1", "model.2.cv1", "model.2.m.0.cv1", "model.3", "model.23.proto.cv2", "model.23.cv3.0.0.0"):
+        assert must in pend, must
+    tight = trainprog.OnLoadScan(128, 640, 640, MSL_BF16, 1.0)
+    graph.walk(tight, "n", 1)
+    assert "model.2.cv1" not in tight.pending() and "model.1" in tight.pending()  # cv1's output is read 0.5 + 0.5 + 1 times
+    f32 = trainprog.OnLoadScan(8, 64, 64, MSL_F32, 2.0)
+    graph.walk(f32, "n", 1)
+    assert not f32.pending()  # a bf16 form
