@@ -246,17 +246,22 @@ const char* msl_last_error(void);
 int msl_launch(const msl_op* op, void* stream);
 /* Enqueue ops[0..n) in order on `stream` (one host call per forward pass). */
 int msl_run_program(const msl_op* ops, int32_t n, void* stream);
-/* Same, with a lane per op (0 = `stream`; 1..4 = fork/join side streams: a lane starts after what `stream` holds so far, the next lane-0 op
- * waits for it — independent chains overlap; 5..7 = deferred side streams: each op waits for what `stream` (or the running fork/join lane in
- * bits 8-15 of its lane word) holds so far, nothing waits for it until the end of the program — work whose result the program itself never
- * reads, e.g. weight gradients).  The call returns with every lane
- * joined into `stream`. */
+/* Same, with a lane per op (0 = `stream`; 1..4 = fork/join lanes on side streams: a lane starts after what `stream` held when the region — the run of ops
+ * between two joins — opened, the next lane-0 op waits for all of them: independent chains overlap; MSL_LANE_MAIN_FREE (0x10000) = an op on `stream` that is
+ * itself one of the region's chains: it neither joins nor delays the lanes forked after it; 5..7 = deferred lanes: each op waits for what `stream` (or the
+ * running fork/join lane in bits 8-15 of its lane word) holds so far, nothing waits for it until the end of the program — work whose result the program
+ * itself never reads, e.g. weight gradients).  Lanes share 3 side streams by (lane - 1) % 3 — with `stream` the 4 hardware queues a process gets; lanes on
+ * one stream run in enqueue order.  The call returns with every lane joined into `stream`. */
+#define MSL_LANE_MAIN_FREE 0x10000
 int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream);
 
 /* 1 if `op` (MSL_OP_CONV or MSL_OP_CONV_WGRAD; shapes, views and flags filled in, pointers may be placeholders) would run on a kernel that honours an
  * input BatchNorm table in p[8] — the "BatchNorm on load" form of the training program (csrc/msl_common.h): the producer's raw conv output stays in
  * memory and this consumer applies act(z * scale + shift) to what it stages.  0 otherwise (the producer must then materialise its activation). */
 int msl_input_table_supported(const msl_op* op);
+/* Diagnostic, with MSL_LANE_STAMPS=1 in the environment: milliseconds since the begin of the last msl_run_program_lanes call — out[0] = 0, out[1] = its end,
+ * out[2k] / out[2k+1] = the fork and the last join of lane k (-1: lane not used); n >= 16.  Synchronises on the events.  Without the variable: MSL_EINVAL. */
+int msl_lane_stamps(float* out, int32_t n);
 
 /* hipGraph capture of a program: launch-bound inner loops (batch-1 predict, ~110 small kernels) replay as one graph. */
 int msl_graph_create(const msl_op* ops, int32_t n, void* stream, void** graph_exec_out);

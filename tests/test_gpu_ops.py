@@ -997,3 +997,41 @@ def test_bn_act_bwd_fused_equals_reduce_plus_apply(dtype, shape):
         tol = (1e-5 if dtype == MSL_F32 else 1e-2) * float(want_dz.abs().max()) + 1e-7
         assert float((got_dz - want_dz).abs().max()) <= tol, (rep, float((got_dz - want_dz).abs().max()), tol)
         assert torch.allclose(got_g, want_g, rtol=1e-5, atol=1e-5 * float(want_g.abs().max()))
+
+
+@pytest.mark.gpu
+def test_program_lanes_region_semantics():
+    """msl_run_program_lanes (csrc/capi.hip): a region of independent chains — fork/join lanes 2 and 4 and a chain on the caller's stream itself
+    (MSL_LANE_MAIN_FREE) — reads what lane 0 wrote before the region, each chain keeps its own order, the next lane-0 op sees all of them, and a deferred op
+    (lane 5, source = the caller's stream) is complete when the call's stream is.  Values make every ordering visible: x -> a = 2x on lane 0; in the region
+    b = a + a (main, free), c = a + a + a (lane 2), d = a, then d += a four times (lane 4); e = b + c + d on lane 0; g = b + b (deferred).  Replayed 20 times."""
+    dev = "cuda:0"
+    N, H, W, C = 4, 64, 64, 32
+    x = torch.randn(N, H, W, C, device=dev)
+    bufs = {k: torch.zeros_like(x) for k in "abcdeg"}
+
+    def add(dst, src, copy=False):
+        return hiplib.make_op(hiplib.OP_ADD_VIEW, MSL_F32, p=(bufs[dst].data_ptr() if dst != "x" else x.data_ptr(), (bufs[src] if src != "x" else x).data_ptr()),
+                              i={0: N, 1: H, 2: W, 3: C, 10: C, 11: 0, 12: C, 13: 0, 20: 1 if copy else 0})
+
+    FREE = hiplib.LANE_MAIN_FREE
+    prog = [(add("a", "x", True), 0), (add("a", "x"), 0),
+            (add("b", "a", True), FREE), (add("c", "a", True), 2), (add("d", "a", True), 4), (add("b", "a"), FREE), (add("c", "a"), 2), (add("d", "a"), 4),
+            (add("c", "a"), 2), (add("d", "a"), 4), (add("d", "a"), 4), (add("d", "a"), 4),
+            (add("g", "b", True), 5), (add("g", "b"), 5),  # deferred: after the two ops of the free chain
+            (add("e", "b", True), 0), (add("e", "c"), 0), (add("e", "d"), 0)]
+    p = hiplib.Program([o for o, _ in prog], lanes=[l for _, l in prog])
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(20):
+        for t in bufs.values():
+            t.zero_()
+        p.run(s)
+        torch.cuda.synchronize()
+        a = 2 * x
+        assert torch.equal(bufs["a"], a) and torch.equal(bufs["b"], a + a) and torch.equal(bufs["c"], a + a + a)
+        assert torch.equal(bufs["d"], a + a + a + a + a)
+        assert torch.equal(bufs["e"], (a + a) + (a + a + a) + (a + a + a + a + a))
+        assert torch.equal(bufs["g"], (a + a) + (a + a))
+    bad = hiplib.Program([add("a", "x")], lanes=[FREE | 2])  # the free flag belongs to lane 0 only
+    with pytest.raises(hiplib.MslError):
+        bad.run(s)

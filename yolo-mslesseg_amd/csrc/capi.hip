@@ -94,18 +94,32 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream) {
 
 // Program with lanes: ops tagged lane 0 run on `stream`; ops tagged 1..MSL_MAX_LANES-1 run on library-owned side streams.
 //   fork/join lanes (1 .. MSL_FIRST_DEFERRED-1): independent chains (the detection-head branches of different pyramid levels) overlap their
-//     launch-latency-bound kernels.  Ops of one lane keep program order; a lane starts after everything issued to `stream` so far (fork
-//     event); a lane-0 op that follows such ops waits for all of them (join).
+//     launch-latency-bound kernels.  Ops of one lane keep program order; a lane starts after everything issued to `stream` BEFORE THE REGION — the run of
+//     ops between two joins — opened (one fork event per region); a lane-0 op that follows such ops waits for all of them (join).
+//   lane word MSL_LANE_MAIN_FREE (bit 16, lane 0): an op on `stream` that is itself one of the region's independent chains — it does not join, and the
+//     lanes forked after it do not wait for it (the caller's stream would otherwise idle while the region runs: it is the fourth hardware queue).
 //   deferred lanes (MSL_FIRST_DEFERRED ..): work whose result nothing in the program reads (weight gradients — only the optimizer step after
 //     the program needs them).  Every such op waits for everything issued so far to `stream` (or to the fork/join lane named in bits 8-15 of
 //     its lane word, when that lane is running), lane-0 ops do NOT wait for it: the chain of
 //     input-gradient / BatchNorm kernels continues while the weight-gradient kernels fill the tails of those launches.
 //   The end of the program joins every lane.
+// Streams: the HIP runtime gives a process 4 hardware queues (GPU_MAX_HW_QUEUES; 8 or 16 were measured: the step goes from 22.4 to 35.8 ms — the queues are
+// then time-sliced); a fifth stream SHARES a queue with an earlier one and its kernels run strictly behind that stream's (scripts/dev_lane_stamps.py showed the
+// fourth head lane starting when the third had finished, profiles/r04ab_lane_stamps.txt).  So the lanes are mapped onto MSL_SIDE_STREAMS = 3 streams — with the
+// caller's stream exactly the 4 queues — by (lane - 1) % 3: which lanes serialise is a decision of the program (lanes 1 / 4 / 7, 2 / 5, 3 / 6), not of the
+// runtime's queue assignment.
 #define MSL_MAX_LANES 8
 #define MSL_FIRST_DEFERRED 5
-static hipStream_t g_side[16][MSL_MAX_LANES];
+#define MSL_SIDE_STREAMS 3
+static hipStream_t g_phys[16][MSL_MAX_LANES];
+static hipStream_t g_side[16][MSL_MAX_LANES];  // lane -> one of g_phys
 static hipEvent_t g_fork[16], g_fork_def[16], g_join[16][MSL_MAX_LANES];
 static bool g_lanes_ready[16];
+// MSL_LANE_STAMPS=1 (diagnostic, scripts/dev_lane_stamps.py): timing events at the begin of every program run and at the fork and the join of each of its
+// fork/join lanes; msl_lane_stamps() reads them for the LAST run.  Off: no event is created or recorded.
+static int g_stamps = -1;
+static hipEvent_t g_st0[16], g_st1[16], g_stb[16][MSL_MAX_LANES], g_ste[16][MSL_MAX_LANES];
+static bool g_st_used[16][MSL_MAX_LANES];
 
 static int lanes_init(int dev) {
   if (g_lanes_ready[dev]) return MSL_OK;
@@ -113,11 +127,25 @@ static int lanes_init(int dev) {
     msl_set_error("lanes: hipEventCreate failed");
     return MSL_ELAUNCH;
   }
-  for (int k = 1; k < MSL_MAX_LANES; ++k) {
-    if (hipStreamCreateWithFlags(&g_side[dev][k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_join[dev][k], hipEventDisableTiming) != hipSuccess) {
+  int nphys = MSL_SIDE_STREAMS;
+  if (const char* e = getenv("MSL_SIDE_STREAMS")) nphys = atoi(e);  // measurements: 7 = a stream per lane (the runtime then decides which lanes share a hardware queue)
+  if (nphys < 1 || nphys > MSL_MAX_LANES - 1) nphys = MSL_SIDE_STREAMS;
+  for (int k = 0; k < nphys; ++k)
+    if (hipStreamCreateWithFlags(&g_phys[dev][k], hipStreamNonBlocking) != hipSuccess) {
       msl_set_error("lanes: cannot create side stream %d", k);
       return MSL_ELAUNCH;
     }
+  for (int k = 1; k < MSL_MAX_LANES; ++k) {
+    g_side[dev][k] = g_phys[dev][(k - 1) % nphys];
+    if (hipEventCreateWithFlags(&g_join[dev][k], hipEventDisableTiming) != hipSuccess) {
+      msl_set_error("lanes: cannot create the join event of lane %d", k);
+      return MSL_ELAUNCH;
+    }
+  }
+  if (g_stamps < 0) { const char* e = getenv("MSL_LANE_STAMPS"); g_stamps = e && atoi(e) ? 1 : 0; }
+  if (g_stamps) {
+    (void)hipEventCreate(&g_st0[dev]); (void)hipEventCreate(&g_st1[dev]);
+    for (int k = 1; k < MSL_MAX_LANES; ++k) { (void)hipEventCreate(&g_stb[dev][k]); (void)hipEventCreate(&g_ste[dev][k]); }
   }
   g_lanes_ready[dev] = true;
   return MSL_OK;
@@ -131,30 +159,44 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
   if (rc != MSL_OK) return rc;
   hipStream_t main_s = (hipStream_t)stream;
   bool active[MSL_MAX_LANES] = {false, false, false, false, false, false, false, false};
+  if (g_stamps) {
+    (void)hipEventRecord(g_st0[dev], main_s);
+    for (int k = 0; k < MSL_MAX_LANES; ++k) g_st_used[dev][k] = false;
+  }
   auto join = [&](int from, int to) {
     for (int k = from; k < to; ++k)
       if (active[k]) {
+        if (g_stamps) (void)hipEventRecord(g_ste[dev][k], g_side[dev][k]);
         (void)hipEventRecord(g_join[dev][k], g_side[dev][k]);
         (void)hipStreamWaitEvent(main_s, g_join[dev][k], 0);
         active[k] = false;
       }
   };
+  bool region = false;  // a fork event of the open region has been recorded
   for (int32_t i = 0; i < n; ++i) {
     const int L = lanes[i] & 0xff, src = (lanes[i] >> 8) & 0xff;  // bits 8-15 (deferred ops): the fork/join lane whose work the op consumes (0 = `stream`)
-    if (lanes[i] < 0 || L >= MSL_MAX_LANES || src >= MSL_FIRST_DEFERRED) { msl_set_error("op %d: lane %d (source %d) out of range", i, L, src); join(1, MSL_MAX_LANES); return MSL_EINVAL; }
+    const bool main_free = (lanes[i] & MSL_LANE_MAIN_FREE) != 0;
+    if (lanes[i] < 0 || L >= MSL_MAX_LANES || src >= MSL_FIRST_DEFERRED || (main_free && L != 0) || (lanes[i] & ~(0xffff | MSL_LANE_MAIN_FREE))) {
+      msl_set_error("op %d: lane word 0x%x out of range", i, lanes[i]); join(1, MSL_MAX_LANES); return MSL_EINVAL;
+    }
     hipStream_t s = main_s;
-    if (L == 0) {
+    if (L == 0 && !main_free) {
       join(1, MSL_FIRST_DEFERRED);
+      region = false;
+    } else if (L == 0) {  // a chain of the region on the caller's stream: the fork point stays before it
+      if (!region) { (void)hipEventRecord(g_fork[dev], main_s); region = true; }
     } else if (L < MSL_FIRST_DEFERRED) {
-      if (!active[L]) {  // fork: the side lane sees everything issued to the main stream so far
-        (void)hipEventRecord(g_fork[dev], main_s);
+      if (!active[L]) {  // fork: the side lane sees everything issued to the main stream before the region
+        if (!region) { (void)hipEventRecord(g_fork[dev], main_s); region = true; }
         (void)hipStreamWaitEvent(g_side[dev][L], g_fork[dev], 0);
         active[L] = true;
+        if (g_stamps && !g_st_used[dev][L]) { (void)hipEventRecord(g_stb[dev][L], g_side[dev][L]); g_st_used[dev][L] = true; }
       }
       s = g_side[dev][L];
     } else {  // deferred: ordered after its source stream as of now, joined only at the end
       (void)hipEventRecord(g_fork_def[dev], src == 0 || !active[src] ? main_s : g_side[dev][src]);
       (void)hipStreamWaitEvent(g_side[dev][L], g_fork_def[dev], 0);
+      if (g_stamps && !g_st_used[dev][L]) { (void)hipEventRecord(g_stb[dev][L], g_side[dev][L]); g_st_used[dev][L] = true; }
       active[L] = true;
       s = g_side[dev][L];
     }
@@ -169,6 +211,24 @@ int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, vo
     }
   }
   join(1, MSL_MAX_LANES);
+  if (g_stamps) (void)hipEventRecord(g_st1[dev], main_s);
+  return MSL_OK;
+}
+
+// Diagnostic (MSL_LANE_STAMPS=1): milliseconds since the begin of the last msl_run_program_lanes call on this device — out[0] = 0, out[1] = its end (all
+// lanes joined), out[2k] / out[2k+1] = lane k's fork (first op may start) and last join, -1 where the lane was not used.  Synchronises on the events.
+int msl_lane_stamps(float* out, int32_t n) {
+  int dev = 0;
+  if (!out || n < 2 * MSL_MAX_LANES || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { msl_set_error("msl_lane_stamps: bad arguments"); return MSL_EINVAL; }
+  if (g_stamps != 1 || !g_lanes_ready[dev]) { msl_set_error("msl_lane_stamps: run a program with MSL_LANE_STAMPS=1 first"); return MSL_EINVAL; }
+  for (int k = 0; k < 2 * MSL_MAX_LANES; ++k) out[k] = -1.f;
+  if (hipEventSynchronize(g_st1[dev]) != hipSuccess || hipEventElapsedTime(&out[1], g_st0[dev], g_st1[dev]) != hipSuccess) { msl_set_error("msl_lane_stamps: no finished program"); return MSL_ELAUNCH; }
+  out[0] = 0.f;
+  for (int k = 1; k < MSL_MAX_LANES; ++k)
+    if (g_st_used[dev][k]) {
+      (void)hipEventElapsedTime(&out[2 * k], g_st0[dev], g_stb[dev][k]);
+      (void)hipEventElapsedTime(&out[2 * k + 1], g_st0[dev], g_ste[dev][k]);
+    }
   return MSL_OK;
 }
 

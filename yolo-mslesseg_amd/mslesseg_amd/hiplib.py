@@ -12,6 +12,7 @@ LIB_PATH = Path(__file__).resolve().parents[1] / "lib" / "libmslesseg_hip.so"
 MSL_BF16, MSL_F32, MSL_F32S = 0, 1, 2  # MSL_F32S: fp32 tensors, split-precision conv products on the f16 matrix cores (include/mslesseg_hip.h)
 PRED_STRIDE = 40
 ABI_VERSION = 2  # include/mslesseg_hip.h MSL_ABI_VERSION
+LANE_MAIN_FREE = 0x10000  # lane word (msl_run_program_lanes): on the caller's stream, as one of the open region's chains (MSL_LANE_MAIN_FREE)
 
 OP_CONV, OP_STEM, OP_DWCONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_ATTENTION = 1, 2, 3, 4, 5, 6
 OP_HEAD_DECODE, OP_NMS, OP_MASK_LOWRES, OP_MASK_UPSAMPLE, OP_MASK_MERGE, OP_LETTERBOX = 7, 8, 9, 10, 11, 12
@@ -25,7 +26,7 @@ EXPORTS = (
     "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_create_lanes", "msl_graph_launch",
     "msl_graph_destroy", "msl_event_create", "msl_event_record", "msl_event_elapsed_ms", "msl_event_destroy",
     "msl_seg_loss_workspace", "msl_conv2d_nhwc", "msl_letterbox_u8", "msl_nms", "msl_volume_consensus", "msl_volume_dice_sums",
-    "msl_conv2d_wgrad_nhwc", "msl_bn_act_fwd", "msl_bn_act_bwd", "msl_seg_loss", "msl_adamw", "msl_input_table_supported",
+    "msl_conv2d_wgrad_nhwc", "msl_bn_act_fwd", "msl_bn_act_bwd", "msl_seg_loss", "msl_adamw", "msl_input_table_supported", "msl_lane_stamps",
 )
 
 
@@ -68,6 +69,7 @@ def lib() -> C.CDLL:
         L.msl_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.msl_event_destroy.argtypes = [C.c_void_p]
         L.msl_input_table_supported.argtypes = [C.POINTER(MslOp)]
+        L.msl_lane_stamps.argtypes = [C.POINTER(C.c_float), C.c_int32]
         L.msl_seg_loss_workspace.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.msl_seg_loss_workspace.restype = C.c_int64
         # typed entry points (plain arguments; the Python host itself goes through descriptors — these are exercised by tests/test_gpu_capi_typed.py)

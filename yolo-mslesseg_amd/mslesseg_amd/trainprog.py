@@ -433,6 +433,10 @@ class TrainPlan(graph.Visitor):
         # the prototype branch on a lane of its own: its input gradient goes to a private buffer that is added to the P3 gradient after the join
         # (it used to share lane 1 with the level-0 head because both accumulate into that gradient — a 5.5 ms serial chain beside two ~1.5 ms ones)
         self._proto_own_lane = self.use_lanes and os.environ.get("MSL_PROTO_SHARED_LANE") is None
+        self._head_main = os.environ.get("MSL_HEAD_LANES", "main") == "main"  # level 0 of the head on the caller's stream (see _set_lane)
+        # its weight gradients stay inline like those of the other head chains; "defer" hands them to the deferred lanes like the trunk's (measured: the head
+        # region is throughput-bound either way — 5.0 ms of the backward program in every layout, profiles/r04ad_head_lanes.txt)
+        self._head_main_defer = os.environ.get("MSL_HEAD_MAIN_WGRAD", "inline") == "defer"
         self._late_adds = []
         self._keep: List[torch.Tensor] = []
         self.grads: Dict[int, torch.Tensor] = {}
@@ -502,14 +506,18 @@ class TrainPlan(graph.Visitor):
         return self._tabs[id(x.t)].data_ptr()
 
     def _set_lane(self, name: Optional[str]) -> int:
-        """Lane (side stream) of the layer being visited: the detection-head chains of pyramid level i run on lane 1+i, concurrently with
-        the other levels (their kernels at 40x40 / 20x20 are launch-latency bound); the prototype branch shares lane 1 with level 0
-        because both accumulate into the gradient of the same P3 feature.  Everything else: lane 0 = the caller's stream."""
+        """Lane word of the layer being visited (capi.hip: msl_run_program_lanes).  The detection-head chains of the three pyramid levels and the prototype
+        branch are independent; a process has 4 hardware queues — the caller's stream and the library's 3 side streams — so the four chains take one each:
+        level 0 (80x80, the longest) stays on the caller's stream as a chain of the region (MSL_LANE_MAIN_FREE: no join, the forks do not wait for it),
+        level 1 → lane 2, level 2 → lane 3, prototypes → lane 4 (= the first side stream).  Everything else: lane 0 = the caller's stream.
+        MSL_HEAD_LANES=side: the earlier layout, level i on lane 1 + i — with 3 side streams level 0 and the prototypes then share one (measurements)."""
         lane = 0
         if self.use_lanes and name:
             m = re.match(r"model\.\d+\.cv[234]\.(\d+)\.", name)
             if m:
                 lane = 1 + min(int(m.group(1)), 2)
+                if lane == 1 and self._head_main:
+                    lane = hiplib.LANE_MAIN_FREE
             elif re.match(r"model\.\d+\.proto\.", name):
                 lane = 4 if self._proto_own_lane else 1
         self._lane = lane
@@ -523,7 +531,8 @@ class TrainPlan(graph.Visitor):
         """Lane of a layer's weight-gradient op: trunk layers (lane 0) hand it to the deferred lane — nothing in the backward program reads a
         weight gradient, the program end joins it — while head layers keep it inside their own fork/join lane."""
         # (measured: deferring the head lanes' weight gradients as well is slower — 27.2 vs 26.5 ms per step: those lanes already overlap each other)
-        if not (self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None and (lane == 0 or os.environ.get("MSL_WGRAD_HEAD_DEFER") is not None)):
+        trunk_like = lane == 0 or (lane == hiplib.LANE_MAIN_FREE and self._head_main_defer)
+        if not (self.use_lanes and os.environ.get("MSL_WGRAD_INLINE") is None and (trunk_like or os.environ.get("MSL_WGRAD_HEAD_DEFER") is not None)):
             return lane
         if os.environ.get("MSL_WGRAD_ONE_LANE") is not None:
             return self.WGRAD_LANE
@@ -532,7 +541,7 @@ class TrainPlan(graph.Visitor):
 
     def _defer(self, op, lane: int):
         if self._wgrad_lane(lane) != lane:
-            op._force_lane = self._wgrad_lane(lane) | (lane << 8)  # bits 8-15: the lane that produced its inputs (capi.hip)
+            op._force_lane = self._wgrad_lane(lane) | ((lane & 0xff) << 8)  # bits 8-15: the lane that produced its inputs (capi.hip; 0 = the caller's stream)
             self._wg_rr = getattr(self, "_wg_rr", 0) + 1  # next weight gradient → the other deferred lane
         return op
 
@@ -795,7 +804,7 @@ class TrainPlan(graph.Visitor):
                                           i={0: self.N, 1: Ho, 2: Wo, 3: cpad, 10: gyw.cs, 11: gyw.co, 19: 1 if gy.f32 else 0, 21: ACC_SLOTS}))
                 ops.append(hiplib.make_op(hiplib.OP_F64_DRAIN, self.dtype, p=(acc.data_ptr(), 0, 0, 0, st.ptr(name + ".bias", st.g)), i={0: cout, 1: 1, 2: ACC_SLOTS, 3: cpad, 4: 1}))
                 if self._wgrad_lane(lane) != lane:  # bias gradient: nothing in the program reads it either
-                    ops[-2]._force_lane = ops[-1]._force_lane = self.WGRAD_LANE | (lane << 8)
+                    ops[-2]._force_lane = ops[-1]._force_lane = self.WGRAD_LANE | ((lane & 0xff) << 8)
                 dz, dz_f32 = gyw, 1 if gy.f32 else 0
             if dz_f32 and self.dtype != MSL_F32:  # the MFMA operands must be the compute dtype (as autocast feeds these convs upstream)
                 dzc = self._new(Ho, Wo, dz.C)
