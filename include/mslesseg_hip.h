@@ -149,7 +149,8 @@ enum {
    * i: 0 N,1 mh,2 mw,4 nm,7 max_det,10 x_cs,11 x_co, 8 Hlb, 9 Wlb */
   MSL_OP_MASK_LOWRES = 9,
   /* Boundary masks (B4): bilinear (align_corners=False) upsample of lowres to (Hlb,Wlb), > 0 → 1.0f/0.0f
-   * p: 0 lowres, 1 det, 2 keep_cnt, 3 offsets i32[N] (exclusive prefix sum of keep_cnt), 4 masks f32 [sum(keep_cnt),Hlb,Wlb]
+   * p: 0 lowres, 1 det, 2 keep_cnt, 3 offsets i32[N] (exclusive prefix sum of keep_cnt), 4 masks f32 [sum(keep_cnt),Hlb,Wlb],
+   *    5 (optional) live i32 [sum(keep_cnt)], zeroed by the caller: set to 1 for every instance whose mask has a pixel on (upstream drops the others)
    * i: 0 N,1 mh,2 mw,7 max_det,8 Hlb,9 Wlb */
   MSL_OP_MASK_UPSAMPLE = 10,
   /* Fused reference post-processing (combinar_predicciones + normalizar_prediccion): OR over instances of the

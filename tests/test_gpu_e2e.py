@@ -413,3 +413,40 @@ def test_graph_replay_equals_eager(eng_f32, golden):
     for _ in range(2):  # second pass re-uses the instantiated graph
         plan = eng_f32.predict_batch(torch.from_numpy(img[None]), graph_replay=True)
         assert int(plan.keep_cnt.cpu()[0]) == n and np.array_equal(plan.merged(*img.shape[:2]).cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_reference_call_masks_come_with_their_host_copy(golden_dir, golden, tmp_path):
+    """The reference's per-slice call [REF generar_predicciones.py:111-120]: `pred.masks.data` is a device tensor as upstream's, and its `.cpu()` is the
+    pinned copy that landed inside the call (yolo._Staged) — byte-equal to an ordinary transfer of the same tensor, a buffer of the caller's own (a second
+    call does not touch it), and equal to the masks of the plain boundary path (engine.Plan.masks())."""
+    from ultralytics import YOLO
+
+    from mslesseg_amd import params
+    from mslesseg_amd import yolo as Y
+
+    ck = tmp_path / "weights" / "best.pt"
+    params.save_checkpoint(ck, torch.load(golden_dir / "synth_n_nc1.pt", map_location="cpu", weights_only=True), "n", 1, {0: "lesion"})
+    model = YOLO(ck, precision="fp32")
+    imgs = [_img(golden, 1), _img(golden, 0), _img(golden, 1)[::-1].copy()]
+    kept = []
+    for im in imgs:
+        pred = model(im, verbose=False)[0]
+        if pred.masks is None:
+            continue
+        d = pred.masks.data
+        assert d.is_cuda and isinstance(d, Y._Staged) and d.dtype == torch.float32
+        host = d.cpu()
+        assert not host.is_cuda and host.is_pinned()
+        assert torch.equal(host, d.as_subclass(torch.Tensor).cpu())
+        assert set(np.unique(host.numpy()).tolist()) <= {0.0, 1.0}
+        plan = model._get_engine().predict_batch(torch.from_numpy(im[None]))
+        plain = plan.masks()[0]
+        live = plain.sum((-2, -1)) > 0
+        assert torch.equal(plain[live].cpu(), host)
+        assert len(pred.boxes) == host.shape[0]
+        kept.append((host, host.clone()))
+    assert kept, "the synthetic weights keep instances on noise slices"
+    for host, snap in kept:  # later calls did not write into earlier results
+        assert torch.equal(host, snap)
+    assert not (d * 2).cpu().is_pinned()  # a derived tensor has no staged copy: the ordinary path

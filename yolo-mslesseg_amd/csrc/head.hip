@@ -436,8 +436,8 @@ int msl_launch_mask_iou(const msl_op& op, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_upsample_kernel(const float* __restrict__ lowres, const float* __restrict__ det,
                                                             const int* __restrict__ keep_cnt, const int* __restrict__ offsets,
-                                                            float* __restrict__ masks, int mh, int mw, int max_det, int Hlb, int Wlb,
-                                                            float sy, float sx, float wr, float hr) {
+                                                            float* __restrict__ masks, int* __restrict__ live, int mh, int mw, int max_det, int Hlb,
+                                                            int Wlb, float sy, float sx, float wr, float hr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* sbox = (float4*)smem;
   const int n = blockIdx.y;
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(const float* __restr
     const float* m = lowres + ((long)n * max_det + d) * mh * mw;
     float v = sample_cropped(m, mw, t, sbox[d]);
     masks[(off + d) * (long)Hlb * Wlb + pix] = v > 0.f ? 1.f : 0.f;
+    if (live && v > 0.f) live[off + d] = 1;  // "this instance's mask is not empty": every writer stores the same value (the caller zeroed the flags)
   }
 }
 
@@ -464,7 +465,7 @@ int msl_launch_mask_upsample(const msl_op& op, hipStream_t s) {
   const float wr = (float)((double)mw / (double)Wlb), hr = (float)((double)mh / (double)Hlb);
   dim3 grid((Hlb * Wlb + 255) / 256, N);
   hipLaunchKernelGGL(mask_upsample_kernel, grid, dim3(256), (size_t)max_det * 16, s, (const float*)op.p[0], (const float*)op.p[1], (const int*)op.p[2],
-                     (const int*)op.p[3], (float*)op.p[4], mh, mw, max_det, Hlb, Wlb, sy, sx, wr, hr);
+                     (const int*)op.p[3], (float*)op.p[4], (int*)op.p[5], mh, mw, max_det, Hlb, Wlb, sy, sx, wr, hr);
   MSL_CHECK_LAUNCH("mask_upsample");
   return MSL_OK;
 }

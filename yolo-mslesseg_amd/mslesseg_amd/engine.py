@@ -184,6 +184,9 @@ class PackedWeights:
         self.t[name] = pack_gemm(wg, b, self.dtype, self.device)
 
 
+STAGE_HOST_BYTES = 256 << 20  # Plan.masks(stage_host=True): masks up to this many bytes per call get their pinned host copy at once
+
+
 def _lane_of(name: str) -> int:
     """Side-stream lane of an inference op (hiplib.Program lanes): the head chains of the three pyramid levels and the prototype branch
     are independent, and at 40x40 / 20x20 their kernels are launch-latency bound — level 0 → lane 1, prototypes → lane 2, levels 1 and 2 →
@@ -403,6 +406,7 @@ class Plan:
         self.program = hiplib.Program(b.ops, lanes=[getattr(o, "_lane", 0) for o in b.ops])
         self.op_names = list(b.names)
         self._merge = {}
+        self._host: Dict[str, torch.Tensor] = {}  # pinned host buffers of the boundary path (_pinned)
 
     def run(self, stream: Optional[int] = None, graph_replay: bool = False) -> None:
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
@@ -412,27 +416,60 @@ class Plan:
             self.program.run(s)
 
     # ---- boundary B4: per-image masks at the letterboxed size
-    def masks(self):
-        """→ list over images of float32 [n_i, Hlb, Wlb] CUDA tensors in {0,1} (or None when nothing was kept)."""
+    def _pinned(self, name: str, shape, dtype) -> torch.Tensor:
+        """A pinned host buffer of this plan, reused from call to call (counts, detection rows, offsets, flags: things the boundary reads and drops)."""
+        t = self._host.get(name)
+        if t is None or t.shape != torch.Size(shape):
+            t = torch.empty(shape, dtype=dtype, pin_memory=True)
+            self._host[name] = t
+        return t
+
+    def counts_and_rows(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """→ (kept counts int32 [N], detection rows float32 [N, max_det, PRED_STRIDE]) on the host: two asynchronous copies into pinned buffers of the
+        plan and ONE wait — the first host synchronisation of the boundary path (it is the wait for the network itself).  Valid until the next call."""
+        cnt, det = self._pinned("cnt", (self.N,), torch.int32), self._pinned("det", tuple(self.det.shape), torch.float32)
+        cnt.copy_(self.keep_cnt, non_blocking=True)
+        det.copy_(self.det, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return cnt, det
+
+    def masks(self, stage_host: bool = False, cnt: Optional[torch.Tensor] = None):
+        """→ list over images of float32 [n_i, Hlb, Wlb] CUDA tensors in {0,1} (or None when nothing was kept).
+        `stage_host`: → list of (device masks, pinned host copy of them — None beyond STAGE_HOST_BYTES per call —, host bool [n_i] "mask not empty") instead — the host copy and the flags ride behind
+        the upsample launch as asynchronous copies and the call returns when they have landed (the second and last synchronisation of the boundary
+        path): what the reference's `pred.masks.data.cpu().numpy()` [REF generar_predicciones.py:120] needs is then already on the host, in a buffer of
+        its own (torch's caching pinned allocator: not reused while the caller holds it)."""
         s = torch.cuda.current_stream(self.device).cuda_stream
-        cnt = self.keep_cnt.cpu()  # the one host sync of the boundary path
+        if cnt is None:
+            cnt = self.keep_cnt.cpu()  # the one host sync of the boundary path
         total = int(cnt.sum())
         if total == 0:
             return [None] * self.N
-        offsets = torch.zeros(self.N, dtype=torch.int32)
-        offsets[1:] = torch.cumsum(cnt, 0)[:-1]
-        off_dev = offsets.to(self.device)
+        offsets = self._pinned("off", (self.N,), torch.int32)
+        offsets[0] = 0
+        if self.N > 1:
+            offsets[1:] = torch.cumsum(cnt, 0)[:-1]
+        off_dev = torch.empty(self.N, dtype=torch.int32, device=self.device)
+        off_dev.copy_(offsets, non_blocking=True)
         out = torch.empty(total, self.Hlb, self.Wlb, dtype=torch.float32, device=self.device)
+        live_dev = torch.zeros(total, dtype=torch.int32, device=self.device) if stage_host else None
         op = hiplib.make_op(hiplib.OP_MASK_UPSAMPLE, self.dtype,
-                            p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), off_dev.data_ptr(), out.data_ptr()),
+                            p=(self.lowres.data_ptr(), self.det.data_ptr(), self.keep_cnt.data_ptr(), off_dev.data_ptr(), out.data_ptr(), live_dev.data_ptr() if stage_host else 0),
                             i={0: self.N, 1: self.proto.H, 2: self.proto.W, 7: self.max_det, 8: self.Hlb, 9: self.Wlb})
         hiplib.launch(op, s)
         self._last_offsets = off_dev  # read asynchronously by the launch above
-        res = []
-        for n in range(self.N):
-            c, o = int(cnt[n]), int(offsets[n])
-            res.append(out[o : o + c] if c else None)
-        return res
+        offs = [int(o) for o in offsets]
+        if not stage_host:
+            return [out[o : o + int(c)] if int(c) else None for o, c in zip(offs, cnt)]
+        host = None
+        if out.numel() * 4 <= STAGE_HOST_BYTES:  # the per-slice call of the reference; a large batch keeps its masks on the device until somebody asks
+            host = torch.empty(total, self.Hlb, self.Wlb, dtype=torch.float32, pin_memory=True)  # the caller's own: handed out through Masks.data.cpu()
+            host.copy_(out, non_blocking=True)
+        live = self._pinned("live", (total,), torch.int32)
+        live.copy_(live_dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        flags = live.bool().clone()
+        return [(out[o : o + int(c)], None if host is None else host[o : o + int(c)], flags[o : o + int(c)]) if int(c) else None for o, c in zip(offs, cnt)]
 
     # ---- fused reference post-processing: merged, re-oriented uint8 slices
     def merged(self, H0: int, W0: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -39,6 +39,24 @@ def _precision(p: Optional[str], env: str, default: str) -> int:
     raise ValueError(f"unknown precision {p!r} (bf16 | fp32 | fp32s)")
 
 
+class _Staged(torch.Tensor):
+    """A device tensor whose host copy has already landed in a pinned buffer of its own (engine.Plan.masks(stage_host=True)): `.cpu()` hands that copy out
+    instead of starting a second, pageable transfer — the reference's `pred.masks.data.cpu().numpy()` [REF generar_predicciones.py:120] then costs
+    nothing.  Everything else is the device tensor it aliases; tensors derived from it have no staged copy and take the ordinary path."""
+
+    @staticmethod
+    def wrap(dev: torch.Tensor, host: torch.Tensor) -> "_Staged":
+        t = dev.as_subclass(_Staged)
+        t._host = host
+        return t
+
+    def cpu(self, *args, **kwargs):
+        host = getattr(self, "_host", None)
+        if host is None or args or kwargs:
+            return self.as_subclass(torch.Tensor).cpu(*args, **kwargs)
+        return host
+
+
 class Masks:
     """`.data`: float32 [n, Hlb, Wlb] in {0,1} at the LETTERBOXED size (the reference resizes from there itself)."""
 
@@ -175,26 +193,26 @@ class YOLO:
         for shape, idxs in by_shape.items():
             batch = torch.from_numpy(np.stack([imgs[i] for i in idxs]))
             plan = eng.predict_batch(batch)
-            masks = plan.masks()  # syncs on keep_cnt
-            cnt = plan.keep_cnt.cpu()
-            det = plan.det.cpu()
+            # two host synchronisations per call: the counts + detection rows (the wait for the network), then the masks with their host copy and
+            # "not empty" flags (engine.Plan.masks); everything else below is host arithmetic on what those two brought back
+            cnt, det = plan.counts_and_rows()
+            masks = plan.masks(stage_host=True, cnt=cnt)
             lb = geometry.letterbox_for(shape[0], shape[1])
             for j, i in enumerate(idxs):
                 n = int(cnt[j])
                 if n == 0:
                     results[i] = Results(imgs[i], self.names, None, None)
                     continue
-                rows, mk = det[j, :n], masks[j]
+                rows, (mk, mk_host, live) = det[j, :n].clone(), masks[j]
                 # instances whose mask came out empty are dropped together with their boxes, as the oracle's reading of 8.3.70's
                 # construct_result does (oracle/prepost.py postprocess_one); invisible after the reference's np.maximum merge, visible in len()
-                live = (mk.sum((-2, -1)) > 0).cpu()
                 if not bool(live.any()):
                     results[i] = Results(imgs[i], self.names, None, None)
                     continue
                 if not bool(live.all()):
-                    rows, mk = rows[live], mk[live.to(mk.device)]
+                    rows, mk, mk_host = rows[live], mk[live.to(mk.device)], None if mk_host is None else mk_host[live]
                 boxes = torch.cat([_scale_boxes(lb, rows[:, :4]), rows[:, 4:6]], 1)
-                results[i] = Results(imgs[i], self.names, Boxes(boxes, shape[:2]), Masks(mk, shape[:2]),
+                results[i] = Results(imgs[i], self.names, Boxes(boxes, shape[:2]), Masks(mk if mk_host is None else _Staged.wrap(mk, mk_host), shape[:2]),
                                      path=srcs[i] if isinstance(srcs[i], (str, Path)) else None)
         return results  # type: ignore[return-value]
 
