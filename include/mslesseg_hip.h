@@ -251,8 +251,8 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream);
  * between two joins — opened, the next lane-0 op waits for all of them: independent chains overlap; MSL_LANE_MAIN_FREE (0x10000) = an op on `stream` that is
  * itself one of the region's chains: it neither joins nor delays the lanes forked after it; 5..7 = deferred lanes: each op waits for what `stream` (or the
  * running fork/join lane in bits 8-15 of its lane word) holds so far, nothing waits for it until the end of the program — work whose result the program
- * itself never reads, e.g. weight gradients).  Lanes share 3 side streams by (lane - 1) % 3 — with `stream` the 4 hardware queues a process gets; lanes on
- * one stream run in enqueue order.  The call returns with every lane joined into `stream`. */
+ * itself never reads, e.g. weight gradients).  Lanes share 2 side streams by (lane - 1) % 2 (a process has 4 hardware queues; a third chain beside `stream`
+ * measured slower than two); lanes on one stream run in enqueue order.  The call returns with every lane joined into `stream`. */
 #define MSL_LANE_MAIN_FREE 0x10000
 int msl_run_program_lanes(const msl_op* ops, const int32_t* lanes, int32_t n, void* stream);
 

@@ -105,12 +105,13 @@ int msl_run_program(const msl_op* ops, int32_t n, void* stream) {
 //   The end of the program joins every lane.
 // Streams: the HIP runtime gives a process 4 hardware queues (GPU_MAX_HW_QUEUES; 8 or 16 were measured: the step goes from 22.4 to 35.8 ms — the queues are
 // then time-sliced); a fifth stream SHARES a queue with an earlier one and its kernels run strictly behind that stream's (scripts/dev_lane_stamps.py showed the
-// fourth head lane starting when the third had finished, profiles/r04ab_lane_stamps.txt).  So the lanes are mapped onto MSL_SIDE_STREAMS = 3 streams — with the
-// caller's stream exactly the 4 queues — by (lane - 1) % 3: which lanes serialise is a decision of the program (lanes 1 / 4 / 7, 2 / 5, 3 / 6), not of the
-// runtime's queue assignment.
+// fourth head lane starting when the third had finished, profiles/r04ab_lane_stamps.txt).  So the lanes are mapped onto MSL_SIDE_STREAMS streams by
+// (lane - 1) % MSL_SIDE_STREAMS: which lanes serialise is a decision of the program, not of the runtime's queue assignment.  2 streams (lanes 1 / 3 / 5 / 7 and
+// 2 / 4 / 6; with the caller's stream 3 of the 4 queues) measured 0.15 ms per train step faster than 3 on two boxes (22.49-22.58 against 22.65-22.79 ms,
+// profiles/r04al_side_streams.txt): the chains are throughput-bound, a third concurrent one only adds contention; 1 stream: +0.25 ms.
 #define MSL_MAX_LANES 8
 #define MSL_FIRST_DEFERRED 5
-#define MSL_SIDE_STREAMS 3
+#define MSL_SIDE_STREAMS 2
 static hipStream_t g_phys[16][MSL_MAX_LANES];
 static hipStream_t g_side[16][MSL_MAX_LANES];  // lane -> one of g_phys
 static hipEvent_t g_fork[16], g_fork_def[16], g_join[16][MSL_MAX_LANES];

@@ -434,6 +434,7 @@ class TrainPlan(graph.Visitor):
         # (it used to share lane 1 with the level-0 head because both accumulate into that gradient — a 5.5 ms serial chain beside two ~1.5 ms ones)
         self._proto_own_lane = self.use_lanes and os.environ.get("MSL_PROTO_SHARED_LANE") is None
         self._head_main = os.environ.get("MSL_HEAD_LANES", "main") == "main"  # level 0 of the head on the caller's stream (see _set_lane)
+        self._head_ids = [int(v) for v in os.environ.get("MSL_HEAD_LANE_IDS", "2,3,4").split(",")]  # lanes of level 1, level 2, prototypes (measurements)
         # its weight gradients stay inline like those of the other head chains; "defer" hands them to the deferred lanes like the trunk's (measured: the head
         # region is throughput-bound either way — 5.0 ms of the backward program in every layout, profiles/r04ad_head_lanes.txt)
         self._head_main_defer = os.environ.get("MSL_HEAD_MAIN_WGRAD", "inline") == "defer"
@@ -507,10 +508,10 @@ class TrainPlan(graph.Visitor):
 
     def _set_lane(self, name: Optional[str]) -> int:
         """Lane word of the layer being visited (capi.hip: msl_run_program_lanes).  The detection-head chains of the three pyramid levels and the prototype
-        branch are independent; a process has 4 hardware queues — the caller's stream and the library's 3 side streams — so the four chains take one each:
-        level 0 (80x80, the longest) stays on the caller's stream as a chain of the region (MSL_LANE_MAIN_FREE: no join, the forks do not wait for it),
-        level 1 → lane 2, level 2 → lane 3, prototypes → lane 4 (= the first side stream).  Everything else: lane 0 = the caller's stream.
-        MSL_HEAD_LANES=side: the earlier layout, level i on lane 1 + i — with 3 side streams level 0 and the prototypes then share one (measurements)."""
+        branch are independent; the library maps its lanes onto 2 side streams (capi.hip: a process has 4 hardware queues, and three concurrent chains measured
+        best): level 0 (80x80, the longest) stays on the caller's stream as a chain of the region (MSL_LANE_MAIN_FREE: no join, the forks do not wait for
+        it), level 1 → lane 2 and the prototypes → lane 4 (second side stream, one after the other), level 2 → lane 3 (first side stream).  Everything else:
+        lane 0 = the caller's stream.  MSL_HEAD_LANES=side: the earlier layout, level 0 on lane 1 (measurements: +0.5 ms per step)."""
         lane = 0
         if self.use_lanes and name:
             m = re.match(r"model\.\d+\.cv[234]\.(\d+)\.", name)
@@ -518,8 +519,10 @@ class TrainPlan(graph.Visitor):
                 lane = 1 + min(int(m.group(1)), 2)
                 if lane == 1 and self._head_main:
                     lane = hiplib.LANE_MAIN_FREE
+                elif lane > 1:
+                    lane = self._head_ids[lane - 2]
             elif re.match(r"model\.\d+\.proto\.", name):
-                lane = 4 if self._proto_own_lane else 1
+                lane = self._head_ids[2] if self._proto_own_lane else 1
         self._lane = lane
         if name:
             self._last_name = name
