@@ -378,11 +378,13 @@ class OnLoadScan(graph.Visitor):
         self._read(p, "loss", False)
 
     # -- decision
-    def pending(self) -> "set[str]":
+    def pending(self, max_hw: int = 0) -> "set[str]":
+        """`max_hw` > 0: only layers whose output map is at most max_hw high (the launch-latency-bound pyramid levels, where the reader's extra vector work
+        costs nothing and the BN_ACT launch it removes is a link of the serial chain)."""
         out = set()
         for pr in self.prod:
             v = pr["v"]
-            if not pr["bn"] or pr["res"]:
+            if not pr["bn"] or pr["res"] or (max_hw and v.H > max_hw):
                 continue
             passes, ok, n = 0.0, True, 0
             for rd in self.reads:
@@ -450,6 +452,7 @@ class TrainPlan(graph.Visitor):
         self.pending: "set[str]" = set()
         self._planes: Dict[int, list] = {}  # id(planar buffer tensor) -> its dense plane sub-tensors (one object each: buffers are identified by tensor id)
         self.pending_on = dtype == MSL_BF16 and os.environ.get("MSL_BN_ONLOAD", "0") == "1"  # (BatchNorm tables are per interleaved buffer: no planar concats beside them)
+        self.onload_max_hw = int(os.environ.get("MSL_BN_ONLOAD_MAX_HW", "0"))  # > 0: the form only on maps up to this height (planar concats stay above it)
         self._tabs: Dict[int, torch.Tensor] = {}   # id(buffer tensor) -> input BatchNorm table (f32 [cs][2] | u8 [cs / 8] flags)
         self._tab_flags: Dict[int, torch.Tensor] = {}  # host copy of the flags
         # Measured (round 4; scripts/dev_bn_on_load_ab.py → profiles/r04c_onload_ab.txt): with the activation's two quarter-rate transcendentals
@@ -458,7 +461,7 @@ class TrainPlan(graph.Visitor):
         if dtype == MSL_BF16 and os.environ.get("MSL_BN_ONLOAD", "0") == "1":
             scan = OnLoadScan(N, H, W, dtype, float(os.environ.get("MSL_BN_ONLOAD_MAX_READS", "2.0")))
             graph.walk(scan, store.scale, store.nc)
-            self.pending = scan.pending()
+            self.pending = scan.pending(self.onload_max_hw)
             only = os.environ.get("MSL_BN_ONLOAD_ONLY")  # measurement switch: a regular expression the pending layers' names must match
             if only:
                 self.pending = {n for n in self.pending if re.search(only, n)}
@@ -935,7 +938,7 @@ class TrainPlan(graph.Visitor):
         algorithmic traffic — round-3 verdict, item 3): such a concat is stored PLANAR — every member a dense plane (View.pl) — and only the 1x1 conv that reads
         the whole concat, its weight gradient and its input gradient address it plane by plane (conv1x1.hip, conv_wgrad_tr.hip; the BatchNorm passes of cv1)."""
         es = 4 if self.dtype == MSL_F32 else 2
-        if member and self.dtype == MSL_BF16 and member % 8 == 0 and C % member == 0 and member * es < 128 and os.environ.get("MSL_PLANAR_CAT", "1") != "0" and not self.pending_on:
+        if member and self.dtype == MSL_BF16 and member % 8 == 0 and C % member == 0 and member * es < 128 and os.environ.get("MSL_PLANAR_CAT", "1") != "0" and not (self.pending_on and (not self.onload_max_hw or like.H <= self.onload_max_hw)):
             t = torch.empty(self.N * like.H * like.W * C, dtype=_dt(self.dtype), device=self.device)
             g = torch.empty_like(t)
             self._keep += [t, g]
