@@ -38,6 +38,8 @@ for i in range(n):
     plan = eng.predict_batch(batch); t = clk("predict_batch (enqueue)", t)
     cnt, det = plan.counts_and_rows(); t = clk("counts_and_rows (waits for the engine)", t)
     masks = plan.masks(stage_host=True, cnt=cnt); t = clk("masks(stage_host): upsample + D2H of masks and flags", t)
+    if masks[0] is None:
+        continue
     mk, mk_host, live = masks[0]
     out = mk_host.numpy(); t = clk("numpy()", t)
 for k, v in T.items():

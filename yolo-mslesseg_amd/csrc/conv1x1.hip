@@ -440,15 +440,18 @@ struct G1Args {
 // LDS: 192 → 128, 384 → 128, 256 → 256, 384 / 512 → 256 ...) ran through conv_igemm_kernel before, at 50-60 TF/s (fp32) / 65-83 TF/s (split).
 // BN = 64 (fp32 forms): layers of at most 64 output channels (model.16.cv1, 256 -> 64 @80²) — the four waves take 32 pixels x 64 channels each instead of
 // computing a half-empty 128-channel tile (the fp32 form is matrix-core bound: 0.45 ms for that layer with BN = 128).
-template <bool STATS, int MODE = 0, int BN = 128>
+// BM = 64 (with BN = 64): 16 pixels per wave — the one-slice-per-call plans, whose layers are a handful of 128-pixel tiles each walking all of K on the fp32 matrix
+// instruction (20² 512 -> 256: 16 workgroups x 16 chunks x 64 MFMAs of 32 cycles per wave): twice the workgroups, half the chain.
+template <bool STATS, int MODE = 0, int BN = 128, int BM = 128>
 __global__ __launch_bounds__(256) void gemm1x1_kernel(G1Args a) {
   static_assert(!(STATS && MODE), "the statistics epilogue is the bf16 training path");
   static_assert(BN == 128 || (BN == 64 && MODE != 0), "64-channel tiles: fp32 forms");
+  static_assert(BM == 128 || (BM == 64 && BN == 64), "64-pixel tiles: a form of the 64-channel tiles");
   constexpr int ES = MODE ? 4 : 2, EPC = 16 / ES;
-  constexpr int BM = 128, BK = 128 / ES, PITCH = BK * ES + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
+  constexpr int BK = 128 / ES, PITCH = BK * ES + 16, CPR = PITCH / 16;  // 9 chunks per row, the 9th is padding
   constexpr int PIECES = BM * CPR / 64, PIECES_W = BN * CPR / 64;                    // 18 per pixel tile, 18 | 9 per weight tile
   constexpr int TILE = PIECES_W * 1024, STAGE = TILE + PIECES * 1024;                // stage image: weight tile | pixel tile
-  constexpr int NPT = BN == 128 ? 4 : 2;                                             // 16-pixel tiles per wave
+  constexpr int NPT = BN == 128 ? 4 : (BM == 64 ? 1 : 2);                            // 16-pixel tiles per wave
   constexpr int KP = (PIECES + 3) / 4;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -738,7 +741,10 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
   const bool f32 = op.dtype != MSL_BF16;
   const bool narrow = f32 && (a.Cout <= 64 || ((a.M + 127) / 128 * ((a.Cout + 127) / 128) < 128 && op.i[23] != -3));
   a.ntn = narrow ? (a.Cout + 63) / 64 : (a.Cout + 127) / 128;
-  const long tiles = (a.M + 127) / 128 * a.ntn;
+  static int half_env = -1;  // MSL_GEMM1X1_HALF=0: measurements
+  if (half_env < 0) { const char* e = getenv("MSL_GEMM1X1_HALF"); half_env = e ? atoi(e) : 1; }
+  const bool half = narrow && half_env && op.i[23] != -3 && (a.M + 127) / 128 * a.ntn < 128;  // still few workgroups: 64-pixel tiles
+  const long tiles = (half ? (a.M + 63) / 64 : (a.M + 127) / 128) * a.ntn;
   MSL_REQUIRE(tiles < (1L << 31), "gemm1x1: too many tiles");
   constexpr size_t LDS = 2 * 2 * 18 * 1024 + 128 * 4 + 2048 * 8 + 256;  // (the 64-channel forms use 2 x 27 KiB of it) + the input BatchNorm table (K <= 2048) and its group flags
   static bool attr = false;
@@ -749,9 +755,13 @@ int msl_launch_gemm1x1(const msl_op& op, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 1, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    (void)hipFuncSetAttribute((const void*)gemm1x1_kernel<false, 2, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     attr = true;
   }
-  if (narrow && op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  if (half && op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2, 64, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else if (half) hipLaunchKernelGGL((gemm1x1_kernel<false, 1, 64, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  else if (narrow && op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   else if (narrow) hipLaunchKernelGGL((gemm1x1_kernel<false, 1, 64>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   else if (op.dtype == MSL_F32S) hipLaunchKernelGGL((gemm1x1_kernel<false, 2>), dim3((unsigned)tiles), dim3(256), LDS, s, a);
   else if (op.dtype == MSL_F32) hipLaunchKernelGGL((gemm1x1_kernel<false, 1>), dim3((unsigned)tiles), dim3(256), LDS, s, a);

@@ -1226,7 +1226,14 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   // rows per wave: bigger tiles amortise the weight slab over more MFMAs; small maps keep the 8-row tile to limit waste
   // i[23]=-4 opts into the 16x32 tile at stride 1 (measured slower: kept for experiments); i[23]=-5 into the 8x32 tile at stride 2 (17-row halo, 73 KiB: one
   // workgroup per CU, but the weight slab and the halo's shared rows are staged once per 256 instead of 128 output pixels)
-  const int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : (op.i[23] == -5 ? 2 : 1);
+  int rw = stride == 1 ? (op.i[23] == -4 && cot == 4 ? 4 : 2) : (op.i[23] == -5 ? 2 : 1);
+  // few-workgroup launches of the 16-channel-block forms (a single slice: 3-120 workgroups of 8 x 32 pixels, each a serial run of chunks x 144 fp32 MFMAs): 4 x 32
+  // tiles double the workgroups and halve each one's chain (MSL_CONV3_SMALL_TILE=0: measurements)
+  static int small_env = -1;
+  if (small_env < 0) { const char* e = getenv("MSL_CONV3_SMALL_TILE"); small_env = e ? atoi(e) : 1; }
+  if (small_env && stride == 1 && rw == 2 && cot == 1 && !a.bn_tab && !a.w2 && !a.acc && op.i[23] <= 0 && op.i[23] > -4 && (f32 || a.Cin >= 32) &&
+      (long)a.N * ((a.Wo + 31) / 32) * ((a.Ho + 7) / 8) * ((a.Cout + 15) / 16) < 256)
+    rw = 1;
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1309,7 +1316,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     // accumulator tiles per wave, one wave per SIMD); an 8-wave pipelined persistent kernel (one slab per 16 x 32 pixels shared by 8 waves, (halo + slab)
     // units double-buffered, asm LDS-DMA): 1.014 ms against 0.965 — and intermittently wrong in one 16-pixel row of a tile (two accumulator registers
     // of one wave; not resolved), so it was removed.  What did pay is in the kernel itself: taps paired on the K = 32 f16 instruction (0.965 -> 0.81 ms).
-    if (stride == 2) L3S(2, 1); else L3S(1, 2);
+    if (stride == 2) L3S(2, 1); else if (rw == 1) return launch3<true, 1, 1, 1, 3, 3, true>(a, cout_blocks, s); else L3S(1, 2);
 #undef L3S
   }
   // narrow bf16 layers (8 or 16 input channels = one or two of the chunk's four k-groups): dense halo slots (halo_byte_kg); i[23] = -7 keeps the
@@ -1342,8 +1349,8 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (stride == 2) L3B(2, 1); else L3B(1, 2);
   }
 #undef L3B
-  if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else L3(true, 1, 2); }
-  else     { if (stride == 2 && rw == 2) L3(false, 2, 2); else if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else L3(false, 1, 2); }
+  if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else if (rw == 1) return launch3<true, 1, 1, 1>(a, cout_blocks, s); else L3(true, 1, 2); }
+  else     { if (stride == 2 && rw == 2) L3(false, 2, 2); else if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else if (rw == 1) return launch3<false, 1, 1, 1>(a, cout_blocks, s); else L3(false, 1, 2); }
 #undef L3
   return MSL_OK;
 }

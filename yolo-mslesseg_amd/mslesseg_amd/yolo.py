@@ -192,7 +192,9 @@ class YOLO:
             by_shape.setdefault(im.shape, []).append(i)
         for shape, idxs in by_shape.items():
             batch = torch.from_numpy(np.stack([imgs[i] for i in idxs]))
-            plan = eng.predict_batch(batch)
+            # the per-slice call of the reference replays the network program as a hipGraph (captured on the first call of a shape; bit-identical to the
+            # eager program, tests/test_gpu_e2e.py::test_graph_replay_equals_eager): ~110 launches become one, 0.1 ms of 1.6 per slice
+            plan = eng.predict_batch(batch, graph_replay=len(idxs) == 1 and os.environ.get("MSLESSEG_PREDICT_GRAPH", "1") != "0")
             # two host synchronisations per call: the counts + detection rows (the wait for the network), then the masks with their host copy and
             # "not empty" flags (engine.Plan.masks); everything else below is host arithmetic on what those two brought back
             cnt, det = plan.counts_and_rows()
