@@ -45,10 +45,10 @@ struct Conv3Args {
                         // act(x * scale + shift) before the tile is published — units that came from the zero page (padding) stay zero
 };
 
-template <int S, int RW, int KH = 3>
+template <int S, int RW, int KH = 3, int TWV = 32>
 struct Tile3 {
-  static constexpr int TW = 32, TH = 4 * RW;
-  static constexpr int ROWP = 34;                                  // slots per halo row (s1; 32 + KW - 1 <= 34) / per parity row (s2)
+  static constexpr int TW = TWV, TH = 4 * RW;                      // TWV = 16: the half-width tile of the few-workgroup launches (conv3x3_lds_kernel)
+  static constexpr int ROWP = TWV + 2;                             // slots per halo row (s1; TW + KW - 1 <= TW + 2) / per parity row (s2)
   static constexpr int ROWS = S == 1 ? TH + KH - 1 : 2 * TH + 1;   // halo rows
   static constexpr int SLOTS = S == 1 ? ROWS * ROWP : ROWS * 2 * ROWP;
   static constexpr int PIECES = (SLOTS + 15) / 16;                 // LDS-DMA pieces of 16 halo pixels x 64 B (1 KiB)
@@ -172,20 +172,22 @@ __device__ __forceinline__ void store_pixel(const Conv3Args& a, long pix, int co
   store_pixel_b<F32, COT>(a, pix, co0, accp, s1, s2, bias);
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4, bool BNT = false>  // BNT: input BatchNorm table (its own instantiation: ~20 registers); KG: k-groups per halo slot (halo_byte_kg); SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4, bool BNT = false, int TWV = 32>  // TWV = 16: 16-column tiles, one pixel tile per wave and row (few-workgroup launches); BNT: input BatchNorm table (its own instantiation: ~20 registers); KG: k-groups per halo slot (halo_byte_kg); SPLIT: fp32 tensors, split-precision products (msl_common.h): the weight
 // image arrives pre-split from the host; every lane rewrites the 16 bytes of the halo tile it staged itself as (hi x 4 | lo x 4) once per chunk,
 // so the nine taps read ready-made f16 operands and the MFMA loop carries no conversion
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   static_assert(!SPLIT || F32, "split-precision products are a mode of the fp32 engine");
   static_assert(KG == 4 || (!F32 && (KG == 1 || KG == 2)), "dense halo slots: bf16 layers of 8 or 16 input channels");
   static_assert(!BNT || (!F32 && KH == 3 && KW == 3), "input BatchNorm table: the plain bf16 3x3 forward conv");
-  using T = Tile3<S, RW, KH>;
+  static_assert(TWV == 32 || (TWV == 16 && KG == 4 && !BNT), "16-column tiles: the plain full-width-slot forms");
+  using T = Tile3<S, RW, KH, TWV>;
+  constexpr int CT = TWV / 16;            // 16-pixel column tiles per row
   constexpr int NT = KH * KW;            // taps: 3x3 (pad 1), or the 1x1 / 1x2 / 2x1 / 2x2 kernels (pad 0) of the stride-2 input gradient's parity classes
   constexpr int PAD = KH == 3 ? 1 : 0;
   constexpr int ES = F32 ? 4 : 2;
   constexpr int CHUNK = 64 / ES;          // channels per chunk (4 groups x 16 B)
   constexpr int COB = COT * 16;
-  constexpr int PT = 2 * RW;              // pixel tiles per wave: RW rows x 2 column halves
+  constexpr int PT = CT * RW;             // pixel tiles per wave: RW rows x CT column tiles
   constexpr int SPP = 64 / KG;            // halo slots per 1-KiB LDS-DMA piece (4 rows of 16 / KG slots)
   constexpr int IN_PIECES = (T::SLOTS + SPP - 1) / SPP;
   constexpr int IN_BYTES = IN_PIECES * 1024;
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
       for (int c = 0; c < COT; ++c) A[c] = *(const uint4*)(s_w + (((t * 4 + g) * COB) + c * 16 + lp) * 16);
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
-        const int row = wave * RW + (p >> 1);     // output row inside the tile
-        const int col = (p & 1) * 16;             // first output col of the pixel tile (this lane: + lp)
+        const int row = wave * RW + p / CT;       // output row inside the tile
+        const int col = (p % CT) * 16;            // first output col of the pixel tile (this lane: + lp)
         int slot;
         if constexpr (S == 1) slot = (row + ty) * T::ROWP + col + tx;
         else slot = ((2 * row + ty) * 2 + (tx & 1)) * T::ROWP + col + (tx >> 1);
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
     if (a.res) {
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
-        int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
+        int oy = oy0 + wave * RW + p / CT, ox = ox0 + (p % CT) * 16 + lp;
         oy = oy < a.Ho ? oy : a.Ho - 1; ox = ox < a.Wo ? ox : a.Wo - 1;
         const long pix = a.lat < 0 ? ((long)n * a.Ho + oy) * a.Wo + ox : ((long)n * a.full_h + 2 * oy + (a.lat & 1)) * a.full_w + 2 * ox + (a.lat >> 1);
         load_res_bf16<COT>(a, pix, cob * COB + g * (4 * COT), rpre[p]);
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
-    const int oy = oy0 + wave * RW + (p >> 1), ox = ox0 + (p & 1) * 16 + lp;
+    const int oy = oy0 + wave * RW + p / CT, ox = ox0 + (p % CT) * 16 + lp;
     if (oy >= a.Ho || ox >= a.Wo) continue;
     const long pix = a.lat < 0 ? ((long)n * a.Ho + oy) * a.Wo + ox : ((long)n * a.full_h + 2 * oy + (a.lat & 1)) * a.full_w + 2 * ox + (a.lat >> 1);
     f32x4 accp[COT];
@@ -417,19 +419,20 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(Conv3Args a) {
   }
 }
 
-template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4, bool BNT = false>
+template <bool F32, int S, int RW, int COT, int KH = 3, int KW = 3, bool SPLIT = false, int KG = 4, bool BNT = false, int TWV = 32>
 static int launch3(const Conv3Args& a, int cout_blocks, hipStream_t s) {
-  using T = Tile3<S, RW, KH>;
+  using T = Tile3<S, RW, KH, TWV>;
   constexpr int LDS = (T::SLOTS + 64 / KG - 1) / (64 / KG) * 1024 + KH * KW * 4 * COT * 16 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG, BNT, TWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   Conv3Args b = a;
   b.cout_blocks = cout_blocks;
-  dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * cout_blocks));
-  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG, BNT>), grid, dim3(256), LDS, s, b);
+  b.tiles_x = (a.Wo + TWV - 1) / TWV;
+  dim3 grid((unsigned)((long)a.N * a.tiles_y * b.tiles_x * cout_blocks));
+  hipLaunchKernelGGL((conv3x3_lds_kernel<F32, S, RW, COT, KH, KW, SPLIT, KG, BNT, TWV>), grid, dim3(256), LDS, s, b);
   MSL_CHECK_LAUNCH("conv3x3_lds");
   return MSL_OK;
 }
@@ -1230,10 +1233,15 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
   // few-workgroup launches of the 16-channel-block forms (a single slice: 3-120 workgroups of 8 x 32 pixels, each a serial run of chunks x 144 fp32 MFMAs): 4 x 32
   // tiles double the workgroups and halve each one's chain (MSL_CONV3_SMALL_TILE=0: measurements)
   static int small_env = -1;
-  if (small_env < 0) { const char* e = getenv("MSL_CONV3_SMALL_TILE"); small_env = e ? atoi(e) : 1; }
-  if (small_env && stride == 1 && rw == 2 && cot == 1 && !a.bn_tab && !a.w2 && !a.acc && op.i[23] <= 0 && op.i[23] > -4 && (f32 || a.Cin >= 32) &&
-      (long)a.N * ((a.Wo + 31) / 32) * ((a.Ho + 7) / 8) * ((a.Cout + 15) / 16) < 256)
-    rw = 1;
+  if (small_env < 0) { const char* e = getenv("MSL_CONV3_SMALL_TILE"); small_env = e ? atoi(e) : 2; }
+  static long small_wgs = -1;  // a launch counts as "few workgroups" below this many (MSL_CONV3_SMALL_WGS: measurements)
+  if (small_wgs < 0) { const char* e = getenv("MSL_CONV3_SMALL_WGS"); small_wgs = e ? atol(e) : 256; }
+  bool half_w = false;  // ... and 16-column tiles when that is still fewer than 256 (both strides): one pixel tile per wave
+  if (small_env && cot == 1 && !a.bn_tab && !a.w2 && !a.acc && op.i[23] <= 0 && op.i[23] > -4 && (f32 || a.Cin >= 32)) {
+    const long cb = (a.Cout + 15) / 16, tx32 = (a.Wo + 31) / 32;
+    if (stride == 1 && rw == 2 && (long)a.N * tx32 * ((a.Ho + 7) / 8) * cb < small_wgs) rw = 1;
+    if (small_env > 1 && rw == 1 && (long)a.N * tx32 * ((a.Ho + 3) / 4) * cb < small_wgs) half_w = true;
+  }
   const int TH = 4 * rw;
   a.tiles_x = (a.Wo + 31) / 32;
   a.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1316,6 +1324,7 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     // accumulator tiles per wave, one wave per SIMD); an 8-wave pipelined persistent kernel (one slab per 16 x 32 pixels shared by 8 waves, (halo + slab)
     // units double-buffered, asm LDS-DMA): 1.014 ms against 0.965 — and intermittently wrong in one 16-pixel row of a tile (two accumulator registers
     // of one wave; not resolved), so it was removed.  What did pay is in the kernel itself: taps paired on the K = 32 f16 instruction (0.965 -> 0.81 ms).
+    if (half_w) { if (stride == 2) return launch3<true, 2, 1, 1, 3, 3, true, 4, false, 16>(a, cout_blocks, s); return launch3<true, 1, 1, 1, 3, 3, true, 4, false, 16>(a, cout_blocks, s); }
     if (stride == 2) L3S(2, 1); else if (rw == 1) return launch3<true, 1, 1, 1, 3, 3, true>(a, cout_blocks, s); else L3S(1, 2);
 #undef L3S
   }
@@ -1349,6 +1358,11 @@ int msl_launch_conv3x3_lds(const msl_op& op, hipStream_t s) {
     if (stride == 2) L3B(2, 1); else L3B(1, 2);
   }
 #undef L3B
+  if (half_w) {
+    if (f32) { if (stride == 2) return launch3<true, 2, 1, 1, 3, 3, false, 4, false, 16>(a, cout_blocks, s); return launch3<true, 1, 1, 1, 3, 3, false, 4, false, 16>(a, cout_blocks, s); }
+    if (stride == 2) return launch3<false, 2, 1, 1, 3, 3, false, 4, false, 16>(a, cout_blocks, s);
+    return launch3<false, 1, 1, 1, 3, 3, false, 4, false, 16>(a, cout_blocks, s);
+  }
   if (f32) { if (stride == 2) L3(true, 2, 1); else if (rw == 4) return launch3<true, 1, 4, 4>(a, cout_blocks, s); else if (rw == 1) return launch3<true, 1, 1, 1>(a, cout_blocks, s); else L3(true, 1, 2); }
   else     { if (stride == 2 && rw == 2) L3(false, 2, 2); else if (stride == 2) L3(false, 2, 1); else if (rw == 4) return launch3<false, 1, 4, 4>(a, cout_blocks, s); else if (rw == 1) return launch3<false, 1, 1, 1>(a, cout_blocks, s); else L3(false, 1, 2); }
 #undef L3
