@@ -191,7 +191,7 @@ class YOLO:
         for i, im in enumerate(imgs):
             by_shape.setdefault(im.shape, []).append(i)
         for shape, idxs in by_shape.items():
-            batch = torch.from_numpy(np.stack([imgs[i] for i in idxs]))
+            batch = torch.from_numpy(imgs[idxs[0]][None] if len(idxs) == 1 else np.stack([imgs[i] for i in idxs]))  # one slice: a view, not a copy
             # the per-slice call of the reference replays the network program as a hipGraph (captured on the first call of a shape; bit-identical to the
             # eager program, tests/test_gpu_e2e.py::test_graph_replay_equals_eager): ~110 launches become one, 0.1 ms of 1.6 per slice
             plan = eng.predict_batch(batch, graph_replay=len(idxs) == 1 and os.environ.get("MSLESSEG_PREDICT_GRAPH", "1") != "0")
