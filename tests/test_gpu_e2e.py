@@ -450,3 +450,26 @@ def test_reference_call_masks_come_with_their_host_copy(golden_dir, golden, tmp_
     for host, snap in kept:  # later calls did not write into earlier results
         assert torch.equal(host, snap)
     assert not (d * 2).cpu().is_pinned()  # a derived tensor has no staged copy: the ordinary path
+
+
+@pytest.mark.gpu
+def test_reference_call_without_the_staged_copy(golden_dir, golden, tmp_path, monkeypatch):
+    """Beyond engine.STAGE_HOST_BYTES per call (large batches) the masks stay on the device and `Masks.data` is an ordinary tensor: same masks, same boxes."""
+    from ultralytics import YOLO
+
+    from mslesseg_amd import engine as E
+    from mslesseg_amd import params
+    from mslesseg_amd import yolo as Y
+
+    ck = tmp_path / "weights" / "best.pt"
+    params.save_checkpoint(ck, torch.load(golden_dir / "synth_n_nc1.pt", map_location="cpu", weights_only=True), "n", 1, {0: "lesion"})
+    model = YOLO(ck, precision="fp32")
+    img = _img(golden, 1)
+    staged = model(img, verbose=False)[0]
+    monkeypatch.setattr(E, "STAGE_HOST_BYTES", 0)
+    plain = model(img, verbose=False)[0]
+    assert isinstance(staged.masks.data, Y._Staged) and not isinstance(plain.masks.data, Y._Staged) and plain.masks.data.is_cuda
+    assert torch.equal(staged.masks.data.cpu(), plain.masks.data.cpu())
+    assert torch.equal(staged.boxes.data, plain.boxes.data)
+    pair = model([img, img], verbose=False)  # a list of sources: one batched pass, each result with its own slice of the staged copy
+    assert all(torch.equal(r.masks.data.cpu(), staged.masks.data.cpu()) for r in pair)

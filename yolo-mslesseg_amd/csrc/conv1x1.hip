@@ -816,7 +816,11 @@ static int c1_launch(const C1Args& a, hipStream_t s) {
 }
 template <int NCP, bool SPLIT = false>
 static int c1_launch_f32(const C1Args& a, hipStream_t s) {
-  if (NCP <= 4 && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true, SPLIT>(a, s);
+  // (few workgroups — the one-slice-per-call plans — keep 16-pixel slices: a wave's chain of fp32 matrix instructions is what such a launch lasts; MSL_CONV1X1_F32_PT2=1: measurements)
+  static int pt2_env = -1;
+  if (pt2_env < 0) { const char* e = getenv("MSL_CONV1X1_F32_PT2"); pt2_env = e ? atoi(e) : 0; }
+  const bool few = !pt2_env && (a.M + 31) / 32 < 4 * 256;
+  if (NCP <= 4 && !few && c1_lds(NCP, a.Kpad, 2, 4, 4) * 2 <= 160 * 1024) return c1_launch<NCP, false, 2, true, SPLIT>(a, s);
   return c1_launch<NCP, false, 1, true, SPLIT>(a, s);
 }
 template <int NCP, bool STATS, bool PLANAR = false, bool BWS = false>
