@@ -383,8 +383,12 @@ class Plan:
         self.A = sum(v[0].H * v[0].W for v in b.levels.values())
         self.pred = torch.empty(N, self.A, PRED_STRIDE, dtype=torch.float32, device=dev)
         self.keep_idx = torch.zeros(N, max_det, dtype=torch.int32, device=dev)
-        self.keep_cnt = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.det = torch.zeros(N, max_det, PRED_STRIDE, dtype=torch.float32, device=dev)
+        # detection rows and kept counts in ONE buffer (rows first: they are read with 16-byte accesses): the boundary brings both back with one copy
+        nd = N * max_det * PRED_STRIDE
+        self._detcnt = torch.zeros(nd + N, dtype=torch.float32, device=dev)
+        self.det = self._detcnt[:nd].view(N, max_det, PRED_STRIDE)
+        self.keep_cnt = self._detcnt[nd:].view(torch.int32)
+        self._zero_off = torch.zeros(1, dtype=torch.int32, device=dev)  # the mask offsets of a one-image plan
         mh, mw = self.proto.H, self.proto.W
         self.lowres = torch.empty(N, max_det, mh, mw, dtype=torch.float32, device=dev)
         self.range = torch.empty(N, mh, mw, dtype=torch.int32, device=dev)  # first|last<<16 positive-instance range per proto pixel
@@ -427,11 +431,11 @@ class Plan:
     def counts_and_rows(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """→ (kept counts int32 [N], detection rows float32 [N, max_det, PRED_STRIDE]) on the host: two asynchronous copies into pinned buffers of the
         plan and ONE wait — the first host synchronisation of the boundary path (it is the wait for the network itself).  Valid until the next call."""
-        cnt, det = self._pinned("cnt", (self.N,), torch.int32), self._pinned("det", tuple(self.det.shape), torch.float32)
-        cnt.copy_(self.keep_cnt, non_blocking=True)
-        det.copy_(self.det, non_blocking=True)
+        host = self._pinned("detcnt", (self._detcnt.numel(),), torch.float32)
+        host.copy_(self._detcnt, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        return cnt, det
+        nd = self.det.numel()
+        return host[nd:].view(torch.int32), host[:nd].view(self.det.shape)
 
     def masks(self, stage_host: bool = False, cnt: Optional[torch.Tensor] = None):
         """→ list over images of float32 [n_i, Hlb, Wlb] CUDA tensors in {0,1} (or None when nothing was kept).
@@ -449,8 +453,10 @@ class Plan:
         offsets[0] = 0
         if self.N > 1:
             offsets[1:] = torch.cumsum(cnt, 0)[:-1]
-        off_dev = torch.empty(self.N, dtype=torch.int32, device=self.device)
-        off_dev.copy_(offsets, non_blocking=True)
+            off_dev = torch.empty(self.N, dtype=torch.int32, device=self.device)
+            off_dev.copy_(offsets, non_blocking=True)
+        else:
+            off_dev = self._zero_off
         out = torch.empty(total, self.Hlb, self.Wlb, dtype=torch.float32, device=self.device)
         live_dev = torch.zeros(total, dtype=torch.int32, device=self.device) if stage_host else None
         op = hiplib.make_op(hiplib.OP_MASK_UPSAMPLE, self.dtype,
