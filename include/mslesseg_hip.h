@@ -219,8 +219,7 @@ enum {
                                      its intersection with every ground-truth instance of the overlap-encoded label map.  p 0 lowres f32 [N,max_det,mh,mw], 1 det,
                                      2 keep_cnt, 3 labels u8 [N,mh,mw], 4 inter i32 [N,max_det,G], 5 parea i32 [N,max_det], 6 garea i32 [N,G] (areas of the ground-truth
                                      instances) ; i 0 N,1 mh,2 mw,3 G,7 max_det,8 Hlb,9 Wlb */
-  MSL_OP_BN_ACT_BWD_FUSED = 40,   /* BN_ACT_BWD_REDUCE + BN_ACT_BWD_APPLY in one launch with a grid barrier (slots of APPLY, no residual fan-out): small tensors whose second
-                                     read comes from cache; at most one in flight per device — put it on a program's main lane only (csrc/train_kernels.hip) */
+  /* 40: retired (BN_ACT_BWD_REDUCE + BN_ACT_BWD_APPLY in one launch with a software grid barrier: measured slower than the two launches in rounds 3 and 4) */
   MSL_OP_SEG_LOSS = 33            /* segmentation loss + d(loss)/d(head outputs): TAL assignment, CIoU, DFL, BCE, cropped mask BCE
                                      [replaces v8SegmentationLoss + loss.backward() under model.train(), REF scripts/train.py:358-366].
                                      p 0 level table (device int64[nlev][20]: box, cls, coef, gbox, gcls, gcoef pointers (fp32 NHWC views),

@@ -964,41 +964,6 @@ def test_conv3x3_with_fused_1x1_tail():
         hiplib.launch(op, _stream())
 
 
-@pytest.mark.parametrize("dtype", [MSL_F32, MSL_BF16])
-@pytest.mark.parametrize("shape", [(128, 20, 20, 256, 1), (64, 40, 40, 128, 1), (3, 17, 23, 48, 0), (16, 20, 20, 64, 1)])
-def test_bn_act_bwd_fused_equals_reduce_plus_apply(dtype, shape):
-    """MSL_OP_BN_ACT_BWD_FUSED (reduction, grid barrier, apply in one launch) against the two separate ops on the same inputs: dz, dgamma, dbeta to
-    fp32 summation-order noise; three launches in a row (the barrier's sense word flips per launch) and the barrier's error flag stays clear."""
-    N, H, W, C, act = shape
-    g = torch.Generator().manual_seed(N + C)
-    td = _tdt(dtype)
-    z = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.2).to(td).to(DEV)
-    dy = torch.randn(N, H, W, C, generator=g).to(td).to(DEV)
-    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.rand(C, generator=g) - 0.5).to(DEV)
-    zf = z.float().reshape(-1, C)
-    mean, var = zf.mean(0), zf.var(0, unbiased=False)
-    stats = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-3)], 1).reshape(-1).contiguous()
-    slots = 8
-    def run(kinds):
-        acc = torch.zeros(slots * 2 * C, dtype=torch.float64, device=DEV)
-        dz = torch.zeros_like(z)
-        dgb = torch.zeros(2 * C, device=DEV)
-        common = (dy.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), acc.data_ptr())
-        dims = {0: N, 1: H, 2: W, 3: C, 10: C, 11: 0, 12: C, 13: 0, 18: act, 21: slots}
-        for kind in kinds:
-            p = common if kind == hiplib.OP_BN_ACT_BWD_REDUCE else common + (dz.data_ptr(), dgb.data_ptr())
-            i = dims if kind == hiplib.OP_BN_ACT_BWD_REDUCE else {**dims, 14: C, 15: 0, 20: C}
-            hiplib.launch(hiplib.make_op(kind, dtype, p=p, i=i), _stream())
-        torch.cuda.synchronize()
-        return dz.float().cpu(), dgb.cpu()
-    want_dz, want_g = run([hiplib.OP_BN_ACT_BWD_REDUCE, hiplib.OP_BN_ACT_BWD_APPLY])
-    for rep in range(3):
-        got_dz, got_g = run([hiplib.OP_BN_ACT_BWD_FUSED])
-        tol = (1e-5 if dtype == MSL_F32 else 1e-2) * float(want_dz.abs().max()) + 1e-7
-        assert float((got_dz - want_dz).abs().max()) <= tol, (rep, float((got_dz - want_dz).abs().max()), tol)
-        assert torch.allclose(got_g, want_g, rtol=1e-5, atol=1e-5 * float(want_g.abs().max()))
-
-
 @pytest.mark.gpu
 def test_program_lanes_region_semantics():
     """msl_run_program_lanes (csrc/capi.hip): a region of independent chains — fork/join lanes 2 and 4 and a chain on the caller's stream itself

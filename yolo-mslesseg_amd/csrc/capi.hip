@@ -41,7 +41,6 @@ static int dispatch(const msl_op& op_in, hipStream_t s) {
     case MSL_OP_BN_ACT: return msl_launch_bn_act(op, s);
     case MSL_OP_BN_ACT_BWD_REDUCE: return msl_launch_bn_act_bwd_reduce(op, s);
     case MSL_OP_BN_ACT_BWD_APPLY: return msl_launch_bn_act_bwd_apply(op, s);
-    case MSL_OP_BN_ACT_BWD_FUSED: return msl_launch_bn_act_bwd_fused(op, s);
     case MSL_OP_COLSUM: return msl_launch_colsum(op, s);
     case MSL_OP_F64_DRAIN: return msl_launch_f64_drain(op, s);
     case MSL_OP_ADD_VIEW: return msl_launch_add_view(op, s);

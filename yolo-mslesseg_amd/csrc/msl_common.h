@@ -324,7 +324,6 @@ int msl_launch_bn_finalize(const msl_op& op, hipStream_t s);
 int msl_launch_bn_act(const msl_op& op, hipStream_t s);
 int msl_launch_bn_act_bwd_reduce(const msl_op& op, hipStream_t s);
 int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s);
-int msl_launch_bn_act_bwd_fused(const msl_op& op, hipStream_t s);
 int msl_launch_colsum(const msl_op& op, hipStream_t s);
 int msl_launch_f64_drain(const msl_op& op, hipStream_t s);
 int msl_launch_add_view(const msl_op& op, hipStream_t s);

@@ -504,174 +504,6 @@ int msl_launch_bn_act_bwd_apply(const msl_op& op, hipStream_t s) {
   return MSL_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// BN_ACT_BWD_FUSED: the reduction and the apply pass of a BatchNorm + activation backward in ONE launch, for tensors small enough that the apply
-// pass's second read of (dy, z) comes from L2 / the Infinity Cache: phase 1 = chan_reduce_kernel<MODE 1> (sums into the slot accumulators), a grid
-// barrier, phase 2 = bn_act_bwd_apply_kernel over the same pixels by the same threads.  Measurement kernel of round 3: at the 40² /
-// 20² levels the two launches are launch-granularity bound (~18 us each for ~6 us of traffic); the barrier costs what a kernel boundary costs, the
-// saving is the second launch's ramp and tail and a cache-resident re-read.
-//   * grid <= 256 workgroups of 256 threads (one per CU): all resident at once.  The caller (trainprog) only puts this op on the program's main lane,
-//     so never two of them wait at their barriers at the same time; other lanes' kernels are ordinary kernels that finish and free their CUs.
-//   * barrier: bar[0] arrival counter, bar[1] sense (flipped by the last arrival, which also resets the counter: reusable across launches on one
-//     stream without host involvement), bar[2] error flag.  The wait is BOUNDED (~50 ms): a workgroup that gives up sets bar[2] and goes on — wrong
-//     numbers that a test catches, never a hung GPU.
-//   * after the barrier the slot sums are read with agent-scope loads (the L2 of an XCD does not see the other XCDs' atomics otherwise).
-template <bool F32, int V>
-__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const void* __restrict__ dy, const void* z, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, double* acc, void* dz, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           long M, int C, int z_cs, int z_co, int dy_cs, int dy_co, int dz_cs, int dz_co, int act, int slots, int pacc,
-                                                           unsigned* bar) {
-  __shared__ float red[2][256][V];
-  __shared__ float ks[2048];
-  const int CV = C / V;
-  const int cq = threadIdx.x % CV, pl = threadIdx.x / CV, PL = 256 / CV;
-  const int c = cq * V;
-  float s1[V], s2[V], mu[V], is[V], ga[V], be[V];
-#pragma unroll
-  for (int r = 0; r < V; ++r) { s1[r] = 0.f; s2[r] = 0.f; mu[r] = 0.f; is[r] = 1.f; ga[r] = 1.f; be[r] = 0.f; }
-  if (pl < PL) {
-#pragma unroll
-    for (int r = 0; r < V; ++r) { mu[r] = stats[2 * (c + r)]; is[r] = stats[2 * (c + r) + 1]; ga[r] = gamma[c + r]; be[r] = beta[c + r]; }
-  }
-  // g = dy * act'(u), zhat = (z - mean) * invstd — the same expressions as the two separate kernels
-  auto gz = [&](const float (&d)[V], const float (&zv)[V], float (&g)[V], float (&zh)[V]) {
-#pragma unroll
-    for (int r = 0; r < V; r += 2) {
-      const f2_t z2 = {zv[r], zv[r + 1]}, d2 = {d[r], d[r + 1]};
-      const f2_t mu2 = {mu[r], mu[r + 1]}, is2 = {is[r], is[r + 1]};
-      const f2_t h = (z2 - mu2) * is2;
-      f2_t q = d2;
-      if (act) {
-        const f2_t ga2 = {ga[r], ga[r + 1]}, be2 = {be[r], be[r + 1]};
-        const f2_t u = ga2 * h + be2;
-        const f2_t t = u * -1.44269504088896f;
-        const f2_t den = (f2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-        const f2_t sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-        q = d2 * (sg * (u * (1.0f - sg) + 1.0f));
-      }
-      g[r] = q.x; g[r + 1] = q.y; zh[r] = h.x; zh[r + 1] = h.y;
-    }
-  };
-  const long step = (long)gridDim.x * PL;
-  constexpr int U = 4;
-  // ---- phase 1: per-channel sums of g and g * zhat
-  if (pl < PL) {
-    long p = (long)blockIdx.x * PL + pl;
-    for (; p < M; p += U * step) {
-      float va[U][V], vb[U][V];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        long q = p + u * step;
-        q = q < M ? q : M - 1;
-        ldv<F32, V>(dy, q * dy_cs + dy_co + c, va[u]);
-        ldv<F32, V>(z, q * z_cs + z_co + c, vb[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (p + u * step >= M) continue;
-        float g[V], zh[V];
-        gz(va[u], vb[u], g, zh);
-#pragma unroll
-        for (int r = 0; r < V; ++r) { s1[r] += g[r]; s2[r] = fmaf(g[r], zh[r], s2[r]); }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < V; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
-  __syncthreads();
-  if (threadIdx.x < CV) {
-    float t1[V], t2[V];
-#pragma unroll
-    for (int r = 0; r < V; ++r) { t1[r] = 0.f; t2[r] = 0.f; }
-    for (int j = 0; j < PL; ++j)
-#pragma unroll
-      for (int r = 0; r < V; ++r) { t1[r] += red[0][j * CV + threadIdx.x][r]; t2[r] += red[1][j * CV + threadIdx.x][r]; }
-    double* dst = acc + (long)(blockIdx.x % slots) * 2 * C;
-#pragma unroll
-    for (int r = 0; r < V; ++r) { atomicAdd(dst + 2 * (c + r), (double)t1[r]); atomicAdd(dst + 2 * (c + r) + 1, (double)t2[r]); }
-  }
-  // ---- grid barrier
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned sense = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read before arriving: it only flips after ALL arrived
-    __threadfence();                                                                               // this workgroup's atomics before its arrival
-    const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == gridDim.x - 1) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(bar + 1, sense ^ 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      int spins = 0;
-      while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == sense) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 20)) { __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // bounded: never hang the device
-      }
-    }
-    __threadfence();
-  }
-  __syncthreads();
-  // ---- phase 2: slot sums (agent-scope loads), parameter gradients, dz over the same pixels
-  for (int v = threadIdx.x; v < 2 * C; v += 256) {
-    double a = 0.0;
-    for (int j = 0; j < slots; ++j) a += __hip_atomic_load(acc + (long)j * 2 * C + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ks[v] = (float)a;
-    if (blockIdx.x == 0 && dgamma) {
-      float* q = (v & 1) ? dgamma + (v >> 1) : dbeta + (v >> 1);
-      *q = pacc ? *q + (float)a : (float)a;
-    }
-  }
-  __syncthreads();
-  if (pl >= PL) return;
-  const float invM = 1.0f / (float)M;
-  float k0[V], k2[V];
-#pragma unroll
-  for (int r = 0; r < V; ++r) { k0[r] = ks[2 * (c + r)] * invM; k2[r] = ks[2 * (c + r) + 1] * invM; }
-  for (long p = (long)blockIdx.x * PL + pl; p < M; p += U * step) {
-    float va[U][V], vb[U][V];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      long q = p + u * step;
-      q = q < M ? q : M - 1;
-      ldv<F32, V>(dy, q * dy_cs + dy_co + c, va[u]);
-      ldv<F32, V>(z, q * z_cs + z_co + c, vb[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long q = p + u * step;
-      if (q >= M) continue;
-      float g[V], zh[V], o[V];
-      gz(va[u], vb[u], g, zh);
-#pragma unroll
-      for (int r = 0; r < V; ++r) o[r] = ga[r] * is[r] * (g[r] - k0[r] - zh[r] * k2[r]);
-      stv<F32, V>(dz, q * dz_cs + dz_co + c, o);
-    }
-  }
-}
-
-static unsigned* g_bn_bar[16];
-// BN_ACT_BWD_FUSED: slots of BN_ACT_BWD_APPLY (p 0 dy, 1 z, 2 stats, 3 gamma, 4 beta, 5 acc, 6 dz, 7 dgamma; i 0-3 dims, 10/11 z view, 12/13 dy view, 14/15 dz view,
-// 17 accumulate parameter gradients, 18 act, 20 dbeta offset, 21 slots); no residual fan-out.  MAIN LANE ONLY (see the kernel's header).
-int msl_launch_bn_act_bwd_fused(const msl_op& op, hipStream_t s) {
-  const long M = (long)op.i[0] * op.i[1] * op.i[2];
-  const int C = op.i[3], slots = slots_of(op, 21);
-  MSL_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6] && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && slots <= MSL_MAX_SLOTS, "bn_act_bwd_fused: bad args");
-  MSL_REQUIRE(op.i[10] % 4 == 0 && op.i[11] % 4 == 0 && op.i[12] % 4 == 0 && op.i[13] % 4 == 0 && op.i[14] % 4 == 0 && op.i[15] % 4 == 0 && op.i[11] + C <= op.i[10] &&
-                  op.i[13] + C <= op.i[12] && op.i[15] + C <= op.i[14] && op.i[16] == 0, "bn_act_bwd_fused: bad views (no residual fan-out in this form)");
-  int dev = 0;
-  MSL_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "bn_act_bwd_fused: bad device");
-  if (!g_bn_bar[dev]) {  // one barrier block per device, allocated on first use (outside any capture) and zeroed once
-    MSL_REQUIRE(hipMalloc((void**)&g_bn_bar[dev], 256) == hipSuccess && hipMemset(g_bn_bar[dev], 0, 256) == hipSuccess, "bn_act_bwd_fused: cannot allocate the barrier block");
-  }
-  const bool v8 = vec8(C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15]);
-  int grid = reduce_grid(M, C, slots, v8 ? 8 : 4);
-  if (grid > 256) grid = 256;
-  float* dgamma = (float*)op.p[7];
-  float* dbeta = dgamma ? dgamma + op.i[20] : nullptr;
-#define BF(F, V) hipLaunchKernelGGL((bn_bwd_fused_kernel<F, V>), dim3((unsigned)grid), dim3(256), 0, s, op.p[0], op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4], (double*)op.p[5], op.p[6], dgamma, dbeta, M, C, op.i[10], op.i[11], op.i[12], op.i[13], op.i[14], op.i[15], op.i[18], slots, op.i[17], g_bn_bar[dev])
-  if (op.dtype == MSL_F32) { if (v8) BF(true, 8); else BF(true, 4); } else { if (v8) BF(false, 8); else BF(false, 4); }
-#undef BF
-  MSL_CHECK_LAUNCH("bn_act_bwd_fused");
-  return MSL_OK;
-}
 
 // COLSUM: out f32[C] += sum over pixels of a view (bias gradients).  p 0 a, 4 acc f64[C] ; i 0 N,1 H,2 W,3 C,10 cs,11 co,19 a_is_f32
 int msl_launch_colsum(const msl_op& op, hipStream_t s) {

@@ -20,7 +20,7 @@ OP_VOL_INSERT, OP_VOL_CONSENSUS, OP_VOL_DICE = 13, 14, 15
 OP_BN_STATS, OP_BN_FINALIZE, OP_BN_ACT, OP_BN_ACT_BWD_REDUCE, OP_BN_ACT_BWD_APPLY = 16, 17, 18, 19, 20
 OP_COLSUM, OP_F64_DRAIN, OP_ADD_VIEW, OP_UPSAMPLE2X_BWD, OP_SPPF_POOL_BWD = 21, 22, 23, 24, 25
 OP_CONV_WGRAD, OP_DW_WGRAD, OP_STEM_WGRAD, OP_CAST_PAD, OP_GATHER_CAST, OP_ADAMW, OP_EMA = 26, 27, 28, 29, 30, 31, 32
-OP_SEG_LOSS, OP_ATTENTION_BWD, OP_SLICE_EXTRACT, OP_SGD, OP_AUGMENT, OP_RASTER_MASKS, OP_MASK_IOU, OP_BN_ACT_BWD_FUSED = 33, 34, 35, 36, 37, 38, 39, 40
+OP_SEG_LOSS, OP_ATTENTION_BWD, OP_SLICE_EXTRACT, OP_SGD, OP_AUGMENT, OP_RASTER_MASKS, OP_MASK_IOU = 33, 34, 35, 36, 37, 38, 39
 
 EXPORTS = (
     "msl_abi_version", "msl_last_error", "msl_launch", "msl_run_program", "msl_run_program_lanes", "msl_graph_create", "msl_graph_create_lanes", "msl_graph_launch",

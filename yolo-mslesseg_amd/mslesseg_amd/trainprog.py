@@ -665,18 +665,10 @@ class TrainPlan(graph.Visitor):
         st = self.store
         gy = self.G(y)
         dz = z if dz is None else dz
-        fuse_max_off = int(os.environ.get("MSL_BN_BWD_FUSE_MAX", "0")) <= 0
         acc = self._acc_bwd(C, ACC_SLOTS)
         dims = {0: self.N, 1: z.H, 2: z.W, 3: C, 10: z.cs, 11: z.co, 12: gy.cs, 13: gy.co, 18: 1 if act else 0, 21: ACC_SLOTS, 26: gy.pl}
-        assert not z.pl and not dz.pl and (not gy.pl or fuse_max_off)
+        assert not z.pl and not dz.pl
         pcommon = (gy.t.data_ptr(), z.t.data_ptr(), stats.data_ptr(), st.ptr(name + ".gamma"), st.ptr(name + ".beta"), acc.data_ptr())
-        # MSL_BN_BWD_FUSE_MAX=<elements> (measurement switch, default off): reduction + apply of small main-lane layers as ONE launch with a grid barrier
-        # (MSL_OP_BN_ACT_BWD_FUSED; at most one such kernel may be in flight, hence lane 0 only; no residual fan-out in that form)
-        fuse_max = int(os.environ.get("MSL_BN_BWD_FUSE_MAX", "0"))
-        if fuse_max > 0 and lane == 0 and (res is None or res_inplace) and self.N * z.H * z.W * C <= fuse_max:
-            ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_FUSED, self.dtype, p=pcommon + (dz.t.data_ptr(), st.ptr(name + ".gamma", st.g)),
-                                      i={**dims, 14: dz.cs, 15: dz.co, 17: 1, 20: st.off(name + ".beta") - st.off(name + ".gamma")}))
-            return
         ops.append(hiplib.make_op(hiplib.OP_BN_ACT_BWD_REDUCE, self.dtype, p=pcommon, i=dims))
         papply, extra = pcommon, {}
         if res is not None and not res_inplace:
