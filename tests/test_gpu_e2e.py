@@ -438,6 +438,8 @@ def test_reference_call_masks_come_with_their_host_copy(golden_dir, golden, tmp_
         assert d.is_cuda and isinstance(d, Y._Staged) and d.dtype == torch.float32
         host = d.cpu()
         assert not host.is_cuda and host.is_pinned()
+        again = d.cpu()  # the staged copy is handed out once; a second call is an ordinary transfer into a tensor of its own
+        assert again.data_ptr() != host.data_ptr() and torch.equal(again, host)
         assert torch.equal(host, d.as_subclass(torch.Tensor).cpu())
         assert set(np.unique(host.numpy()).tolist()) <= {0.0, 1.0}
         plan = model._get_engine().predict_batch(torch.from_numpy(im[None]))

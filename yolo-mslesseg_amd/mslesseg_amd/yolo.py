@@ -54,6 +54,7 @@ class _Staged(torch.Tensor):
         host = getattr(self, "_host", None)
         if host is None or args or kwargs:
             return self.as_subclass(torch.Tensor).cpu(*args, **kwargs)
+        self._host = None  # handed out once: like upstream's, every .cpu() gives the caller a tensor of its own (a second call transfers again)
         return host
 
 
