@@ -1000,3 +1000,48 @@ def test_program_lanes_region_semantics():
     bad = hiplib.Program([add("a", "x")], lanes=[FREE | 2])  # the free flag belongs to lane 0 only
     with pytest.raises(hiplib.MslError):
         bad.run(s)
+
+
+@pytest.mark.gpu
+def test_lane_stamps_diagnostic():
+    """msl_lane_stamps (MSL_LANE_STAMPS=1, read once at library start — hence a process of its own): fork and join of every used lane of the last program lie inside
+    the program, in order; unused lanes read -1; without the variable the call is refused."""
+    import os
+    import subprocess
+    import sys as _sys
+    from pathlib import Path
+
+    ROOT = Path(__file__).resolve().parents[1]
+    code = r'''
+import ctypes, sys
+sys.path[:0] = [%r, %r]
+import torch
+from mslesseg_amd import hiplib
+from mslesseg_amd.hiplib import MSL_F32
+x = torch.randn(4, 64, 64, 32, device="cuda:0"); bufs = [torch.zeros_like(x) for _ in range(3)]
+def add(d, s_):
+    return hiplib.make_op(hiplib.OP_ADD_VIEW, MSL_F32, p=(d.data_ptr(), s_.data_ptr()), i={0: 4, 1: 64, 2: 64, 3: 32, 10: 32, 11: 0, 12: 32, 13: 0, 20: 0})
+ops = [(add(bufs[0], x), 0), (add(bufs[1], bufs[0]), 2), (add(bufs[2], bufs[0]), 3), (add(bufs[1], bufs[0]), 2), (add(bufs[0], bufs[1]), 0)]
+p = hiplib.Program([o for o, _ in ops], lanes=[l for _, l in ops])
+p.run(torch.cuda.current_stream().cuda_stream)
+out = (ctypes.c_float * 16)()
+rc = hiplib.lib().msl_lane_stamps(out, 16)
+print("RC", rc, " ".join("%%.4f" %% v for v in out))
+''' % (str(ROOT), str(ROOT / "yolo-mslesseg_amd"))
+    env = dict(os.environ, MSL_LANE_STAMPS="1")
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RC")]
+    assert line, r.stdout + r.stderr
+    parts = line[0].split()
+    assert parts[1] == "0"
+    v = [float(t) for t in parts[2:]]
+    end = v[1]
+    assert v[0] == 0.0 and end > 0
+    for k in (2, 3):
+        assert 0 <= v[2 * k] <= v[2 * k + 1] <= end + 1e-3, (k, v)
+    for k in (1, 4, 5, 6, 7):
+        assert v[2 * k] == -1.0 and v[2 * k + 1] == -1.0
+    env.pop("MSL_LANE_STAMPS")
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RC")]
+    assert line and line[0].split()[1] != "0", r.stdout + r.stderr
