@@ -632,7 +632,12 @@ int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
       return MSL_OK;
     }
   }
-  const int V = v8 ? 8 : 4;
+  // few workgroups (one-slice plans): 4 channels per thread — twice the waves, half the serial work of each (a thread's 2 x V outputs with their taps and the
+  // activation are one dependent instruction stream; MSL_DWCONV_V8=1: measurements)
+  static int v8_env = -1;
+  if (v8_env < 0) { const char* e = getenv("MSL_DWCONV_V8"); v8_env = e ? atoi(e) : 0; }
+  const bool few = !v8_env && ((long)N * H * ((W + 1) / 2) * (C / 8) + 255) / 256 < 256;
+  const int V = (v8 && !few) ? 8 : 4;
   const long total = (long)N * H * ((W + 1) / 2) * (C / V);
   MSL_REQUIRE(total < (1L << 31), "dwconv: too many items for 32-bit indexing");
   long nchunks = (total + 255) / 256;
@@ -641,7 +646,7 @@ int msl_launch_dwconv(const msl_op& op, hipStream_t s) {
   const unsigned grid = (unsigned)nwg;
   const size_t lds = (size_t)10 * C * 4;
 #define DW(F, VV) hipLaunchKernelGGL((dwconv_kernel<F, VV>), dim3(grid), dim3(256), lds, s, op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], op.p[4], N, H, W, C, x_cs, x_co, y_cs, y_co, res_cs, res_co, act, gsz, gstride, goff, flip, omap, (unsigned)total)
-  if (op.dtype == MSL_F32) { if (v8) DW(true, 8); else DW(true, 4); } else { if (v8) DW(false, 8); else DW(false, 4); }
+  if (op.dtype == MSL_F32) { if (V == 8) DW(true, 8); else DW(true, 4); } else { if (V == 8) DW(false, 8); else DW(false, 4); }
 #undef DW
   MSL_CHECK_LAUNCH("dwconv");
   return MSL_OK;
